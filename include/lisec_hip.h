@@ -1,0 +1,91 @@
+/*
+ * lisec_hip.h -- C ABI of the MI355X (gfx950) hot path of Lisec.
+ *
+ * The reference (bot15498/Lisec) has no FFI: its hot path is Python calling
+ * TensorFlow/Keras.  Every entry point below replaces one group of reference
+ * statements; the citation is file:line in the reference tree.
+ *
+ * Conventions
+ *   - plain C types only; every pointer marked "dev" is a device (HBM) pointer the
+ *     CALLER owns; nothing here allocates or frees device memory;
+ *   - every function takes the HIP stream to enqueue on (void* == hipStream_t) and
+ *     returns immediately after enqueueing; no host synchronisation inside;
+ *   - return value: 0 ok, < 0 error (LISEC_E*), message via lisec_last_error()
+ *     (thread local);
+ *   - scratch memory comes from the caller: *_workspace_bytes() says how much;
+ *   - tensors are channels-last fp32, exactly the Keras layouts of the reference:
+ *       activations (D,H,W,C) / (H,W,C); Dense kernel (in,out);
+ *       Conv3D kernel (kd,kh,kw,in,out); Conv2D (kh,kw,in,out);
+ *       Conv2DTranspose (kh,kw,out,in).
+ */
+#ifndef LISEC_HIP_H
+#define LISEC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LISEC_OK 0
+#define LISEC_EINVAL (-1)   /* bad argument / shape the kernels do not support */
+#define LISEC_ENOSPC (-2)   /* workspace or output capacity too small           */
+#define LISEC_EHIP (-3)     /* a HIP runtime call failed                        */
+
+typedef void* lisec_stream_t; /* hipStream_t */
+
+const char* lisec_last_error(void);
+/* ABI version, bumped on any signature change. */
+int lisec_abi_version(void);
+/* Fills name (<= cap bytes) with the device's gcnArchName; returns CU count or < 0. */
+int lisec_device_info(char* name, int cap);
+
+/* ------------------------------------------------------------------------------------------
+ * 1. Voxeliser  -- replaces get_voxel + VFE_preprocessing + sparse.to_dense
+ *    (model_training.py:103-152, :279; Predict.py:21-30).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    double xSize, ySize, zSize;            /* Constants.voxelx/y/z                      */
+    int maxVoxelX, maxVoxelY, maxVoxelZ;   /* Constants.nx//2, ny//2, nz                */
+    int sampleSize;                        /* Constants.maxPoints (T), <= 64            */
+} lisec_voxel_cfg;
+
+/* Header written by lisec_voxelize at the start of `info` (device int32[8]). */
+enum { LISEC_VI_NVOX = 0, LISEC_VI_NROWS = 1, LISEC_VI_NVALID = 2, LISEC_VI_MAXCOUNT = 3,
+       LISEC_VI_OVERFLOW = 4 };
+
+size_t lisec_voxelize_workspace_bytes(const lisec_voxel_cfg* cfg, int n_points);
+
+/*
+ * points      dev  n_points rows of `point_stride` elements, first three = x, y, z
+ *                  (dtype: 0 = float32, 1 = float64; the reference feeds float64,
+ *                  model_training.py:93-96)
+ * cap_voxels       capacity of the per-voxel outputs (V <= min(n_points, cells))
+ * info        dev  int32[8]   see LISEC_VI_*
+ * cell_voxel  dev  int32[NZ*NX*NY]  voxel ordinal of every grid cell, -1 if empty
+ * coords      dev  int32[cap_voxels*3]  (z, x, y) as model_training.py:148, sorted by cell
+ * counts      dev  int32[cap_voxels]    raw in-range point count
+ * npts        dev  int32[cap_voxels]    min(count, sampleSize)
+ * row_start   dev  int32[cap_voxels+1]  exclusive prefix of npts
+ * rows        dev  float32[n_points*6]  compact feature rows [x,y,z,x-cx,y-cy,z-cz]
+ *                  (model_training.py:135-140), voxel v owns rows row_start[v]..+npts[v];
+ *                  ascending original point index, first sampleSize kept
+ * row_point   dev  int32[n_points] or NULL: original point index of every row
+ */
+int lisec_voxelize(const lisec_voxel_cfg* cfg, const void* points, int dtype, int n_points,
+                   int point_stride, void* workspace, size_t workspace_bytes, int cap_voxels,
+                   int32_t* info, int32_t* cell_voxel, int32_t* coords, int32_t* counts,
+                   int32_t* npts, int32_t* row_start, float* rows, int32_t* row_point,
+                   lisec_stream_t stream);
+
+/* Expands compact rows into the zero padded (V, T, 6) block layout the reference's
+ * SparseTensor / dense tensor uses (model_training.py:141-152).  padded: float32[V*T*6]. */
+int lisec_voxel_rows_to_padded(const int32_t* info, const int32_t* npts, const int32_t* row_start,
+                               const float* rows, int sampleSize, int cap_voxels, float* padded,
+                               lisec_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LISEC_HIP_H */

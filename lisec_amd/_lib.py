@@ -1,0 +1,75 @@
+"""ctypes binding of the C ABI (include/lisec_hip.h).  No fallback: a missing library is an error."""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblisec_hip.so")
+
+
+class LisecError(RuntimeError):
+    pass
+
+
+class VoxelCfg(Structure):
+    _fields_ = [("xSize", c_double), ("ySize", c_double), ("zSize", c_double),
+                ("maxVoxelX", c_int), ("maxVoxelY", c_int), ("maxVoxelZ", c_int),
+                ("sampleSize", c_int)]
+
+
+_lib = None
+
+
+def _declare(lib):
+    P = c_void_p
+    lib.lisec_last_error.restype = c_char_p
+    lib.lisec_last_error.argtypes = []
+    lib.lisec_abi_version.restype = c_int
+    lib.lisec_device_info.restype = c_int
+    lib.lisec_device_info.argtypes = [ctypes.c_char_p, c_int]
+    lib.lisec_voxelize_workspace_bytes.restype = c_size_t
+    lib.lisec_voxelize_workspace_bytes.argtypes = [POINTER(VoxelCfg), c_int]
+    lib.lisec_voxelize.restype = c_int
+    lib.lisec_voxelize.argtypes = [POINTER(VoxelCfg), P, c_int, c_int, c_int, P, c_size_t, c_int,
+                                   P, P, P, P, P, P, P, P, P]
+    lib.lisec_voxel_rows_to_padded.restype = c_int
+    lib.lisec_voxel_rows_to_padded.argtypes = [P, P, P, P, c_int, c_int, P, P]
+
+
+def load():
+    """Returns the loaded library; raises LisecError when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise LisecError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C lisec_amd/csrc`.  There is no CPU fallback.")
+        lib = ctypes.CDLL(LIB_PATH)
+        _declare(lib)
+        _lib = lib
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise LisecError(f"lisec C ABI error {rc}: {load().lisec_last_error().decode()}")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    if t is None:
+        return None
+    return c_void_p(t.data_ptr())
+
+
+def current_stream():
+    import torch
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_gpu():
+    import torch
+    if not torch.cuda.is_available():
+        raise LisecError("lisec_amd needs an MI355X (torch.cuda.is_available() is False); "
+                         "there is no CPU fallback for the hot path")
+    return torch.device("cuda", torch.cuda.current_device())
