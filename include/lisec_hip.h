@@ -85,6 +85,35 @@ int lisec_voxel_rows_to_padded(const int32_t* info, const int32_t* npts, const i
                                const float* rows, int sampleSize, int cap_voxels, float* padded,
                                lisec_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * 2. VFE stack (sparse-exact) -- replaces addVFELayer(6,32) + addVFELayer(32,64) + addFCN(64,64)
+ *    + MaxPoolingVFELayer(combine=True) (model_training.py:155-186, :231-235, layers :32-61) on the
+ *    dense (D,H,W,T,6) input; output is the dense (D,H,W,64) grid the first Conv3D reads (:236).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    const float* kernel[3];   /* Dense(use_bias=False) kernels (6,16) (32,32) (64,64)  (:184)          */
+    const float* gamma[3];    /* BatchNormalization() variables, 16 / 32 / 64 channels (:171)          */
+    const float* beta[3];
+    float* moving_mean[3];    /* updated in place by a training forward (momentum 0.99)                */
+    float* moving_var[3];
+} lisec_vfe_params;
+
+/* Size (floats) of the `saved` buffer a forward fills and the backward reads: BN batch statistics
+ * and the per-voxel pre-BN max/min of each layer. */
+size_t lisec_vfe_saved_floats(int cap_voxels);
+size_t lisec_vfe_workspace_bytes(void);
+
+/*
+ * info/cell_voxel/npts/row_start/rows: outputs of lisec_voxelize (device).
+ * ncells = NZ*NX*NY, T = sampleSize.  training != 0: batch statistics (Keras fit), moving stats
+ * updated; training == 0: moving statistics (Keras predict, Predict.py:38).
+ * grid  dev float32[ncells*64]: (D,H,W,64), every cell written (empty cells hold relu(BN3(.)) != 0).
+ */
+int lisec_vfe_forward(const lisec_vfe_params* p, const int32_t* info, const int32_t* cell_voxel,
+                      const int32_t* npts, const int32_t* row_start, const float* rows, int ncells, int T,
+                      int cap_voxels, int training, float* saved, void* workspace, size_t workspace_bytes,
+                      float* grid, lisec_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

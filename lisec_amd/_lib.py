@@ -17,6 +17,11 @@ class VoxelCfg(Structure):
                 ("sampleSize", c_int)]
 
 
+class VfeParams(Structure):
+    _fields_ = [("kernel", c_void_p * 3), ("gamma", c_void_p * 3), ("beta", c_void_p * 3),
+                ("moving_mean", c_void_p * 3), ("moving_var", c_void_p * 3)]
+
+
 _lib = None
 
 
@@ -34,6 +39,13 @@ def _declare(lib):
                                    P, P, P, P, P, P, P, P, P]
     lib.lisec_voxel_rows_to_padded.restype = c_int
     lib.lisec_voxel_rows_to_padded.argtypes = [P, P, P, P, c_int, c_int, P, P]
+    lib.lisec_vfe_saved_floats.restype = c_size_t
+    lib.lisec_vfe_saved_floats.argtypes = [c_int]
+    lib.lisec_vfe_workspace_bytes.restype = c_size_t
+    lib.lisec_vfe_workspace_bytes.argtypes = []
+    lib.lisec_vfe_forward.restype = c_int
+    lib.lisec_vfe_forward.argtypes = [POINTER(VfeParams), P, P, P, P, P, c_int, c_int, c_int, c_int, P, P,
+                                      c_size_t, P, P]
 
 
 def load():

@@ -1,0 +1,85 @@
+// BatchNormalization statistic finalisation (tiny, latency-bound kernels).
+#include "bn.h"
+
+namespace lisec {
+namespace {
+
+__global__ void k_bn_finalize(const double* __restrict__ parts, int nparts, int C, double N,
+                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                              float* __restrict__ mmean, float* __restrict__ mvar, int unbiased,
+                              float* __restrict__ st) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = 0; b < nparts; ++b) {
+        s1 += parts[((size_t)b * 2 + 0) * C + c];
+        s2 += parts[((size_t)b * 2 + 1) * C + c];
+    }
+    double mean = s1 / N;
+    double var = s2 / N - mean * mean;            // biased; fp64 so the cancellation is harmless
+    if (var < 0.0) var = 0.0;
+    double inv = 1.0 / sqrt(var + (double)kBnEps);
+    double scale = (double)gamma[c] * inv;
+    st[c] = (float)scale;
+    st[C + c] = (float)((double)beta[c] - mean * scale);
+    st[2 * C + c] = (float)mean;
+    st[3 * C + c] = (float)inv;
+    if (mmean) {
+        double v = unbiased && N > 1.0 ? var * (N / (N - 1.0)) : var;
+        mmean[c] = (float)((double)mmean[c] * (double)kBnMomentum + mean * (1.0 - (double)kBnMomentum));
+        mvar[c] = (float)((double)mvar[c] * (double)kBnMomentum + v * (1.0 - (double)kBnMomentum));
+    }
+}
+
+__global__ void k_bn_fold(const float* __restrict__ gamma, const float* __restrict__ beta,
+                          const float* __restrict__ mmean, const float* __restrict__ mvar, int C,
+                          float* __restrict__ st) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double inv = 1.0 / sqrt((double)mvar[c] + (double)kBnEps);
+    double scale = (double)gamma[c] * inv;
+    st[c] = (float)scale;
+    st[C + c] = (float)((double)beta[c] - (double)mmean[c] * scale);
+    st[2 * C + c] = mmean[c];
+    st[3 * C + c] = (float)inv;
+}
+
+__global__ void k_reduce_parts(const double* __restrict__ parts, int nparts, int C, double scale,
+                               float* __restrict__ out_f, double* __restrict__ out_d) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int b = 0; b < nparts; ++b) s += parts[(size_t)b * C + c];
+    s *= scale;
+    if (out_f) out_f[c] = (float)s;
+    if (out_d) out_d[c] = s;
+}
+
+}  // namespace
+
+int launch_bn_finalize(const double* partials, int nparts, int C, double N, const float* gamma,
+                       const float* beta, float* moving_mean, float* moving_var, int unbiased_moving,
+                       float* bnstate, hipStream_t st) {
+    hipLaunchKernelGGL(k_bn_finalize, dim3(cdiv(C, 64)), dim3(64), 0, st, partials, nparts, C, N, gamma,
+                       beta, moving_mean, moving_var, unbiased_moving, bnstate);
+    LISEC_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_bn_fold(const float* gamma, const float* beta, const float* moving_mean,
+                   const float* moving_var, int C, float* bnstate, hipStream_t st) {
+    hipLaunchKernelGGL(k_bn_fold, dim3(cdiv(C, 64)), dim3(64), 0, st, gamma, beta, moving_mean,
+                       moving_var, C, bnstate);
+    LISEC_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_reduce_parts(const double* parts, int nparts, int C, double scale, float* out_f, double* out_d,
+                        hipStream_t st) {
+    hipLaunchKernelGGL(k_reduce_parts, dim3(cdiv(C, 256)), dim3(256), 0, st, parts, nparts, C, scale,
+                       out_f, out_d);
+    LISEC_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace lisec

@@ -1,0 +1,50 @@
+"""Host side of the sparse-exact VFE stack (lisec_vfe_forward/backward, include/lisec_hip.h section 2).
+
+Stands where the reference applies addVFELayer(6,32), addVFELayer(32,64), addFCN(64,64) and
+MaxPoolingVFELayer(combine=True) to the dense (D,H,W,T,6) tensor (model_training.py:231-235).
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import VfeParams
+
+VFE_LAYERS = ("vfe1", "vfe2", "fcn")
+
+
+class VFEStack:
+    def __init__(self, params, device=None):
+        self.device = device or _lib.require_gpu()
+        self.lib = _lib.load()
+        self.params = params
+        self._ws = torch.empty(self.lib.lisec_vfe_workspace_bytes(), dtype=torch.uint8, device=self.device)
+        self._saved = None
+        self._sample = None
+
+    def _cparams(self, theta=None):
+        p, s = self.params, VfeParams()
+        for i, n in enumerate(VFE_LAYERS):
+            s.kernel[i] = p.ptr(f"{n}.dense.kernel", theta).value
+            s.gamma[i] = p.ptr(f"{n}.bn.gamma", theta).value
+            s.beta[i] = p.ptr(f"{n}.bn.beta", theta).value
+            s.moving_mean[i] = p.ptr(f"{n}.bn.moving_mean").value
+            s.moving_var[i] = p.ptr(f"{n}.bn.moving_variance").value
+        return s
+
+    def forward(self, sample, training, out=None):
+        """sample: VoxelSample.  Returns the dense (D, H, W, 64) grid (device tensor)."""
+        D, H, W = sample.grid_shape
+        ncells = D * H * W
+        need = self.lib.lisec_vfe_saved_floats(sample.cap)
+        if self._saved is None or self._saved.numel() < need:
+            self._saved = torch.empty(need, dtype=torch.float32, device=self.device)
+        grid = out if out is not None else torch.empty((D, H, W, 64), dtype=torch.float32, device=self.device)
+        cp = self._cparams()
+        _lib.check(self.lib.lisec_vfe_forward(
+            ctypes.byref(cp), _lib.ptr(sample.info), _lib.ptr(sample.cell_voxel), _lib.ptr(sample.npts),
+            _lib.ptr(sample.row_start), _lib.ptr(sample.rows), ncells, sample.cfg.sampleSize, sample.cap,
+            1 if training else 0, _lib.ptr(self._saved), _lib.ptr(self._ws), self._ws.numel(),
+            _lib.ptr(grid), _lib.current_stream()))
+        self._sample = sample
+        return grid
