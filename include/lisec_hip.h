@@ -114,6 +114,62 @@ int lisec_vfe_forward(const lisec_vfe_params* p, const int32_t* info, const int3
                       int cap_voxels, int training, float* saved, void* workspace, size_t workspace_bytes,
                       float* grid, lisec_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * 3. Dense contractions on the fp32 matrix cores (implicit GEMM, no im2col buffer).
+ *    One geometry descriptor covers Conv3D (model_training.py:192-193), Conv2D (:202-203),
+ *    Conv2DTranspose (:246,:249,:252), Dense on the last axis (:184,:195), the 1x1 heads (:254-255)
+ *    and the data gradients of all of them.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    int mode;           /* 0: conv,  src = o*stride - pad + k   (ZeroPaddingND + 'valid', cross-correlation)
+                           1: transposed conv, src = (o + pad - k)/stride when divisible
+                              (Conv2DTranspose forward; data gradient of a mode-0 conv)                */
+    int Di, Hi, Wi;     /* spatial dims of the tensor gathered from (2D: Di = 1)                       */
+    int Do, Ho, Wo;     /* spatial dims of the tensor written                                          */
+    int KD, KH, KW;     /* kernel taps                                                                 */
+    int sd, sh, sw;     /* strides: 1, 2 or 4                                                          */
+    int pd, ph, pw;     /* ZeroPadding (mode 0) / padding of the conv this is the transpose of (mode 1) */
+    int Cin, in_stride;   /* channels contracted over; floats between positions of `in` (>= Cin)       */
+    int Cout, out_stride; /* channels produced; floats between positions of `out` (concat: 768)        */
+} lisec_conv_geom;
+
+#define LISEC_CONV_IN_RELU 1     /* apply ReLU to the gathered input (after the optional affine)        */
+#define LISEC_CONV_OUT_RELU 2    /* apply ReLU before the store (Dense(..., 'relu'), :195)              */
+#define LISEC_CONV_ACCUMULATE 4  /* out += result (gradient fan-in)                                     */
+
+/* Packed weight layout the kernels read: [tap][K/4][N][4] fp32, K and N zero padded to 64.
+ * src element (tap, k, n) is read at src[tap*tap_stride + k*k_stride + n*n_stride], so any Keras
+ * kernel layout (and its transpose for the data gradient) packs without a host-side copy. */
+size_t lisec_conv_packed_floats(int ntaps, int K, int N);
+int lisec_conv_pack_weights(const float* src, int ntaps, int K, int N, long long tap_stride,
+                            long long k_stride, long long n_stride, float* dst, lisec_stream_t stream);
+
+/* Number of 128-row tiles = leading dimension of `stats_partials`. */
+int lisec_conv_num_mblocks(const lisec_conv_geom* g);
+
+/*
+ * out[m, n] = sum_tap sum_c f(in[src(m,tap), c]) * W[tap][c][n] + bias[n]
+ *   in_bnstate  NULL, or float[4*Cin] {scale, shift, mean, invstd}: f(x) = x*scale + shift, the
+ *               BatchNormalization of the producing layer (:194,:204), then ReLU if LISEC_CONV_IN_RELU
+ *               (:206); padding stays exactly zero, as ZeroPadding follows the activation in the graph
+ *   bias        NULL or float[Cout]
+ *   stats_partials NULL, or double[num_mblocks][2][Cout]: per-tile sum and sum of squares of the
+ *               stored values, the input of lisec_bn_finalize (training-mode batch statistics)
+ */
+int lisec_conv_forward(const lisec_conv_geom* g, const float* in, const float* packed_w, const float* bias,
+                       const float* in_bnstate, int flags, float* out, double* stats_partials,
+                       lisec_stream_t stream);
+
+/* BatchNormalization statistics (Keras: axis -1, eps 1e-3, momentum 0.99, biased batch variance).
+ * bnstate: float[4*C] {scale = gamma*rsqrt(var+eps), shift = beta - mean*scale, mean, invstd}.
+ * finalize: reduces partials in index order, optionally updates the moving statistics in place
+ * (NULL to skip); fold: bnstate from the moving statistics (inference, Predict.py:38). */
+int lisec_bn_finalize(const double* partials, int nparts, int C, double n_rows, const float* gamma,
+                      const float* beta, float* moving_mean, float* moving_var, int unbiased_moving,
+                      float* bnstate, lisec_stream_t stream);
+int lisec_bn_fold(const float* gamma, const float* beta, const float* moving_mean, const float* moving_var,
+                  int C, float* bnstate, lisec_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -22,6 +22,12 @@ class VfeParams(Structure):
                 ("moving_mean", c_void_p * 3), ("moving_var", c_void_p * 3)]
 
 
+class ConvGeom(Structure):
+    _fields_ = [(n, c_int) for n in ("mode", "Di", "Hi", "Wi", "Do", "Ho", "Wo", "KD", "KH", "KW",
+                                     "sd", "sh", "sw", "pd", "ph", "pw", "Cin", "in_stride", "Cout",
+                                     "out_stride")]
+
+
 _lib = None
 
 
@@ -43,6 +49,19 @@ def _declare(lib):
     lib.lisec_vfe_saved_floats.argtypes = [c_int]
     lib.lisec_vfe_workspace_bytes.restype = c_size_t
     lib.lisec_vfe_workspace_bytes.argtypes = []
+    LL = ctypes.c_longlong
+    lib.lisec_conv_packed_floats.restype = c_size_t
+    lib.lisec_conv_packed_floats.argtypes = [c_int, c_int, c_int]
+    lib.lisec_conv_pack_weights.restype = c_int
+    lib.lisec_conv_pack_weights.argtypes = [P, c_int, c_int, c_int, LL, LL, LL, P, P]
+    lib.lisec_conv_num_mblocks.restype = c_int
+    lib.lisec_conv_num_mblocks.argtypes = [POINTER(ConvGeom)]
+    lib.lisec_conv_forward.restype = c_int
+    lib.lisec_conv_forward.argtypes = [POINTER(ConvGeom), P, P, P, P, c_int, P, P, P]
+    lib.lisec_bn_finalize.restype = c_int
+    lib.lisec_bn_finalize.argtypes = [P, c_int, c_int, c_double, P, P, P, P, c_int, P, P]
+    lib.lisec_bn_fold.restype = c_int
+    lib.lisec_bn_fold.argtypes = [P, P, P, P, c_int, P, P]
     lib.lisec_vfe_forward.restype = c_int
     lib.lisec_vfe_forward.argtypes = [POINTER(VfeParams), P, P, P, P, P, c_int, c_int, c_int, c_int, P, P,
                                       c_size_t, P, P]

@@ -83,3 +83,20 @@ int launch_reduce_parts(const double* parts, int nparts, int C, double scale, fl
 }
 
 }  // namespace lisec
+
+using namespace lisec;
+
+extern "C" int lisec_bn_finalize(const double* partials, int nparts, int C, double n_rows, const float* gamma,
+                                 const float* beta, float* moving_mean, float* moving_var, int unbiased_moving,
+                                 float* bnstate, lisec_stream_t stream) {
+    LISEC_CHECK_ARG(partials && gamma && beta && bnstate && nparts > 0 && C > 0 && n_rows > 0, "bad bn_finalize arguments");
+    LISEC_CHECK_ARG((moving_mean == nullptr) == (moving_var == nullptr), "moving_mean/moving_var must both be set or NULL");
+    return launch_bn_finalize(partials, nparts, C, n_rows, gamma, beta, moving_mean, moving_var, unbiased_moving,
+                              bnstate, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int lisec_bn_fold(const float* gamma, const float* beta, const float* moving_mean,
+                             const float* moving_var, int C, float* bnstate, lisec_stream_t stream) {
+    LISEC_CHECK_ARG(gamma && beta && moving_mean && moving_var && bnstate && C > 0, "bad bn_fold arguments");
+    return launch_bn_fold(gamma, beta, moving_mean, moving_var, C, bnstate, static_cast<hipStream_t>(stream));
+}

@@ -1,0 +1,334 @@
+// Implicit-GEMM convolution on the fp32 matrix cores of gfx950 (v_mfma_f32_32x32x2_f32).
+//
+// One kernel family serves every dense contraction of the network
+//   Conv3D  (model_training.py:193)     Conv2D (:203)      Conv2DTranspose (:246,:249,:252)
+//   Dense on the last axis (:184,:195)  1x1 heads (:254-255)
+// and their data gradients, as   out[m, n] = sum_tap sum_c  A_tap[m, c] * W[tap][c][n]  (+ bias)
+// with A_tap[m, :] = f(in[src(m, tap), :]) gathered on the fly (never an im2col buffer):
+//   mode 0 (conv):            src = o*stride - pad + k          (ZeroPadding + 'valid')
+//   mode 1 (transposed conv): src = (o + pad - k) / stride      when divisible and in range
+// f is an optional per-channel affine (+ReLU): the BatchNormalization(+ReLU) of the PRODUCING
+// layer is applied while the tile is staged, so normalised activations are never written to HBM.
+//
+// Tiling (per 256-thread workgroup = 4 waves, one per SIMD): 128 output positions x 64 output
+// channels; every wave owns 32 x 64 = two 32x32 MFMA accumulators.  Per (tap, 64-channel slab):
+//   A slab 128 x 64 fp32 -> LDS rows padded to 68 floats (conflict-free ds_read_b128 fragments)
+//   W slab  64 x 64 fp32 -> LDS in the packed [k/4][n][4] order (linear copy, conflict-free)
+//   64 MFMAs per wave (4096 SIMD cycles at the 64-cycle issue rate of the f32 MFMA).
+// The next slab is prefetched into registers while the MFMAs run and written to LDS between two
+// barriers (single LDS buffer, 51 KB => 3 workgroups per CU cover each other's staging).
+// fp32 in / fp32 accumulate: bit-for-bit an fmaf chain, so parity with the fp32 oracle holds to
+// summation-order noise (no reduced precision anywhere).
+#include "conv.h"
+
+namespace lisec {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128, BN = 64, BK = 64;
+constexpr int LDA = 68;                          // padded A row (floats)
+constexpr int kThreads = 256;
+constexpr int A_FLOATS = BM * LDA;               // 8704
+constexpr int B_FLOATS = BK * BN;                // 4096
+
+struct RowCoord {                                // output position of one A row, packed
+    int packed;                                  // w | h << 10 | d << 20, -1 when m >= M
+};
+
+__device__ __forceinline__ int src_coord(int o, int k, int ls, int pad, int n_in, int mode, bool& ok) {
+    if (mode == 0) {
+        int s = (o << ls) - pad + k;
+        ok = ok && s >= 0 && s < n_in;
+        return s;
+    }
+    int t = o + pad - k;
+    int s = t >> ls;
+    ok = ok && t >= 0 && (t & ((1 << ls) - 1)) == 0 && s < n_in;
+    return s;
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(kThreads)
+k_igemm(ConvGeom g, const float* __restrict__ in, const float* __restrict__ wp,
+        const float* __restrict__ bias, const float* __restrict__ in_bn, int flags,
+        float* __restrict__ out, double* __restrict__ stats) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sA = smem;
+    float* sB = smem + A_FLOATS;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // XCD-aware tile order: consecutive M tiles (which share halo rows) stay on one XCD's L2
+    const int nmb = gridDim.x;
+    int mb;
+    {
+        const int orig = blockIdx.x, q = nmb >> 3, r = nmb & 7, xcd = orig & 7;
+        mb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    }
+    const int m0 = mb * BM;
+    const int n0 = blockIdx.y * BN;
+    const int HW = g.Ho * g.Wo;
+
+    // ---- rows this thread stages: r = p*16 + tid/16, 16-byte piece tid%16 ----------------------
+    const int piece = tid & 15;
+    int rowc[8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        int m = m0 + p * 16 + (tid >> 4);
+        if (m < g.M) {
+            int d = m / HW, rem = m - d * HW;
+            int h = rem / g.Wo, w = rem - h * g.Wo;
+            rowc[p] = w | (h << 10) | (d << 20);
+        } else {
+            rowc[p] = -1;
+        }
+    }
+    // tile-uniform depth range for whole-tap skipping
+    const int mlast = (m0 + BM - 1 < g.M ? m0 + BM - 1 : g.M - 1);
+    const int d_first = m0 / HW, d_last = mlast / HW;
+
+    const int ncc = (g.Cin + BK - 1) / BK;
+    const int ntaps = g.KD * g.KH * g.KW;
+    const int nsteps = ntaps * ncc;
+    const int KpQ = ncc * (BK / 4);              // packed K quads per tap
+
+    auto live = [&](int s) -> bool {
+        if (d_first != d_last) return true;
+        int tap = s / ncc;
+        int kd = tap / (g.KH * g.KW);
+        bool ok = true;
+        (void)src_coord(d_first, kd, g.ls_d, g.pd, g.Di, MODE, ok);
+        return ok;
+    };
+    auto advance = [&](int s) -> int {
+        while (s < nsteps && !live(s)) ++s;
+        return s;
+    };
+
+    float4 ra[8];
+    float4 rb0, rb1, rb2, rb3;
+    float4 tsc = make_float4(1, 1, 1, 1), tsh = make_float4(0, 0, 0, 0);
+    unsigned valid_mask = 0;
+
+    auto issue_loads = [&](int s) {
+        const int tap = s / ncc, cc = s - tap * ncc;
+        const int kw = tap % g.KW, kh = (tap / g.KW) % g.KH, kd = tap / (g.KW * g.KH);
+        const int c = cc * BK + piece * 4;
+        const bool cok = c < g.Cin;
+        valid_mask = 0;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            bool ok = rowc[p] >= 0 && cok;
+            int w = rowc[p] & 1023, h = (rowc[p] >> 10) & 1023, d = (rowc[p] >> 20) & 1023;
+            int sd = src_coord(d, kd, g.ls_d, g.pd, g.Di, MODE, ok);
+            int sh = src_coord(h, kh, g.ls_h, g.ph, g.Hi, MODE, ok);
+            int sw = src_coord(w, kw, g.ls_w, g.pw, g.Wi, MODE, ok);
+            if (ok) {
+                size_t pos = ((size_t)sd * g.Hi + sh) * g.Wi + sw;
+                ra[p] = *reinterpret_cast<const float4*>(in + pos * g.in_stride + c);
+                valid_mask |= 1u << p;
+            } else {
+                ra[p] = make_float4(0, 0, 0, 0);
+            }
+        }
+        if (in_bn && cok) {
+            tsc = *reinterpret_cast<const float4*>(in_bn + c);
+            tsh = *reinterpret_cast<const float4*>(in_bn + g.Cin + c);
+        }
+        const float* wb = wp + ((size_t)(tap * KpQ + cc * (BK / 4)) * g.CoutP + n0) * 4;
+        const float* wl = wb + (size_t)(tid >> 6) * g.CoutP * 4 + (tid & 63) * 4;
+        const size_t wstep = (size_t)4 * g.CoutP * 4;
+        rb0 = *reinterpret_cast<const float4*>(wl);
+        rb1 = *reinterpret_cast<const float4*>(wl + wstep);
+        rb2 = *reinterpret_cast<const float4*>(wl + 2 * wstep);
+        rb3 = *reinterpret_cast<const float4*>(wl + 3 * wstep);
+    };
+    const float relu_lo = (flags & LISEC_CONV_IN_RELU) ? 0.f : -INFINITY;
+    auto store_lds = [&]() {
+        // branch-free: without an affine tsc = 1, tsh = 0 (x*1 + 0 is exact); padding stays 0
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            float4 v = ra[p];
+            const bool ok = (valid_mask >> p) & 1;
+            v.x = ok ? fmaxf(fmaf(v.x, tsc.x, tsh.x), relu_lo) : 0.f;
+            v.y = ok ? fmaxf(fmaf(v.y, tsc.y, tsh.y), relu_lo) : 0.f;
+            v.z = ok ? fmaxf(fmaf(v.z, tsc.z, tsh.z), relu_lo) : 0.f;
+            v.w = ok ? fmaxf(fmaf(v.w, tsc.w, tsh.w), relu_lo) : 0.f;
+            *reinterpret_cast<float4*>(sA + (p * 16 + (tid >> 4)) * LDA + piece * 4) = v;
+        }
+        float* bl = sB + ((tid >> 6) * BN + (tid & 63)) * 4;
+        *reinterpret_cast<float4*>(bl) = rb0;
+        *reinterpret_cast<float4*>(bl + 4 * BN * 4) = rb1;
+        *reinterpret_cast<float4*>(bl + 8 * BN * 4) = rb2;
+        *reinterpret_cast<float4*>(bl + 12 * BN * 4) = rb3;
+    };
+
+    f32x16 acc0 = {0}, acc1 = {0};
+    const float* aRow = sA + (wave * 32 + (lane & 31)) * LDA + 4 * (lane >> 5);
+    const float* bCol = sB + ((lane >> 5) * BN + (lane & 31)) * 4;
+
+    int s = advance(0);
+    if (s < nsteps) {
+        issue_loads(s);
+        store_lds();
+    }
+    __syncthreads();
+    while (s < nsteps) {
+        const int snext = advance(s + 1);
+        if (snext < nsteps) issue_loads(snext);
+#pragma unroll
+        for (int kc = 0; kc < BK / 8; ++kc) {
+            const float4 a = *reinterpret_cast<const float4*>(aRow + kc * 8);
+            const float4 b0 = *reinterpret_cast<const float4*>(bCol + kc * 2 * BN * 4);
+            const float4 b1 = *reinterpret_cast<const float4*>(bCol + kc * 2 * BN * 4 + 32 * 4);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1.x, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b0.y, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1.y, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b0.z, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b1.z, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b0.w, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b1.w, acc1, 0, 0, 0);
+        }
+        __syncthreads();
+        if (snext < nsteps) store_lds();
+        __syncthreads();
+        s = snext;
+    }
+
+    // ---- epilogue: C layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const int col = lane & 31;
+    const int nA = n0 + col, nB = n0 + 32 + col;
+    const float biasA = (bias && nA < g.Cout) ? bias[nA] : 0.f;
+    const float biasB = (bias && nB < g.Cout) ? bias[nB] : 0.f;
+    const bool orelu = (flags & LISEC_CONV_OUT_RELU) != 0, accum = (flags & LISEC_CONV_ACCUMULATE) != 0;
+    float sumA = 0.f, sqA = 0.f, sumB = 0.f, sqB = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int m = m0 + wave * 32 + row;
+        if (m < g.M) {
+            float* o = out + (size_t)m * g.out_stride;
+            float va = acc0[r] + biasA, vb = acc1[r] + biasB;
+            if (accum) {
+                if (nA < g.Cout) va += o[nA];
+                if (nB < g.Cout) vb += o[nB];
+            }
+            if (orelu) { va = fmaxf(va, 0.f); vb = fmaxf(vb, 0.f); }
+            if (nA < g.Cout) o[nA] = va;
+            if (nB < g.Cout) o[nB] = vb;
+            sumA += va; sqA = fmaf(va, va, sqA);
+            sumB += vb; sqB = fmaf(vb, vb, sqB);
+        }
+    }
+    if (stats) {
+        // per-channel partial sums of this 128-row tile (BatchNormalization batch statistics)
+        __syncthreads();
+        float* red = smem;                       // [4 waves][4][32]
+        sumA += __shfl_xor(sumA, 32, 64); sqA += __shfl_xor(sqA, 32, 64);
+        sumB += __shfl_xor(sumB, 32, 64); sqB += __shfl_xor(sqB, 32, 64);
+        if (lane < 32) {
+            red[(wave * 4 + 0) * 32 + lane] = sumA; red[(wave * 4 + 1) * 32 + lane] = sqA;
+            red[(wave * 4 + 2) * 32 + lane] = sumB; red[(wave * 4 + 3) * 32 + lane] = sqB;
+        }
+        __syncthreads();
+        if (tid < 128) {
+            const int q = tid >> 5, c = tid & 31;            // q: 0 sumA, 1 sqA, 2 sumB, 3 sqB
+            double v = 0.0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v += (double)red[(k * 4 + q) * 32 + c];
+            const int n = n0 + (q >> 1) * 32 + c;
+            if (n < g.Cout) stats[((size_t)mb * 2 + (q & 1)) * g.Cout + n] = v;
+        }
+    }
+}
+
+// dst[tap][k/4][n][k%4] (K padded to 64, N padded to 64, zero filled) from an arbitrary strided source
+__global__ void k_pack_weights(const float* __restrict__ src, int ntaps, int K, int N, long long tap_stride,
+                               long long k_stride, long long n_stride, int Kp, int Np, float* __restrict__ dst) {
+    const long long total = (long long)ntaps * Kp * Np;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        int j = (int)(i & 3);
+        long long t = i >> 2;
+        int n = (int)(t % Np);
+        t /= Np;
+        int kq = (int)(t % (Kp / 4));
+        int tap = (int)(t / (Kp / 4));
+        int k = kq * 4 + j;
+        dst[i] = (k < K && n < N) ? src[tap * tap_stride + k * k_stride + n * n_stride] : 0.f;
+    }
+}
+
+}  // namespace
+
+int conv_geom_check(const lisec_conv_geom* c, ConvGeom* g) {
+    LISEC_CHECK_ARG(c, "geom is NULL");
+    LISEC_CHECK_ARG(c->mode == 0 || c->mode == 1, "mode must be 0 or 1");
+    auto lg = [](int s) { return s == 1 ? 0 : s == 2 ? 1 : s == 4 ? 2 : -1; };
+    int ld = lg(c->sd), lh = lg(c->sh), lw = lg(c->sw);
+    LISEC_CHECK_ARG(ld >= 0 && lh >= 0 && lw >= 0, "strides must be 1, 2 or 4");
+    LISEC_CHECK_ARG(c->Di > 0 && c->Hi > 0 && c->Wi > 0 && c->Do > 0 && c->Ho > 0 && c->Wo > 0, "bad dims");
+    LISEC_CHECK_ARG(c->Do < 1024 && c->Ho < 1024 && c->Wo < 1024, "output dims must be < 1024");
+    LISEC_CHECK_ARG(c->KD >= 1 && c->KH >= 1 && c->KW >= 1 && c->KD * c->KH * c->KW <= 64, "bad kernel size");
+    LISEC_CHECK_ARG(c->Cin >= 4 && c->Cin % 4 == 0 && c->in_stride >= c->Cin && c->in_stride % 4 == 0,
+                    "Cin/in_stride must be multiples of 4");
+    LISEC_CHECK_ARG(c->Cout >= 1 && c->out_stride >= c->Cout, "bad Cout/out_stride");
+    LISEC_CHECK_ARG((long long)c->Do * c->Ho * c->Wo < (1LL << 30), "too many output positions");
+    g->Di = c->Di; g->Hi = c->Hi; g->Wi = c->Wi; g->Do = c->Do; g->Ho = c->Ho; g->Wo = c->Wo;
+    g->KD = c->KD; g->KH = c->KH; g->KW = c->KW; g->ls_d = ld; g->ls_h = lh; g->ls_w = lw;
+    g->pd = c->pd; g->ph = c->ph; g->pw = c->pw;
+    g->Cin = c->Cin; g->in_stride = c->in_stride; g->Cout = c->Cout; g->out_stride = c->out_stride;
+    g->CoutP = (int)align_up(c->Cout, 64);
+    g->M = c->Do * c->Ho * c->Wo;
+    return 0;
+}
+
+}  // namespace lisec
+
+using namespace lisec;
+
+extern "C" size_t lisec_conv_packed_floats(int ntaps, int K, int N) {
+    if (ntaps <= 0 || K <= 0 || N <= 0) return 0;
+    return (size_t)ntaps * align_up(K, 64) * align_up(N, 64);
+}
+
+extern "C" int lisec_conv_pack_weights(const float* src, int ntaps, int K, int N, long long tap_stride,
+                                       long long k_stride, long long n_stride, float* dst,
+                                       lisec_stream_t stream_) {
+    LISEC_CHECK_ARG(src && dst && ntaps > 0 && K > 0 && N > 0, "bad pack arguments");
+    int Kp = (int)align_up(K, 64), Np = (int)align_up(N, 64);
+    long long total = (long long)ntaps * Kp * Np;
+    int gb = cdiv(total, 256);
+    if (gb > 8192) gb = 8192;
+    hipLaunchKernelGGL(k_pack_weights, dim3(gb), dim3(256), 0, static_cast<hipStream_t>(stream_), src, ntaps,
+                       K, N, tap_stride, k_stride, n_stride, Kp, Np, dst);
+    LISEC_LAUNCH_CHECK();
+    return LISEC_OK;
+}
+
+extern "C" int lisec_conv_num_mblocks(const lisec_conv_geom* c) {
+    ConvGeom g;
+    if (conv_geom_check(c, &g)) return -1;
+    return cdiv(g.M, BM);
+}
+
+extern "C" int lisec_conv_forward(const lisec_conv_geom* c, const float* in, const float* packed_w,
+                                  const float* bias, const float* in_bnstate, int flags, float* out,
+                                  double* stats_partials, lisec_stream_t stream_) {
+    ConvGeom g;
+    if (int rc = conv_geom_check(c, &g)) return rc;
+    LISEC_CHECK_ARG(in && packed_w && out, "NULL tensor pointer");
+    LISEC_CHECK_ARG(((uintptr_t)in & 15) == 0 && ((uintptr_t)packed_w & 15) == 0, "in/weights must be 16-byte aligned");
+    dim3 grid(cdiv(g.M, BM), g.CoutP / BN);
+    size_t lds = (size_t)(A_FLOATS + B_FLOATS) * sizeof(float);
+    hipStream_t st = static_cast<hipStream_t>(stream_);
+    if (c->mode == 0)
+        hipLaunchKernelGGL(k_igemm<0>, grid, dim3(kThreads), lds, st, g, in, packed_w, bias, in_bnstate, flags,
+                           out, stats_partials);
+    else
+        hipLaunchKernelGGL(k_igemm<1>, grid, dim3(kThreads), lds, st, g, in, packed_w, bias, in_bnstate, flags,
+                           out, stats_partials);
+    LISEC_LAUNCH_CHECK();
+    return LISEC_OK;
+}

@@ -1,0 +1,124 @@
+"""MFMA implicit-GEMM kernels (C ABI) vs plain PyTorch fp32 CPU references of the same op.
+Tolerance rtol 1e-4 + atol 1e-4*max|ref| (fp32 in/accumulate on both sides; only summation order differs)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _close(got, ref, rtol=1e-4):
+    got, ref = got.double().cpu(), ref.double().cpu()
+    atol = rtol * ref.abs().max().item()
+    err = (got - ref).abs()
+    assert (err <= atol + rtol * ref.abs()).all(), f"max err {err.max().item():.3e}, atol {atol:.3e}"
+
+
+def _conv_case(D, H, W, Cin, Cout, k, stride, pad, in_bn=False, in_relu=False, out_relu=False, bias=True,
+               stats=False, seed=0):
+    from lisec_amd import ops
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(D, H, W, Cin, generator=g)
+    w = torch.randn(*k, Cin, Cout, generator=g) * 0.1                   # Keras (kd,kh,kw,in,out)
+    b = torch.randn(Cout, generator=g) if bias else None
+    Do = (D + 2 * pad[0] - k[0]) // stride[0] + 1
+    Ho = (H + 2 * pad[1] - k[1]) // stride[1] + 1
+    Wo = (W + 2 * pad[2] - k[2]) // stride[2] + 1
+    xin = x
+    bn = None
+    if in_bn:
+        sc, sh = torch.randn(Cin, generator=g), torch.randn(Cin, generator=g)
+        bn = torch.cat([sc, sh, torch.zeros(2 * Cin)])
+        xin = x * sc + sh
+    if in_relu:
+        xin = F.relu(xin)
+    ref = F.conv3d(xin.permute(3, 0, 1, 2)[None], w.permute(4, 3, 0, 1, 2), b, stride=stride, padding=pad)[0]
+    ref = ref.permute(1, 2, 3, 0)
+    if out_relu:
+        ref = F.relu(ref)
+    geo = ops.geom(0, (D, H, W), (Do, Ho, Wo), k, stride, pad, Cin, Cout)
+    wd = w.to(DEV)
+    ntaps = k[0] * k[1] * k[2]
+    wp = ops.pack_weights(wd, ntaps, Cin, Cout, Cin * Cout, Cout, 1)
+    out = torch.full((Do, Ho, Wo, Cout), float("nan"), device=DEV)
+    st = None
+    if stats:
+        st = torch.zeros(ops.num_mblocks(geo), 2, Cout, dtype=torch.float64, device=DEV)
+    flags = (ops.IN_RELU if in_relu else 0) | (ops.OUT_RELU if out_relu else 0)
+    ops.conv_forward(geo, x.to(DEV), wp, out, bias=None if b is None else b.to(DEV),
+                     in_bn=None if bn is None else bn.to(DEV), flags=flags, stats=st)
+    _close(out, ref)
+    if stats:
+        s = st.sum(0).cpu()
+        flat = ref.reshape(-1, Cout).double()
+        _close(s[0], flat.sum(0), rtol=1e-5)
+        _close(s[1], (flat ** 2).sum(0), rtol=1e-5)
+
+
+def test_conv3d_mid_layers():
+    # addConv3DLayer geometries (model_training.py:236-238) on a small H, W
+    _conv_case(8, 12, 20, 64, 64, (3, 3, 3), (2, 1, 1), (1, 1, 1), stats=True)
+    _conv_case(4, 12, 20, 64, 64, (3, 3, 3), (1, 1, 1), (0, 1, 1), stats=True, seed=1)
+    _conv_case(2, 9, 21, 64, 64, (3, 3, 3), (2, 1, 1), (1, 1, 1), seed=2)          # ragged M (189)
+
+
+def test_conv2d_rpn_layers():
+    # addConv2DLayer (model_training.py:201-207): BN+ReLU of the producer applied on load
+    _conv_case(1, 24, 40, 64, 128, (1, 3, 3), (1, 2, 2), (0, 1, 1), stats=True)
+    _conv_case(1, 12, 20, 128, 128, (1, 3, 3), (1, 1, 1), (0, 1, 1), in_bn=True, in_relu=True, stats=True, seed=3)
+    _conv_case(1, 7, 13, 128, 256, (1, 3, 3), (1, 2, 2), (0, 1, 1), in_bn=True, in_relu=True, seed=4)
+    _conv_case(1, 5, 7, 256, 256, (1, 3, 3), (1, 1, 1), (0, 1, 1), in_bn=True, in_relu=True, seed=5)
+
+
+def test_dense_and_heads():
+    # Dense(64, relu, no bias) on BN output (:195) and the 1x1 heads on the 768-channel concat (:254-255)
+    _conv_case(2, 10, 30, 64, 64, (1, 1, 1), (1, 1, 1), (0, 0, 0), in_bn=True, out_relu=True, bias=False, seed=6)
+    _conv_case(1, 10, 30, 768, 16, (1, 1, 1), (1, 1, 1), (0, 0, 0), seed=7)
+
+
+@pytest.mark.parametrize("k,s,cin", [(3, 1, 128), (2, 2, 128), (4, 4, 256)])
+def test_conv2d_transpose(k, s, cin):
+    # Conv2DTranspose(256, padding='same') (:246,:249,:252) written into a 768-channel concat slice
+    from lisec_amd import ops
+    g = torch.Generator().manual_seed(k)
+    H, W, cout = 6, 10, 256
+    x = torch.randn(H, W, cin, generator=g)
+    w = torch.randn(k, k, cout, cin, generator=g) * 0.1                 # Keras (kh,kw,out,in)
+    b = torch.randn(cout, generator=g)
+    sc, sh = torch.randn(cin, generator=g), torch.randn(cin, generator=g)
+    xin = F.relu(x * sc + sh)
+    pad = (k - s) // 2
+    ref = F.conv_transpose2d(xin.permute(2, 0, 1)[None], w.permute(3, 2, 0, 1), b, stride=s, padding=pad)[0]
+    ref = ref.permute(1, 2, 0)
+    Ho, Wo = H * s, W * s
+    assert ref.shape == (Ho, Wo, cout)
+    geo = ops.geom(1, (1, H, W), (1, Ho, Wo), (1, k, k), (1, s, s), (0, pad, pad), cin, cout, out_stride=768)
+    wp = ops.pack_weights(w.to(DEV), k * k, cin, cout, cout * cin, 1, cin)   # K = in (stride 1), N = out
+    cat = torch.zeros(Ho, Wo, 768, device=DEV)
+    bn = torch.cat([sc, sh, torch.zeros(2 * cin)]).to(DEV)
+    ops.conv_forward(geo, x.to(DEV), wp, cat[:, :, 256:], bias=b.to(DEV), in_bn=bn, flags=ops.IN_RELU)
+    _close(cat[:, :, 256:512], ref)
+    assert (cat[:, :, :256] == 0).all() and (cat[:, :, 512:] == 0).all()
+
+
+def test_accumulate_and_data_gradient():
+    # data gradient of a stride-2 conv = mode-1 gather with (out,in)-transposed weights; ACCUMULATE adds
+    from lisec_amd import ops
+    g = torch.Generator().manual_seed(11)
+    D, H, W, Cin, Cout = 4, 10, 14, 64, 64
+    k, stride, pad = (3, 3, 3), (2, 1, 1), (1, 1, 1)
+    x = torch.randn(D, H, W, Cin, generator=g, requires_grad=True)
+    w = torch.randn(*k, Cin, Cout, generator=g) * 0.1
+    y = F.conv3d(x.permute(3, 0, 1, 2)[None], w.permute(4, 3, 0, 1, 2), None, stride=stride, padding=pad)[0]
+    y = y.permute(1, 2, 3, 0)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    Do, Ho, Wo = y.shape[:3]
+    geo = ops.geom(1, (Do, Ho, Wo), (D, H, W), k, stride, pad, Cout, Cin)
+    wp = ops.pack_weights(w.to(DEV), 27, Cout, Cin, Cin * Cout, 1, Cout)       # K = out, N = in
+    base = torch.randn(D, H, W, Cin, generator=g)
+    dx = base.to(DEV).clone()
+    ops.conv_forward(geo, dy.to(DEV), wp, dx, flags=ops.ACCUMULATE)
+    _close(dx, x.grad + base)
