@@ -1,0 +1,174 @@
+"""The Lisec network (createModel, reference model_training.py:222-257) as a static schedule of
+C-ABI calls on one HIP stream.
+
+There is no graph tracer and no autograd: the layer order is fixed, so forward and backward are
+explicit launch sequences over pre-allocated device buffers.  BatchNormalization(+ReLU) of a layer
+is never materialised: every consumer applies scale/shift(+ReLU) while staging its input tile, so
+only the raw convolution outputs ("y") live in HBM.  Per sample (batch 1, as model.fit(batch_size=1),
+model_training.py:299):
+
+    voxel sample -> VFE (sparse-exact) -> grid (D,H,W,64)
+    mid_i : y_i = conv3d(u_{i-1}) ; stats ; u_i = relu(bn(y_i) @ Wd_i)              i = 1..3
+    rpn_b : y_{b,j} = conv2d(relu(bn(y_{b,j-1}))) ; stats                           j = 0..q_b
+    up_b  : concat[..., 256b:256(b+1)] = deconv(relu(bn(y_{b,q})))
+    head  : (M,16) = concat @ [W_cls | W_reg] + bias     (cls = [:, :2], reg = [:, 2:])
+"""
+import numpy as np
+import torch
+
+from . import _lib, ops
+from .params import DECONVS, MID, RPN_BLOCKS, ParamStore
+from .vfe import VFEStack
+
+
+class ConvLayer:
+    """One dense contraction: geometry + packed-weight slot + (optional) BatchNormalization."""
+
+    def __init__(self, name, g, wname, pack, bias=None, bn=None, in_bn=None, in_relu=False, out_relu=False):
+        self.name, self.g, self.wname, self.pack = name, g, wname, pack
+        self.bias, self.bn, self.in_bn, self.in_relu, self.out_relu = bias, bn, in_bn, in_relu, out_relu
+        self.M = g.Do * g.Ho * g.Wo
+        self.nmb = ops.num_mblocks(g)
+
+
+class LisecNet:
+    def __init__(self, nx, ny, nz, maxPoints, params=None, device=None):
+        self.device = device or _lib.require_gpu()
+        self.lib = _lib.load()
+        if nx % 8 or ny % 8:
+            raise ValueError("nx and ny must be multiples of 8 (three stride-2 RPN blocks)")
+        self.H, self.W, self.D, self.T = nx, ny, nz, maxPoints
+        self.params = params if params is not None else ParamStore(self.device)
+        self.vfe = VFEStack(self.params, self.device)
+        dev, f32 = self.device, torch.float32
+        D, H, W = self.D, self.H, self.W
+        self.act = {}          # name -> device tensor (raw conv outputs, mid outputs, grid, concat, head)
+        self.bnstate = {}      # bn prefix -> float[4*C]
+        self.layers = []
+
+        def buf(name, *shape):
+            self.act[name] = torch.empty(shape, dtype=f32, device=dev)
+            return self.act[name]
+
+        buf("grid", D, H, W, 64)
+        # ---- middle layers (model_training.py:236-238) ----------------------------------------
+        d_in, prev = D, "grid"
+        for i, (stride, pad) in enumerate(MID):
+            d_out = (d_in + 2 * pad[0] - 3) // stride[0] + 1
+            n = f"mid{i+1}"
+            buf(n + ".y", d_out, H, W, 64)
+            buf(n + ".u", d_out, H, W, 64)
+            g = ops.geom(0, (d_in, H, W), (d_out, H, W), (3, 3, 3), stride, pad, 64, 64)
+            self.layers.append(dict(kind="mid", name=n, src=prev, conv=ConvLayer(
+                n + ".conv", g, n + ".conv.kernel", (27, 64, 64, 64 * 64, 64, 1), bias=n + ".conv.bias", bn=n + ".bn"),
+                dense=ConvLayer(n + ".dense", ops.geom(0, (d_out, H, W), (d_out, H, W), (1, 1, 1), (1, 1, 1),
+                                                       (0, 0, 0), 64, 64),
+                                n + ".dense.kernel", (1, 64, 64, 0, 64, 1), in_bn=n + ".bn", out_relu=True)))
+            d_in, prev = d_out, n + ".u"
+        if d_in != 1:
+            raise ValueError(f"the middle layers must reduce depth to 1 (got {d_in}); nz={nz} unsupported")
+        # ---- RPN (model_training.py:245-255) -----------------------------------------------------
+        h, w, cin = H, W, 64
+        src, src_bn = prev, None
+        Ho, Wo = H // 2, W // 2
+        buf("concat", Ho, Wo, 768)
+        for b, (cout, q) in enumerate(RPN_BLOCKS):
+            for j in range(q + 1):
+                s = 2 if j == 0 else 1
+                ho, wo = (h + 2 - 3) // s + 1, (w + 2 - 3) // s + 1
+                n = f"rpn{b+1}"
+                buf(f"{n}.y{j}", ho, wo, cout)
+                g = ops.geom(0, (1, h, w), (1, ho, wo), (1, 3, 3), (1, s, s), (0, 1, 1), cin, cout)
+                self.layers.append(dict(kind="conv", name=f"{n}.conv{j}", src=src, dst=f"{n}.y{j}", conv=ConvLayer(
+                    f"{n}.conv{j}", g, f"{n}.conv{j}.kernel", (9, cin, cout, cin * cout, cout, 1),
+                    bias=f"{n}.conv{j}.bias", bn=f"{n}.bn{j}", in_bn=src_bn, in_relu=src_bn is not None)))
+                src, src_bn, h, w, cin = f"{n}.y{j}", f"{n}.bn{j}", ho, wo, cout
+            k, s = DECONVS[b]
+            pad = (k - s) // 2
+            g = ops.geom(1, (1, h, w), (1, h * s, w * s), (1, k, k), (1, s, s), (0, pad, pad), cin, 256, out_stride=768)
+            if (h * s, w * s) != (Ho, Wo):
+                raise ValueError("deconv output does not match the concat map")
+            self.layers.append(dict(kind="deconv", name=f"up{b+1}", src=src, slot=b, conv=ConvLayer(
+                f"up{b+1}", g, f"up{b+1}.kernel", (k * k, cin, 256, 256 * cin, 1, cin), bias=f"up{b+1}.bias",
+                in_bn=src_bn, in_relu=True)))
+        buf("head", Ho, Wo, 16)
+        self.Ho, self.Wo = Ho, Wo
+        self.head_geom = ops.geom(0, (1, Ho, Wo), (1, Ho, Wo), (1, 1, 1), (1, 1, 1), (0, 0, 0), 768, 16)
+        # ---- packed weights + BN state + stats scratch ---------------------------------------------
+        self.packed = {}
+        max_parts = 1
+        for L in self.layers:
+            for key in ("conv", "dense"):
+                if key in L:
+                    c = L[key]
+                    self.packed[c.name] = torch.empty(ops.packed_floats(c.pack[0], c.pack[1], c.pack[2]),
+                                                      dtype=f32, device=dev)
+                    if c.bn:
+                        self.bnstate[c.bn] = torch.zeros(4 * c.g.Cout, dtype=f32, device=dev)
+                        max_parts = max(max_parts, c.nmb * 2 * c.g.Cout)
+        self.packed["head"] = torch.empty(ops.packed_floats(1, 768, 16), dtype=f32, device=dev)
+        self.head_w = torch.empty(768, 16, dtype=f32, device=dev)
+        self.head_b = torch.empty(16, dtype=f32, device=dev)
+        self.parts = torch.empty(max_parts, dtype=torch.float64, device=dev)
+        self._packed_version = -1
+        self.params_version = 0
+
+    # ------------------------------------------------------------------------------------------------
+    def _pack_all(self):
+        """Repack theta into the kernels' [tap][K/4][N][4] layout (after every optimizer step)."""
+        if self._packed_version == self.params_version:
+            return
+        p = self.params
+        for L in self.layers:
+            for key in ("conv", "dense"):
+                if key in L:
+                    c = L[key]
+                    nt, K, N, ts, ks, ns = c.pack
+                    ops.pack_weights(p.view(c.wname), nt, K, N, ts, ks, ns, out=self.packed[c.name])
+        self.head_w[:, :2] = p.view("cls.kernel")[0, 0]
+        self.head_w[:, 2:] = p.view("reg.kernel")[0, 0]
+        self.head_b[:2] = p.view("cls.bias")
+        self.head_b[2:] = p.view("reg.bias")
+        ops.pack_weights(self.head_w, 1, 768, 16, 0, 16, 1, out=self.packed["head"])
+        self._packed_version = self.params_version
+
+    def _bn_after(self, c, training):
+        p = self.params
+        C = c.g.Cout
+        if training:
+            ops.bn_finalize(self.parts, c.nmb, C, c.M, p.view(c.bn + ".gamma"), p.view(c.bn + ".beta"),
+                            p.view(c.bn + ".moving_mean"), p.view(c.bn + ".moving_variance"), True,
+                            self.bnstate[c.bn])
+        else:
+            ops.bn_fold(p.view(c.bn + ".gamma"), p.view(c.bn + ".beta"), p.view(c.bn + ".moving_mean"),
+                        p.view(c.bn + ".moving_variance"), C, self.bnstate[c.bn])
+
+    def _run_conv(self, c, x, out, training):
+        p = self.params
+        flags = (ops.IN_RELU if c.in_relu else 0) | (ops.OUT_RELU if c.out_relu else 0)
+        stats = self.parts if (c.bn and training) else None
+        ops.conv_forward(c.g, x, self.packed[c.name], out, bias=p.view(c.bias) if c.bias else None,
+                         in_bn=self.bnstate[c.in_bn] if c.in_bn else None, flags=flags, stats=stats)
+        if c.bn:
+            self._bn_after(c, training)
+
+    def forward(self, sample, training=False):
+        """sample: VoxelSample of one lidar sweep.  Returns (cls (1,Ho,Wo,2), reg (1,Ho,Wo,14)) device views."""
+        if sample.grid_shape != (self.D, self.H, self.W) or sample.cfg.sampleSize != self.T:
+            raise ValueError("voxel sample does not match the model's grid")
+        self._pack_all()
+        a = self.act
+        self.vfe.forward(sample, training, out=a["grid"])
+        for L in self.layers:
+            if L["kind"] == "mid":
+                n = L["name"]
+                self._run_conv(L["conv"], a[L["src"]], a[n + ".y"], training)
+                self._run_conv(L["dense"], a[n + ".y"], a[n + ".u"], training)
+            elif L["kind"] == "conv":
+                self._run_conv(L["conv"], a[L["src"]], a[L["dst"]], training)
+            else:
+                b = L["slot"]
+                self._run_conv(L["conv"], a[L["src"]], a["concat"][:, :, 256 * b:], training)
+        ops.conv_forward(self.head_geom, a["concat"], self.packed["head"], a["head"], bias=self.head_b)
+        head = a["head"]
+        return head[None, :, :, :2], head[None, :, :, 2:]
