@@ -160,6 +160,15 @@ int lisec_conv_forward(const lisec_conv_geom* g, const float* in, const float* p
                        const float* in_bnstate, int flags, float* out, double* stats_partials,
                        lisec_stream_t stream);
 
+/* Weight gradient of the contraction described by `g` (the geometry of the FORWARD layer):
+ *   dW[tap][c][n] = sum_m f(in[src(m,tap), c]) * dy[m, n]      dy: float32, g->out_stride floats per row
+ * Written in the Keras kernel layout (taps, Cin, Cout); transpose_out != 0 writes (taps, Cout, Cin),
+ * the Conv2DTranspose layout (kh,kw,out,in).  Deterministic: partial slabs reduced in index order. */
+size_t lisec_conv_wgrad_workspace_bytes(const lisec_conv_geom* g);
+int lisec_conv_wgrad(const lisec_conv_geom* g, const float* in, const float* in_bnstate, int flags,
+                     const float* dy, void* workspace, size_t workspace_bytes, int transpose_out, float* dW,
+                     lisec_stream_t stream);
+
 /* BatchNormalization statistics (Keras: axis -1, eps 1e-3, momentum 0.99, biased batch variance).
  * bnstate: float[4*C] {scale = gamma*rsqrt(var+eps), shift = beta - mean*scale, mean, invstd}.
  * finalize: reduces partials in index order, optionally updates the moving statistics in place
@@ -169,6 +178,43 @@ int lisec_bn_finalize(const double* partials, int nparts, int C, double n_rows, 
                       float* bnstate, lisec_stream_t stream);
 int lisec_bn_fold(const float* gamma, const float* beta, const float* moving_mean, const float* moving_var,
                   int C, float* bnstate, lisec_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * 4. Training-step helpers (what Keras' fit() does around the contractions, model_training.py:295-299)
+ * ------------------------------------------------------------------------------------------ */
+size_t lisec_eltwise_workspace_bytes(void);
+
+/* Backward of BatchNormalization (training mode) optionally followed by ReLU (:171-173, :194, :204-206).
+ *   dA (M rows, da_stride floats apart, C channels): gradient wrt the activation a = [relu](y*scale+shift)
+ *   y  (M, C) raw pre-BN values; bnstate from the forward's lisec_bn_finalize
+ *   dz = dA * [z > 0];  dbeta = sum dz;  dgamma = sum dz*yhat;
+ *   dy = scale * (dz - dbeta/M - yhat*dgamma/M)           (may alias dA when da_stride == C)
+ *   dbias (optional): sum over rows of dy -- the gradient of the bias of the conv that produced y */
+int lisec_bn_backward(const float* dA, int da_stride, const float* y, const float* bnstate, long long M, int C,
+                      int relu, float* dgamma, float* dbeta, float* dbias, float* dy, void* workspace,
+                      size_t workspace_bytes, lisec_stream_t stream);
+
+/* grad[i] = act[i] > 0 ? grad[i] : 0   (backward of Dense(..., 'relu'), :195) */
+int lisec_relu_mask(float* grad, const float* act, long long n, lisec_stream_t stream);
+
+/* out[c] = sum_m x[m*stride + c]  (bias gradients of Conv2DTranspose / head layers) */
+int lisec_colsum(const float* x, int stride, long long M, int C, float* out, void* workspace,
+                 size_t workspace_bytes, lisec_stream_t stream);
+
+/* head: (M,16) = [classification (2) | regression (14)] maps.  kind 0: loss=['mse','mse'] (:296);
+ * kind 1: sigmoid cross-entropy + SmoothL1 (BASELINE config 4).  Writes dhead = grad_scale * dLoss/dhead and
+ * loss_out[3] = {total, class, regression}. */
+int lisec_rpn_loss(const float* head, const float* y_cls, const float* y_reg, long long M, int kind,
+                   float grad_scale, float* dhead, float* loss_out, void* workspace, size_t workspace_bytes,
+                   lisec_stream_t stream);
+
+/* optimizers.SGD(lr=0.01, decay=1e-6, momentum=0.9, nesterov=True) (:295) on the flat parameter buffer:
+ * v <- m*v - lr_t*g;  w <- w + m*v - lr_t*g;  lr_t = lr/(1 + decay*iterations) is computed by the caller. */
+int lisec_sgd_nesterov_step(float* theta, const float* grad, float* velocity, long long n, float lr_t,
+                            float momentum, lisec_stream_t stream);
+
+/* x *= s  (gradient averaging after the data-parallel all-reduce) */
+int lisec_scale(float* x, long long n, float s, lisec_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -1,7 +1,7 @@
 """ctypes binding of the C ABI (include/lisec_hip.h).  No fallback: a missing library is an error."""
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_size_t, c_void_p
+from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_size_t, c_void_p  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblisec_hip.so")
@@ -58,6 +58,24 @@ def _declare(lib):
     lib.lisec_conv_num_mblocks.argtypes = [POINTER(ConvGeom)]
     lib.lisec_conv_forward.restype = c_int
     lib.lisec_conv_forward.argtypes = [POINTER(ConvGeom), P, P, P, P, c_int, P, P, P]
+    lib.lisec_conv_wgrad_workspace_bytes.restype = c_size_t
+    lib.lisec_conv_wgrad_workspace_bytes.argtypes = [POINTER(ConvGeom)]
+    lib.lisec_conv_wgrad.restype = c_int
+    lib.lisec_conv_wgrad.argtypes = [POINTER(ConvGeom), P, P, c_int, P, P, c_size_t, c_int, P, P]
+    lib.lisec_eltwise_workspace_bytes.restype = c_size_t
+    lib.lisec_eltwise_workspace_bytes.argtypes = []
+    lib.lisec_bn_backward.restype = c_int
+    lib.lisec_bn_backward.argtypes = [P, c_int, P, P, LL, c_int, c_int, P, P, P, P, P, c_size_t, P]
+    lib.lisec_relu_mask.restype = c_int
+    lib.lisec_relu_mask.argtypes = [P, P, LL, P]
+    lib.lisec_colsum.restype = c_int
+    lib.lisec_colsum.argtypes = [P, c_int, LL, c_int, P, P, c_size_t, P]
+    lib.lisec_rpn_loss.restype = c_int
+    lib.lisec_rpn_loss.argtypes = [P, P, P, LL, c_int, c_float, P, P, P, c_size_t, P]
+    lib.lisec_sgd_nesterov_step.restype = c_int
+    lib.lisec_sgd_nesterov_step.argtypes = [P, P, P, LL, c_float, c_float, P]
+    lib.lisec_scale.restype = c_int
+    lib.lisec_scale.argtypes = [P, LL, c_float, P]
     lib.lisec_bn_finalize.restype = c_int
     lib.lisec_bn_finalize.argtypes = [P, c_int, c_int, c_double, P, P, P, P, c_int, P, P]
     lib.lisec_bn_fold.restype = c_int

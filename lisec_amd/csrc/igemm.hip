@@ -32,22 +32,6 @@ constexpr int kThreads = 256;
 constexpr int A_FLOATS = BM * LDA;               // 8704
 constexpr int B_FLOATS = BK * BN;                // 4096
 
-struct RowCoord {                                // output position of one A row, packed
-    int packed;                                  // w | h << 10 | d << 20, -1 when m >= M
-};
-
-__device__ __forceinline__ int src_coord(int o, int k, int ls, int pad, int n_in, int mode, bool& ok) {
-    if (mode == 0) {
-        int s = (o << ls) - pad + k;
-        ok = ok && s >= 0 && s < n_in;
-        return s;
-    }
-    int t = o + pad - k;
-    int s = t >> ls;
-    ok = ok && t >= 0 && (t & ((1 << ls) - 1)) == 0 && s < n_in;
-    return s;
-}
-
 template <int MODE>
 __global__ void __launch_bounds__(kThreads)
 k_igemm(ConvGeom g, const float* __restrict__ in, const float* __restrict__ wp,
@@ -60,12 +44,7 @@ k_igemm(ConvGeom g, const float* __restrict__ in, const float* __restrict__ wp,
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // XCD-aware tile order: consecutive M tiles (which share halo rows) stay on one XCD's L2
-    const int nmb = gridDim.x;
-    int mb;
-    {
-        const int orig = blockIdx.x, q = nmb >> 3, r = nmb & 7, xcd = orig & 7;
-        mb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
-    }
+    const int mb = xcd_remap(blockIdx.x, gridDim.x);
     const int m0 = mb * BM;
     const int n0 = blockIdx.y * BN;
     const int HW = g.Ho * g.Wo;

@@ -1,0 +1,292 @@
+// Weight gradients of every dense contraction on the fp32 matrix cores (gfx950).
+//
+//   dW[tap][c][n] = sum_m  A_tap[m][c] * dY[m][n]        (what Keras' fit() derives by autograd for
+//   Conv3D / Conv2D / Conv2DTranspose / Dense kernels, model_training.py:184,193,203,246-255,:299)
+// A_tap is the same on-the-fly gather (+ BatchNormalization/ReLU of the producing layer applied on
+// load) as in igemm.hip; the contraction runs over output positions m, so the GEMM is
+// (64 c) x (64 n) with K = M: tiny output, huge K.  Work split:
+//   workgroup = (group of KW consecutive taps) x (64-channel c block) x (64-channel n block)
+//               x (one of S ranges of 128-row M tiles)
+// The dY tile is staged once per M tile and reused by the KW taps of the group; each wave keeps one
+// 32x32 accumulator per tap for its whole M range and writes it once to a partial slab
+// [S][tap][Cin][Cout]; a second kernel sums the S slabs in index order (deterministic, no atomics)
+// into the Keras kernel layout.
+#include "conv.h"
+
+namespace lisec {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BMW = 128, BC = 64;                // rows per M tile, channel block
+constexpr int kThreads = 256;
+constexpr int TILE_FLOATS = BMW * BC;            // 8192 (32 KB)
+
+template <int MODE, int TG>
+__global__ void __launch_bounds__(kThreads)
+k_wgrad(ConvGeom g, const float* __restrict__ in, const float* __restrict__ in_bn, int flags,
+        const float* __restrict__ dy, int nsplit, int tiles_per_split, float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sA = smem;
+    float* sD = smem + TILE_FLOATS;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ngroups = g.KD * g.KH * (g.KW / TG);
+    const int split = blockIdx.x / ngroups, group = blockIdx.x - split * ngroups;
+    const int tap0 = group * TG;                 // taps tap0 .. tap0+TG-1 share (kd, kh)
+    const int c0 = blockIdx.y * BC, n0 = blockIdx.z * BC;
+    const int HW = g.Ho * g.Wo;
+    const int ntiles = (g.M + BMW - 1) / BMW;
+    const int t_begin = split * tiles_per_split;
+    const int t_end = t_begin + tiles_per_split < ntiles ? t_begin + tiles_per_split : ntiles;
+    const int kd = tap0 / (g.KH * g.KW), kh = (tap0 / g.KW) % g.KH, kw0 = tap0 % g.KW;
+
+    const int piece = tid & 15;
+    const int cA = c0 + piece * 4, cD = n0 + piece * 4;
+    const bool cokA = cA < g.Cin, cokD = cD < g.Cout;
+    float4 tsc = make_float4(1, 1, 1, 1), tsh = make_float4(0, 0, 0, 0);
+    if (in_bn && cokA) {
+        tsc = *reinterpret_cast<const float4*>(in_bn + cA);
+        tsh = *reinterpret_cast<const float4*>(in_bn + g.Cin + cA);
+    }
+    const float relu_lo = (flags & LISEC_CONV_IN_RELU) ? 0.f : -INFINITY;
+
+    f32x16 acc[TG];
+#pragma unroll
+    for (int t = 0; t < TG; ++t) acc[t] = (f32x16){0};
+
+    float4 ra[8], rd[8];
+    unsigned valid_mask = 0;
+    int rowc[8];
+
+    auto decode_rows = [&](int tile) {
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            int m = tile * BMW + p * 16 + (tid >> 4);
+            if (m < g.M) {
+                int d = m / HW, rem = m - d * HW;
+                int h = rem / g.Wo, w = rem - h * g.Wo;
+                rowc[p] = w | (h << 10) | (d << 20);
+            } else {
+                rowc[p] = -1;
+            }
+        }
+    };
+    auto tile_live = [&](int tile) -> bool {     // whole tile outside the valid depth range of this tap group
+        int mfirst = tile * BMW, mlast = mfirst + BMW - 1 < g.M ? mfirst + BMW - 1 : g.M - 1;
+        int df = mfirst / HW, dl = mlast / HW;
+        if (df != dl) return true;
+        bool ok = true;
+        (void)src_coord(df, kd, g.ls_d, g.pd, g.Di, MODE, ok);
+        return ok;
+    };
+    auto load_a = [&](int kw) {
+        valid_mask = 0;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            bool ok = rowc[p] >= 0 && cokA;
+            int w = rowc[p] & 1023, h = (rowc[p] >> 10) & 1023, d = (rowc[p] >> 20) & 1023;
+            int sd = src_coord(d, kd, g.ls_d, g.pd, g.Di, MODE, ok);
+            int sh = src_coord(h, kh, g.ls_h, g.ph, g.Hi, MODE, ok);
+            int sw = src_coord(w, kw, g.ls_w, g.pw, g.Wi, MODE, ok);
+            if (ok) {
+                size_t pos = ((size_t)sd * g.Hi + sh) * g.Wi + sw;
+                ra[p] = *reinterpret_cast<const float4*>(in + pos * g.in_stride + cA);
+                valid_mask |= 1u << p;
+            } else {
+                ra[p] = make_float4(0, 0, 0, 0);
+            }
+        }
+    };
+    auto load_d = [&](int tile) {
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            int m = tile * BMW + p * 16 + (tid >> 4);
+            rd[p] = (m < g.M && cokD) ? *reinterpret_cast<const float4*>(dy + (size_t)m * g.out_stride + cD)
+                                      : make_float4(0, 0, 0, 0);
+        }
+    };
+    auto store_a = [&]() {
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            float4 v = ra[p];
+            const bool ok = (valid_mask >> p) & 1;
+            v.x = ok ? fmaxf(fmaf(v.x, tsc.x, tsh.x), relu_lo) : 0.f;
+            v.y = ok ? fmaxf(fmaf(v.y, tsc.y, tsh.y), relu_lo) : 0.f;
+            v.z = ok ? fmaxf(fmaf(v.z, tsc.z, tsh.z), relu_lo) : 0.f;
+            v.w = ok ? fmaxf(fmaf(v.w, tsc.w, tsh.w), relu_lo) : 0.f;
+            *reinterpret_cast<float4*>(sA + (p * 16 + (tid >> 4)) * BC + piece * 4) = v;
+        }
+    };
+    auto store_d = [&]() {
+#pragma unroll
+        for (int p = 0; p < 8; ++p)
+            *reinterpret_cast<float4*>(sD + (p * 16 + (tid >> 4)) * BC + piece * 4) = rd[p];
+    };
+
+    // MFMA 32x32x2: A operand lane(i = c, h) <- A_tap[m = 8*kk + 4h + j][c]; B operand lane(h, n) <- dY[m][n]
+    const float* aCol = sA + (4 * (lane >> 5)) * BC + (wave >> 1) * 32 + (lane & 31);
+    const float* dCol = sD + (4 * (lane >> 5)) * BC + (wave & 1) * 32 + (lane & 31);
+
+    // step list: (tile, t) with t in [0, TG); dY is staged with t == 0
+    int tile = t_begin;
+    while (tile < t_end && !tile_live(tile)) ++tile;
+    int t = 0;
+    if (tile < t_end) {
+        decode_rows(tile);
+        load_a(kw0);
+        load_d(tile);
+        store_a();
+        store_d();
+    }
+    __syncthreads();
+    while (tile < t_end) {
+        // next step
+        int ntile = tile, nt = t + 1;
+        if (nt == TG) {
+            nt = 0;
+            ++ntile;
+            while (ntile < t_end && !tile_live(ntile)) ++ntile;
+        }
+        const bool more = ntile < t_end;
+        if (more) {
+            if (nt == 0) { decode_rows(ntile); load_d(ntile); }
+            load_a(kw0 + nt);
+        }
+#pragma unroll
+        for (int tt = 0; tt < TG; ++tt) {
+            if (tt == t) {
+#pragma unroll 4
+                for (int kk = 0; kk < BMW / 8; ++kk) {
+                    const float* ap = aCol + kk * 8 * BC;
+                    const float* dp = dCol + kk * 8 * BC;
+                    const float a0 = ap[0], a1 = ap[BC], a2 = ap[2 * BC], a3 = ap[3 * BC];
+                    const float b0 = dp[0], b1 = dp[BC], b2 = dp[2 * BC], b3 = dp[3 * BC];
+                    acc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[tt], 0, 0, 0);
+                    acc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[tt], 0, 0, 0);
+                    acc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b2, acc[tt], 0, 0, 0);
+                    acc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, b3, acc[tt], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+        if (more) {
+            store_a();
+            if (nt == 0) store_d();
+        }
+        __syncthreads();
+        tile = ntile;
+        t = nt;
+    }
+
+    // partial slab [split][tap][Cin][Cout]; C layout: col = lane&31 (n), row = (r&3)+8*(r>>2)+4*(lane>>5) (c)
+    const int ntaps = g.KD * g.KH * g.KW;
+#pragma unroll
+    for (int tt = 0; tt < TG; ++tt) {
+        float* base = partial + ((size_t)split * ntaps + tap0 + tt) * g.Cin * g.Cout;
+        const int n = n0 + (wave & 1) * 32 + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int c = c0 + (wave >> 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (c < g.Cin && n < g.Cout) base[(size_t)c * g.Cout + n] = acc[tt][r];
+        }
+    }
+}
+
+// dW = sum over splits (index order).  transpose: write [tap][n][c] (Conv2DTranspose kernels are (kh,kw,out,in))
+__global__ void k_wgrad_reduce(const float* __restrict__ partial, int nsplit, int ntaps, int Cin, int Cout,
+                               int transpose, float* __restrict__ dW) {
+    const long long per = (long long)ntaps * Cin * Cout;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < per; i += (long long)gridDim.x * 256) {
+        float s = 0.f;
+        for (int k = 0; k < nsplit; ++k) s += partial[(size_t)k * per + i];
+        if (!transpose) {
+            dW[i] = s;
+        } else {
+            int n = (int)(i % Cout);
+            long long t = i / Cout;
+            int c = (int)(t % Cin);
+            int tap = (int)(t / Cin);
+            dW[((size_t)tap * Cout + n) * Cin + c] = s;
+        }
+    }
+}
+
+struct WgradPlan {
+    int TG, ngroups, nsplit, tiles_per_split, ntiles;
+    size_t ws_bytes;
+};
+
+WgradPlan make_plan(const ConvGeom& g) {
+    WgradPlan p;
+    p.TG = g.KW <= 4 ? g.KW : 1;
+    if (g.KW % p.TG) p.TG = 1;
+    p.ngroups = g.KD * g.KH * (g.KW / p.TG);
+    p.ntiles = cdiv(g.M, BMW);
+    int cb = cdiv(g.Cin, BC), nb = cdiv(g.Cout, BC);
+    int base = p.ngroups * cb * nb;
+    int want = cdiv(640, base);                 // ~2.5 workgroups per CU in total
+    if (want < 1) want = 1;
+    if (want > p.ntiles) want = p.ntiles;
+    p.tiles_per_split = cdiv(p.ntiles, want);
+    p.nsplit = cdiv(p.ntiles, p.tiles_per_split);
+    p.ws_bytes = align_up(sizeof(float) * (size_t)p.nsplit * g.KD * g.KH * g.KW * g.Cin * g.Cout, 256);
+    return p;
+}
+
+template <int MODE>
+int launch_wgrad(const ConvGeom& g, const WgradPlan& p, const float* in, const float* in_bn, int flags,
+                 const float* dy, float* partial, hipStream_t st) {
+    dim3 grid(p.nsplit * p.ngroups, cdiv(g.Cin, BC), cdiv(g.Cout, BC));
+    size_t lds = 2 * TILE_FLOATS * sizeof(float);
+#define LISEC_WG(T) hipLaunchKernelGGL((k_wgrad<MODE, T>), grid, dim3(kThreads), lds, st, g, in, in_bn, flags, dy, \
+                                       p.nsplit, p.tiles_per_split, partial)
+    switch (p.TG) {
+        case 1: LISEC_WG(1); break;
+        case 2: LISEC_WG(2); break;
+        case 3: LISEC_WG(3); break;
+        default: LISEC_WG(4); break;
+    }
+#undef LISEC_WG
+    LISEC_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace
+}  // namespace lisec
+
+using namespace lisec;
+
+extern "C" size_t lisec_conv_wgrad_workspace_bytes(const lisec_conv_geom* c) {
+    ConvGeom g;
+    if (conv_geom_check(c, &g)) return 0;
+    return make_plan(g).ws_bytes;
+}
+
+extern "C" int lisec_conv_wgrad(const lisec_conv_geom* c, const float* in, const float* in_bnstate, int flags,
+                                const float* dy, void* workspace, size_t workspace_bytes, int transpose_out,
+                                float* dW, lisec_stream_t stream_) {
+    ConvGeom g;
+    if (int rc = conv_geom_check(c, &g)) return rc;
+    LISEC_CHECK_ARG(in && dy && workspace && dW, "NULL pointer");
+    LISEC_CHECK_ARG(g.out_stride % 4 == 0 && g.Cout % 4 == 0, "dY channels/stride must be multiples of 4");
+    LISEC_CHECK_ARG(((uintptr_t)in & 15) == 0 && ((uintptr_t)dy & 15) == 0, "in/dy must be 16-byte aligned");
+    WgradPlan p = make_plan(g);
+    if (workspace_bytes < p.ws_bytes) {
+        set_error("wgrad workspace too small: %zu < %zu", workspace_bytes, p.ws_bytes);
+        return LISEC_ENOSPC;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream_);
+    float* partial = static_cast<float*>(workspace);
+    int rc = c->mode == 0 ? launch_wgrad<0>(g, p, in, in_bnstate, flags, dy, partial, st)
+                          : launch_wgrad<1>(g, p, in, in_bnstate, flags, dy, partial, st);
+    if (rc) return rc;
+    const int ntaps = g.KD * g.KH * g.KW;
+    long long per = (long long)ntaps * g.Cin * g.Cout;
+    int gb = cdiv(per, 256);
+    if (gb > 4096) gb = 4096;
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3(gb), dim3(256), 0, st, partial, p.nsplit, ntaps, g.Cin, g.Cout,
+                       transpose_out, dW);
+    LISEC_LAUNCH_CHECK();
+    return LISEC_OK;
+}

@@ -64,3 +64,57 @@ def bn_finalize(partials, nparts, C, n_rows, gamma, beta, moving_mean, moving_va
 def bn_fold(gamma, beta, moving_mean, moving_var, C, bnstate):
     _lib.check(_lib.load().lisec_bn_fold(_lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(moving_mean),
                                          _lib.ptr(moving_var), C, _lib.ptr(bnstate), _lib.current_stream()))
+
+
+def wgrad_workspace_bytes(g):
+    return _lib.load().lisec_conv_wgrad_workspace_bytes(ctypes.byref(g))
+
+
+def conv_wgrad(g, x, dy, dW, workspace, in_bn=None, flags=0, transpose_out=False):
+    _lib.check(_lib.load().lisec_conv_wgrad(ctypes.byref(g), _lib.ptr(x), _lib.ptr(in_bn), flags, _lib.ptr(dy),
+                                            _lib.ptr(workspace), workspace.numel() * workspace.element_size(),
+                                            1 if transpose_out else 0, _lib.ptr(dW), _lib.current_stream()))
+    return dW
+
+
+_EW = {}
+
+
+def _ew_workspace(device):
+    key = str(device)
+    if key not in _EW:
+        _EW[key] = torch.empty(_lib.load().lisec_eltwise_workspace_bytes(), dtype=torch.uint8, device=device)
+    return _EW[key]
+
+
+def bn_backward(dA, da_stride, y, bnstate, M, C, relu, dgamma, dbeta, dy, dbias=None):
+    ws = _ew_workspace(y.device)
+    _lib.check(_lib.load().lisec_bn_backward(_lib.ptr(dA), da_stride, _lib.ptr(y), _lib.ptr(bnstate), M, C,
+                                             1 if relu else 0, _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(dbias),
+                                             _lib.ptr(dy), _lib.ptr(ws), ws.numel(), _lib.current_stream()))
+
+
+def relu_mask(grad, act):
+    _lib.check(_lib.load().lisec_relu_mask(_lib.ptr(grad), _lib.ptr(act), grad.numel(), _lib.current_stream()))
+
+
+def colsum(x, stride, M, C, out):
+    ws = _ew_workspace(x.device)
+    _lib.check(_lib.load().lisec_colsum(_lib.ptr(x), stride, M, C, _lib.ptr(out), _lib.ptr(ws), ws.numel(),
+                                        _lib.current_stream()))
+
+
+def rpn_loss(head, y_cls, y_reg, M, kind, dhead, loss_out, grad_scale=1.0):
+    ws = _ew_workspace(head.device)
+    _lib.check(_lib.load().lisec_rpn_loss(_lib.ptr(head), _lib.ptr(y_cls), _lib.ptr(y_reg), M, kind, grad_scale,
+                                          _lib.ptr(dhead), _lib.ptr(loss_out), _lib.ptr(ws), ws.numel(),
+                                          _lib.current_stream()))
+
+
+def sgd_nesterov_step(theta, grad, velocity, lr_t, momentum):
+    _lib.check(_lib.load().lisec_sgd_nesterov_step(_lib.ptr(theta), _lib.ptr(grad), _lib.ptr(velocity),
+                                                   theta.numel(), lr_t, momentum, _lib.current_stream()))
+
+
+def scale_(x, s):
+    _lib.check(_lib.load().lisec_scale(_lib.ptr(x), x.numel(), s, _lib.current_stream()))
