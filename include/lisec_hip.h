@@ -114,6 +114,21 @@ int lisec_vfe_forward(const lisec_vfe_params* p, const int32_t* info, const int3
                       int cap_voxels, int training, float* saved, void* workspace, size_t workspace_bytes,
                       float* grid, lisec_stream_t stream);
 
+/* Gradients of the VFE variables (what fit() derives for the layers of :231-235), training-mode BN.
+ * dgrid: float32[ncells*64], gradient wrt the grid written by lisec_vfe_forward(training=1);
+ * saved: the buffer that forward filled.  Outputs are written (not accumulated). */
+typedef struct {
+    float* kernel[3];   /* (6,16) (32,32) (64,64) */
+    float* gamma[3];
+    float* beta[3];
+} lisec_vfe_grads;
+size_t lisec_vfe_backward_workspace_bytes(int cap_voxels, int n_points);
+int lisec_vfe_backward(const lisec_vfe_params* p, const int32_t* info, const int32_t* cell_voxel,
+                       const int32_t* npts, const int32_t* row_start, const float* rows, int n_points,
+                       int ncells, int T, int cap_voxels, const float* saved, const float* dgrid,
+                       const lisec_vfe_grads* grads, void* workspace, size_t workspace_bytes,
+                       lisec_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * 3. Dense contractions on the fp32 matrix cores (implicit GEMM, no im2col buffer).
  *    One geometry descriptor covers Conv3D (model_training.py:192-193), Conv2D (:202-203),

@@ -22,6 +22,10 @@ class VfeParams(Structure):
                 ("moving_mean", c_void_p * 3), ("moving_var", c_void_p * 3)]
 
 
+class VfeGrads(Structure):
+    _fields_ = [("kernel", c_void_p * 3), ("gamma", c_void_p * 3), ("beta", c_void_p * 3)]
+
+
 class ConvGeom(Structure):
     _fields_ = [(n, c_int) for n in ("mode", "Di", "Hi", "Wi", "Do", "Ho", "Wo", "KD", "KH", "KW",
                                      "sd", "sh", "sw", "pd", "ph", "pw", "Cin", "in_stride", "Cout",
@@ -50,6 +54,11 @@ def _declare(lib):
     lib.lisec_vfe_workspace_bytes.restype = c_size_t
     lib.lisec_vfe_workspace_bytes.argtypes = []
     LL = ctypes.c_longlong
+    lib.lisec_vfe_backward_workspace_bytes.restype = c_size_t
+    lib.lisec_vfe_backward_workspace_bytes.argtypes = [c_int, c_int]
+    lib.lisec_vfe_backward.restype = c_int
+    lib.lisec_vfe_backward.argtypes = [POINTER(VfeParams), P, P, P, P, P, c_int, c_int, c_int, c_int, P, P,
+                                       POINTER(VfeGrads), P, c_size_t, P]
     lib.lisec_conv_packed_floats.restype = c_size_t
     lib.lisec_conv_packed_floats.argtypes = [c_int, c_int, c_int]
     lib.lisec_conv_pack_weights.restype = c_int

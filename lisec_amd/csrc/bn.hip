@@ -55,7 +55,31 @@ __global__ void k_reduce_parts(const double* __restrict__ parts, int nparts, int
     if (out_d) out_d[c] = s;
 }
 
+__global__ void k_bn_bwd_finalize(const double* __restrict__ parts, int nparts, int C, double N,
+                                  float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                  float* __restrict__ coef) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = 0; b < nparts; ++b) {
+        s1 += parts[((size_t)b * 2 + 0) * C + c];
+        s2 += parts[((size_t)b * 2 + 1) * C + c];
+    }
+    dbeta[c] = (float)s1;
+    dgamma[c] = (float)s2;
+    coef[c] = (float)(s1 / N);          // mean(dz)
+    coef[C + c] = (float)(s2 / N);      // mean(dz * yhat)
+}
+
 }  // namespace
+
+int launch_bn_bwd_finalize(const double* parts, int nparts, int C, double N, float* dgamma, float* dbeta,
+                           float* coef, hipStream_t st) {
+    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(cdiv(C, 64)), dim3(64), 0, st, parts, nparts, C, N, dgamma,
+                       dbeta, coef);
+    LISEC_LAUNCH_CHECK();
+    return 0;
+}
 
 int launch_bn_finalize(const double* partials, int nparts, int C, double N, const float* gamma,
                        const float* beta, float* moving_mean, float* moving_var, int unbiased_moving,

@@ -49,23 +49,6 @@ k_bn_bwd_reduce(const float* __restrict__ dA, int da_stride, const float* __rest
     }
 }
 
-// dbeta/dgamma (fp32 gradients) + the per-channel coefficients of pass 2
-__global__ void k_bn_bwd_finalize(const double* __restrict__ parts, int nparts, int C, double M,
-                                  float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                  float* __restrict__ coef) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s1 = 0.0, s2 = 0.0;
-    for (int b = 0; b < nparts; ++b) {
-        s1 += parts[((size_t)b * 2 + 0) * C + c];
-        s2 += parts[((size_t)b * 2 + 1) * C + c];
-    }
-    dbeta[c] = (float)s1;
-    dgamma[c] = (float)s2;
-    coef[c] = (float)(s1 / M);          // mean(dz)
-    coef[C + c] = (float)(s2 / M);      // mean(dz * yhat)
-}
-
 // pass 2: dy = scale * (dz - mean(dz) - yhat * mean(dz*yhat));  parts[b][c] = sum dy (conv bias gradient)
 template <bool RELU>
 __global__ void __launch_bounds__(kEwThreads)
@@ -257,7 +240,7 @@ extern "C" int lisec_bn_backward(const float* dA, int da_stride, const float* y,
         hipLaunchKernelGGL(k_bn_bwd_reduce<true>, dim3(nb), dim3(kEwThreads), 0, st, dA, da_stride, y, bnstate, M, C, parts);
     else
         hipLaunchKernelGGL(k_bn_bwd_reduce<false>, dim3(nb), dim3(kEwThreads), 0, st, dA, da_stride, y, bnstate, M, C, parts);
-    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(cdiv(C, 64)), dim3(64), 0, st, parts, nb, C, (double)M, dgamma, dbeta, coef);
+    if (int rc = launch_bn_bwd_finalize(parts, nb, C, (double)M, dgamma, dbeta, coef, st)) return rc;
     double* bparts = dbias ? parts : nullptr;
     if (relu)
         hipLaunchKernelGGL(k_bn_bwd_apply<true>, dim3(nb), dim3(kEwThreads), 0, st, dA, da_stride, y, bnstate, coef, M, C, dy, bparts);

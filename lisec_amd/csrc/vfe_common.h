@@ -1,0 +1,58 @@
+// Internal: device helpers shared by the VFE forward (vfe.hip) and backward (vfe_bwd.hip) kernels.
+#pragma once
+#include "bn.h"
+
+namespace lisec {
+
+constexpr int kVfeBlocks = 512;
+constexpr int kVfeThreads = 256;     // 4 waves
+
+__device__ __forceinline__ float rl(float v, int k) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), k));
+}
+__device__ __forceinline__ float bnrelu(float y, float sc, float sh) { return fmaxf(fmaf(y, sc, sh), 0.0f); }
+__device__ __forceinline__ float pool_from(float ymax, float ymin, float sc, float sh) {
+    return bnrelu(sc >= 0.0f ? ymax : ymin, sc, sh);
+}
+
+struct VfeIn {
+    const int* info; const int* npts; const int* row_start; const float* rows;
+    int ncells, T, cap;
+};
+
+struct VfeWeights {          // per lane: column (lane & (C-1)) of each Dense kernel
+    float w1[6];
+    float w2p[16], w2a[16];
+    float w3p[32], w3a[32];
+    __device__ void load(const float* W1, const float* W2, const float* W3, int stage) {
+        const int lane = lane_id();
+#pragma unroll
+        for (int k = 0; k < 6; ++k) w1[k] = W1[k * 16 + (lane & 15)];
+        if (stage != 1) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) { w2p[k] = W2[k * 32 + (lane & 31)]; w2a[k] = W2[(16 + k) * 32 + (lane & 31)]; }
+        }
+        if (stage == 0 || stage == 3) {
+#pragma unroll
+            for (int k = 0; k < 32; ++k) { w3p[k] = W3[k * 64 + lane]; w3a[k] = W3[(32 + k) * 64 + lane]; }
+        }
+    }
+};
+
+
+struct VfeSaved {            // layout of the caller-owned `saved` float buffer (lisec_vfe_saved_floats)
+    float *bn1, *bn2, *bn3, *ymm1, *ymm2, *ymm3;
+    size_t floats;
+    VfeSaved(float* base, int cap) {
+        size_t o = 0;
+        bn1 = base + o; o += 4 * 16;
+        bn2 = base + o; o += 4 * 32;
+        bn3 = base + o; o += 4 * 64;
+        ymm1 = base + o; o += (size_t)(cap + 1) * 32;
+        ymm2 = base + o; o += (size_t)(cap + 1) * 64;
+        ymm3 = base + o; o += (size_t)(cap + 1) * 128;
+        floats = o;
+    }
+};
+
+}  // namespace lisec

@@ -8,7 +8,7 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import VfeParams
+from ._lib import VfeGrads, VfeParams
 
 VFE_LAYERS = ("vfe1", "vfe2", "fcn")
 
@@ -48,3 +48,23 @@ class VFEStack:
             _lib.ptr(grid), _lib.current_stream()))
         self._sample = sample
         return grid
+
+    def backward(self, dgrid, grad):
+        """dgrid: (D,H,W,64) gradient wrt the grid of the last training forward; grad: flat gradient buffer
+        laid out like params.theta (VFE entries are overwritten)."""
+        sample, p = self._sample, self.params
+        D, H, W = sample.grid_shape
+        need = self.lib.lisec_vfe_backward_workspace_bytes(sample.cap, sample.n_points)
+        if getattr(self, "_bws", None) is None or self._bws.numel() < need:
+            self._bws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        g = VfeGrads()
+        for i, n in enumerate(VFE_LAYERS):
+            g.kernel[i] = p.ptr(f"{n}.dense.kernel", grad).value
+            g.gamma[i] = p.ptr(f"{n}.bn.gamma", grad).value
+            g.beta[i] = p.ptr(f"{n}.bn.beta", grad).value
+        cp = self._cparams()
+        _lib.check(self.lib.lisec_vfe_backward(
+            ctypes.byref(cp), _lib.ptr(sample.info), _lib.ptr(sample.cell_voxel), _lib.ptr(sample.npts),
+            _lib.ptr(sample.row_start), _lib.ptr(sample.rows), sample.n_points, D * H * W,
+            sample.cfg.sampleSize, sample.cap, _lib.ptr(self._saved), _lib.ptr(dgrid), ctypes.byref(g),
+            _lib.ptr(self._bws), self._bws.numel(), _lib.current_stream()))

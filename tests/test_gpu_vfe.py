@@ -93,3 +93,54 @@ def test_vfe_full_lyft_grid_vs_sparse_oracle():
     assert (g[empty] == const[None, :]).all()
     _close(const, out[-1])
     assert np.abs(const).max() > 0
+
+
+@pytest.mark.parametrize("grid", ["small", "lyft"])
+def test_vfe_backward_vs_sparse_oracle(grid):
+    """Gradients of the VFE variables from a random grid gradient, vs the fp64 row-class oracle
+    (itself proven equal to dense torch autograd in tests/test_oracle_model.py)."""
+    from lisec_amd.params import ParamStore
+    from lisec_amd.vfe import VFEStack
+    from lisec_amd.voxelizer import Voxelizer
+    from oracle import vfe_sparse_ref as S
+    from oracle import voxel_ref
+
+    rng = np.random.default_rng(4)
+    if grid == "small":
+        cfg = dict(xSize=0.5, ySize=0.25, zSize=0.25, sampleSize=35, maxVoxelX=8, maxVoxelY=16, maxVoxelZ=8)
+        n = 3000
+        pts = np.stack([rng.uniform(-4.2, 4.2, n), rng.uniform(-4.2, 4.2, n), rng.uniform(0.0, 2.1, n)], 1)
+        pts[:600, :2] *= 0.1
+        pts[:600, 2] = 0.5 + 0.5 * rng.uniform(0, 1, 600)
+    else:
+        cfg = LYFT
+        n = 20000
+        pts = np.stack([rng.uniform(-55, 55, n), rng.uniform(-55, 55, n), rng.uniform(-0.5, 2.5, n)], 1)
+    pts = pts.astype(np.float32)
+    D, H, W = cfg["maxVoxelZ"], 2 * cfg["maxVoxelX"], 2 * cfg["maxVoxelY"]
+    ncells = D * H * W
+    op = _oracle_params(13)
+    dev = torch.device("cuda")
+    store = ParamStore(dev, init=op)
+    vfe = VFEStack(store)
+    sample = Voxelizer(**cfg)(pts)
+    vfe.forward(sample, training=True)
+    dgrid = torch.randn(D, H, W, 64, device=dev) * (1.0 / ncells) ** 0.5
+    grad = torch.zeros_like(store.theta)
+    vfe.backward(dgrid, grad)
+    torch.cuda.synchronize()
+
+    ref_vox = voxel_ref.voxelize_ref(pts.astype(np.float64), **cfg)
+    x, w, vox, seg = S.build_rows(ref_vox["feats"], ref_vox["npts"], 35, ncells)
+    pn = {k: v.double().numpy() for k, v in op.items()}
+    _, cache = S.forward(pn, x, w, vox, seg, N=float(ncells * 35), training=True)
+    dg = dgrid.cpu().numpy().astype(np.float64).reshape(ncells, 64)
+    c = ref_vox["coords"]
+    cells = (c[:, 0] * H + c[:, 1]) * W + c[:, 2]
+    empty = np.ones(ncells, bool)
+    empty[cells] = False
+    dout = np.concatenate([dg[cells], dg[empty].sum(0, keepdims=True)])
+    ref = S.backward(pn, cache, dout)
+    for name, r in ref.items():
+        got = store.grad_view(grad, name).cpu().numpy()
+        _close(got, r, rtol=2e-3)
