@@ -112,6 +112,9 @@ class LisecNet:
         self.parts = torch.empty(max_parts, dtype=torch.float64, device=dev)
         self._packed_version = -1
         self.params_version = 0
+        self._train_ready = False
+        self.iterations = 0
+        self.loss_out = torch.zeros(3, dtype=f32, device=dev)
 
     # ------------------------------------------------------------------------------------------------
     def _pack_all(self):
@@ -172,3 +175,141 @@ class LisecNet:
         ops.conv_forward(self.head_geom, a["concat"], self.packed["head"], a["head"], bias=self.head_b)
         head = a["head"]
         return head[None, :, :, :2], head[None, :, :, 2:]
+
+    # ------------------------------------------------------------------------------------------------
+    # training: explicit backward schedule (what Keras' fit() derives by autograd, model_training.py:299)
+    def _prepare_training(self):
+        if self._train_ready:
+            return
+        dev, f32 = self.device, torch.float32
+        p = self.params
+        self.grad = torch.zeros_like(p.theta)
+        self.velocity = torch.zeros_like(p.theta)
+        self.dact = {}
+        for name, t in self.act.items():
+            if name.endswith(".u") or name in ("grid", "concat", "head") or ".y" in name:
+                self.dact[name] = torch.empty_like(t)
+        self.packed_t = {}
+        self.dgeom = {}
+        ws_bytes = ops.wgrad_workspace_bytes(self.head_geom)
+        Ho, Wo = self.Ho, self.Wo
+        for L in self.layers:
+            c = L["conv"]
+            g = c.g
+            ntaps = g.KD * g.KH * g.KW
+            ws_bytes = max(ws_bytes, ops.wgrad_workspace_bytes(g))
+            if L["kind"] == "deconv":
+                # data gradient of a transposed conv = plain strided conv over dY (K = out, N = in)
+                self.dgeom[c.name] = ops.geom(0, (1, g.Ho, g.Wo), (1, g.Hi, g.Wi), (1, g.KH, g.KW),
+                                              (1, g.sh, g.sw), (0, g.ph, g.pw), 256, g.Cin, in_stride=768)
+                self.packed_t[c.name] = (torch.empty(ops.packed_floats(ntaps, 256, g.Cin), dtype=f32, device=dev),
+                                         (ntaps, 256, g.Cin, 256 * g.Cin, g.Cin, 1))
+            else:
+                self.dgeom[c.name] = ops.geom(1, (g.Do, g.Ho, g.Wo), (g.Di, g.Hi, g.Wi), (g.KD, g.KH, g.KW),
+                                              (g.sd, g.sh, g.sw), (g.pd, g.ph, g.pw), g.Cout, g.Cin)
+                self.packed_t[c.name] = (torch.empty(ops.packed_floats(ntaps, g.Cout, g.Cin), dtype=f32, device=dev),
+                                         (ntaps, g.Cout, g.Cin, g.Cin * g.Cout, 1, g.Cout))
+            if "dense" in L:
+                d = L["dense"]
+                ws_bytes = max(ws_bytes, ops.wgrad_workspace_bytes(d.g))
+                self.dgeom[d.name] = d.g          # 1x1: the data gradient is the same geometry with W^T
+                self.packed_t[d.name] = (torch.empty(ops.packed_floats(1, 64, 64), dtype=f32, device=dev),
+                                         (1, 64, 64, 0, 1, 64))
+                self.dact[L["name"] + ".z"] = torch.empty_like(self.act[L["name"] + ".y"])
+        self.head_dgeom = ops.geom(0, (1, Ho, Wo), (1, Ho, Wo), (1, 1, 1), (1, 1, 1), (0, 0, 0), 16, 768)
+        self.packed_t["head"] = (torch.empty(ops.packed_floats(1, 16, 768), dtype=f32, device=dev), None)
+        self.head_dw = torch.empty(768, 16, dtype=f32, device=dev)
+        self.head_db = torch.empty(16, dtype=f32, device=dev)
+        self.wgrad_ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        self._packed_t_version = -1
+        self._train_ready = True
+
+    def _pack_all_t(self):
+        if self._packed_t_version == self.params_version:
+            return
+        p = self.params
+        for L in self.layers:
+            for key in ("conv", "dense"):
+                if key in L:
+                    c = L[key]
+                    buf, (nt, K, N, ts, ks, ns) = self.packed_t[c.name]
+                    ops.pack_weights(p.view(c.wname), nt, K, N, ts, ks, ns, out=buf)
+        ops.pack_weights(self.head_w, 1, 16, 768, 0, 1, 16, out=self.packed_t["head"][0])
+        self._packed_t_version = self.params_version
+
+    def backward(self, y_cls, y_reg, loss="mse", grad_scale=1.0):
+        """y_cls (Ho,Wo,2), y_reg (Ho,Wo,14): float32 device tensors.  Fills self.grad (layout of theta)
+        and self.loss_out = [total, class, regression].  Must follow forward(training=True)."""
+        self._prepare_training()
+        self._pack_all_t()
+        p, a, d, G = self.params, self.act, self.dact, self.grad
+        M = self.Ho * self.Wo
+        kind = {"mse": 0, "smoothl1_ce": 1}[loss]
+        ops.rpn_loss(a["head"], y_cls, y_reg, M, kind, d["head"], self.loss_out, grad_scale=grad_scale)
+        # ---- heads (model_training.py:254-255) ---------------------------------------------------
+        ops.conv_wgrad(self.head_geom, a["concat"], d["head"], self.head_dw, self.wgrad_ws)
+        ops.colsum(d["head"], 16, M, 16, self.head_db)
+        p.grad_view(G, "cls.kernel")[0, 0].copy_(self.head_dw[:, :2])
+        p.grad_view(G, "reg.kernel")[0, 0].copy_(self.head_dw[:, 2:])
+        p.grad_view(G, "cls.bias").copy_(self.head_db[:2])
+        p.grad_view(G, "reg.bias").copy_(self.head_db[2:])
+        ops.conv_forward(self.head_dgeom, d["head"], self.packed_t["head"][0], d["concat"])
+        # ---- RPN blocks, last to first -------------------------------------------------------------
+        layers = self.layers
+        first_write = set()                    # gradient buffers that already hold a contribution
+
+        def dgrad_into(c, dy, dst_name):
+            flags = ops.ACCUMULATE if dst_name in first_write else 0
+            ops.conv_forward(self.dgeom[c.name], dy, self.packed_t[c.name][0], d[dst_name], flags=flags)
+            first_write.add(dst_name)
+
+        for L in reversed(layers):
+            c = L["conv"]
+            if L["kind"] == "deconv":
+                b = L["slot"]
+                dy = d["concat"][:, :, 256 * b:]
+                ops.conv_wgrad(c.g, a[L["src"]], dy, p.grad_view(G, c.wname), self.wgrad_ws,
+                               in_bn=self.bnstate[c.in_bn], flags=ops.IN_RELU, transpose_out=True)
+                ops.colsum(dy, 768, M, 256, p.grad_view(G, c.bias))
+                dgrad_into(c, dy, L["src"])
+            elif L["kind"] == "conv":
+                dst = L["dst"]
+                C = c.g.Cout
+                ops.bn_backward(d[dst], C, a[dst], self.bnstate[c.bn], c.M, C, True,
+                                p.grad_view(G, c.bn + ".gamma"), p.grad_view(G, c.bn + ".beta"), d[dst],
+                                dbias=p.grad_view(G, c.bias))
+                ops.conv_wgrad(c.g, a[L["src"]], d[dst], p.grad_view(G, c.wname), self.wgrad_ws,
+                               in_bn=self.bnstate[c.in_bn] if c.in_bn else None,
+                               flags=ops.IN_RELU if c.in_relu else 0)
+                dgrad_into(c, d[dst], L["src"])
+            else:   # mid layer: conv3d -> BN -> Dense(relu)
+                n, dn = L["name"], L["dense"]
+                ops.relu_mask(d[n + ".u"], a[n + ".u"])
+                ops.conv_wgrad(dn.g, a[n + ".y"], d[n + ".u"], p.grad_view(G, dn.wname), self.wgrad_ws,
+                               in_bn=self.bnstate[dn.in_bn])
+                ops.conv_forward(self.dgeom[dn.name], d[n + ".u"], self.packed_t[dn.name][0], d[n + ".z"])
+                ops.bn_backward(d[n + ".z"], 64, a[n + ".y"], self.bnstate[c.bn], c.M, 64, False,
+                                p.grad_view(G, c.bn + ".gamma"), p.grad_view(G, c.bn + ".beta"), d[n + ".z"],
+                                dbias=p.grad_view(G, c.bias))
+                ops.conv_wgrad(c.g, a[L["src"]], d[n + ".z"], p.grad_view(G, c.wname), self.wgrad_ws)
+                dgrad_into(c, d[n + ".z"], L["src"])
+        # ---- VFE -----------------------------------------------------------------------------------
+        self.vfe.backward(d["grid"], G)
+        return self.loss_out
+
+    def apply_gradients(self, lr=0.01, decay=1e-6, momentum=0.9):
+        """optimizers.SGD(lr=0.01, decay=1e-6, momentum=0.9, nesterov=True) (model_training.py:295)."""
+        lr_t = lr / (1.0 + decay * self.iterations)
+        ops.sgd_nesterov_step(self.params.theta, self.grad, self.velocity, lr_t, momentum)
+        self.iterations += 1
+        self.params_version += 1
+
+    def train_step(self, sample, y_cls, y_reg, loss="mse", allreduce=None):
+        """One fit() step at batch_size=1: forward (batch statistics) + backward + SGD-Nesterov.
+        allreduce: optional callable(grad) that averages the flat gradient across data-parallel ranks."""
+        self.forward(sample, training=True)
+        self.backward(y_cls, y_reg, loss=loss)
+        if allreduce is not None:
+            allreduce(self.grad)
+        self.apply_gradients()
+        return self.loss_out

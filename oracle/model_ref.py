@@ -144,6 +144,8 @@ def forward(params, x, training=False, stats=None, taps=None):
             y = F.conv2d(h.permute(0, 3, 1, 2), w, p[f"rpn{b+1}.conv{j}.bias"],
                          stride=2 if j == 0 else 1, padding=1)
             y = _bn(y.permute(0, 2, 3, 1), p, f"rpn{b+1}.bn{j}", training, stats, fused=True)
+            if taps is not None:
+                taps[f"rpn{b+1}.z{j}"] = y                      # pre-ReLU (kink diagnostics in tests)
             h = F.relu(y)
         if taps is not None:
             taps[f"rpn{b+1}"] = h
