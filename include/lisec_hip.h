@@ -146,11 +146,16 @@ typedef struct {
     int pd, ph, pw;     /* ZeroPadding (mode 0) / padding of the conv this is the transpose of (mode 1) */
     int Cin, in_stride;   /* channels contracted over; floats between positions of `in` (>= Cin)       */
     int Cout, out_stride; /* channels produced; floats between positions of `out` (concat: 768)        */
+    int ps, ps_channels;  /* "pixel-shuffle" store for a Conv2DTranspose whose kernel == stride (:249,:252),
+                             run as a 1x1 conv with Cout = ps*ps*ps_channels: result column tap*ps_channels+n of
+                             input position (h,w) is stored at position (h*ps+kh, w*ps+kw), channel n
+                             (tap = kh*ps+kw) of a (Ho*ps, Wo*ps) map; bias is indexed by n.  0 = off.       */
 } lisec_conv_geom;
 
 #define LISEC_CONV_IN_RELU 1     /* apply ReLU to the gathered input (after the optional affine)        */
 #define LISEC_CONV_OUT_RELU 2    /* apply ReLU before the store (Dense(..., 'relu'), :195)              */
 #define LISEC_CONV_ACCUMULATE 4  /* out += result (gradient fan-in)                                     */
+#define LISEC_CONV_DY_RELU 8     /* wgrad only: ReLU on the (optionally affine-transformed) dy operand     */
 
 /* Packed weight layout the kernels read: [tap][K/4][N][4] fp32, K and N zero padded to 64.
  * src element (tap, k, n) is read at src[tap*tap_stride + k*k_stride + n*n_stride], so any Keras
@@ -178,11 +183,14 @@ int lisec_conv_forward(const lisec_conv_geom* g, const float* in, const float* p
 /* Weight gradient of the contraction described by `g` (the geometry of the FORWARD layer):
  *   dW[tap][c][n] = sum_m f(in[src(m,tap), c]) * dy[m, n]      dy: float32, g->out_stride floats per row
  * Written in the Keras kernel layout (taps, Cin, Cout); transpose_out != 0 writes (taps, Cout, Cin),
- * the Conv2DTranspose layout (kh,kw,out,in).  Deterministic: partial slabs reduced in index order. */
+ * the Conv2DTranspose layout (kh,kw,out,in).  dy_bnstate (optional, float[4*Cout]) applies the same
+ * affine (+ReLU with LISEC_CONV_DY_RELU) to the dy operand: the kernel==stride Conv2DTranspose layers
+ * swap roles (in = gathered output gradient, dy = the layer's BN+ReLU input).
+ * Deterministic: partial slabs reduced in index order. */
 size_t lisec_conv_wgrad_workspace_bytes(const lisec_conv_geom* g);
 int lisec_conv_wgrad(const lisec_conv_geom* g, const float* in, const float* in_bnstate, int flags,
-                     const float* dy, void* workspace, size_t workspace_bytes, int transpose_out, float* dW,
-                     lisec_stream_t stream);
+                     const float* dy, const float* dy_bnstate, void* workspace, size_t workspace_bytes,
+                     int transpose_out, float* dW, lisec_stream_t stream);
 
 /* BatchNormalization statistics (Keras: axis -1, eps 1e-3, momentum 0.99, biased batch variance).
  * bnstate: float[4*C] {scale = gamma*rsqrt(var+eps), shift = beta - mean*scale, mean, invstd}.

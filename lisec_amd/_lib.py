@@ -29,7 +29,7 @@ class VfeGrads(Structure):
 class ConvGeom(Structure):
     _fields_ = [(n, c_int) for n in ("mode", "Di", "Hi", "Wi", "Do", "Ho", "Wo", "KD", "KH", "KW",
                                      "sd", "sh", "sw", "pd", "ph", "pw", "Cin", "in_stride", "Cout",
-                                     "out_stride")]
+                                     "out_stride", "ps", "ps_channels")]
 
 
 _lib = None
@@ -70,7 +70,7 @@ def _declare(lib):
     lib.lisec_conv_wgrad_workspace_bytes.restype = c_size_t
     lib.lisec_conv_wgrad_workspace_bytes.argtypes = [POINTER(ConvGeom)]
     lib.lisec_conv_wgrad.restype = c_int
-    lib.lisec_conv_wgrad.argtypes = [POINTER(ConvGeom), P, P, c_int, P, P, c_size_t, c_int, P, P]
+    lib.lisec_conv_wgrad.argtypes = [POINTER(ConvGeom), P, P, c_int, P, P, P, c_size_t, c_int, P, P]
     lib.lisec_eltwise_workspace_bytes.restype = c_size_t
     lib.lisec_eltwise_workspace_bytes.argtypes = []
     lib.lisec_bn_backward.restype = c_int

@@ -4,17 +4,38 @@
 namespace lisec {
 namespace {
 
-__global__ void k_bn_finalize(const double* __restrict__ parts, int nparts, int C, double N,
-                              const float* __restrict__ gamma, const float* __restrict__ beta,
-                              float* __restrict__ mmean, float* __restrict__ mvar, int unbiased,
-                              float* __restrict__ st) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s1 = 0.0, s2 = 0.0;
-    for (int b = 0; b < nparts; ++b) {
-        s1 += parts[((size_t)b * 2 + 0) * C + c];
-        s2 += parts[((size_t)b * 2 + 1) * C + c];
+// Deterministic parallel column sums of parts[nparts][ld] (double): a 1024-thread block owns 32
+// consecutive columns; 32 row groups stride over the parts, then a fixed-order LDS tree combines them.
+constexpr int kRedCols = 32, kRedRows = 32;
+
+__device__ __forceinline__ double column_sum(const double* __restrict__ parts, int nparts, size_t ld, int col,
+                                             bool col_ok, double (*red)[kRedCols]) {
+    const int cx = threadIdx.x % kRedCols, ry = threadIdx.x / kRedCols;
+    double s = 0.0;
+    if (col_ok)
+        for (int b = ry; b < nparts; b += kRedRows) s += parts[(size_t)b * ld + col];
+    red[ry][cx] = s;
+    __syncthreads();
+    for (int o = kRedRows / 2; o > 0; o >>= 1) {
+        if (ry < o) red[ry][cx] += red[ry + o][cx];
+        __syncthreads();
     }
+    const double r = red[0][cx];
+    __syncthreads();
+    return r;
+}
+
+__global__ void __launch_bounds__(1024)
+k_bn_finalize(const double* __restrict__ parts, int nparts, int C, double N,
+              const float* __restrict__ gamma, const float* __restrict__ beta,
+              float* __restrict__ mmean, float* __restrict__ mvar, int unbiased,
+              float* __restrict__ st) {
+    __shared__ double red[kRedRows][kRedCols];
+    const int c = blockIdx.x * kRedCols + threadIdx.x % kRedCols;
+    const bool ok = c < C;
+    const double s1 = column_sum(parts, nparts, (size_t)2 * C, c, ok, red);
+    const double s2 = column_sum(parts + C, nparts, (size_t)2 * C, c, ok, red);
+    if (!ok || threadIdx.x >= kRedCols) return;
     double mean = s1 / N;
     double var = s2 / N - mean * mean;            // biased; fp64 so the cancellation is harmless
     if (var < 0.0) var = 0.0;
@@ -44,27 +65,28 @@ __global__ void k_bn_fold(const float* __restrict__ gamma, const float* __restri
     st[3 * C + c] = (float)inv;
 }
 
-__global__ void k_reduce_parts(const double* __restrict__ parts, int nparts, int C, double scale,
-                               float* __restrict__ out_f, double* __restrict__ out_d) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0;
-    for (int b = 0; b < nparts; ++b) s += parts[(size_t)b * C + c];
+__global__ void __launch_bounds__(1024)
+k_reduce_parts(const double* __restrict__ parts, int nparts, int C, double scale,
+               float* __restrict__ out_f, double* __restrict__ out_d) {
+    __shared__ double red[kRedRows][kRedCols];
+    const int c = blockIdx.x * kRedCols + threadIdx.x % kRedCols;
+    const bool ok = c < C;
+    double s = column_sum(parts, nparts, (size_t)C, c, ok, red);
+    if (!ok || threadIdx.x >= kRedCols) return;
     s *= scale;
     if (out_f) out_f[c] = (float)s;
     if (out_d) out_d[c] = s;
 }
 
-__global__ void k_bn_bwd_finalize(const double* __restrict__ parts, int nparts, int C, double N,
-                                  float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                  float* __restrict__ coef) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s1 = 0.0, s2 = 0.0;
-    for (int b = 0; b < nparts; ++b) {
-        s1 += parts[((size_t)b * 2 + 0) * C + c];
-        s2 += parts[((size_t)b * 2 + 1) * C + c];
-    }
+__global__ void __launch_bounds__(1024)
+k_bn_bwd_finalize(const double* __restrict__ parts, int nparts, int C, double N,
+                  float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ coef) {
+    __shared__ double red[kRedRows][kRedCols];
+    const int c = blockIdx.x * kRedCols + threadIdx.x % kRedCols;
+    const bool ok = c < C;
+    const double s1 = column_sum(parts, nparts, (size_t)2 * C, c, ok, red);
+    const double s2 = column_sum(parts + C, nparts, (size_t)2 * C, c, ok, red);
+    if (!ok || threadIdx.x >= kRedCols) return;
     dbeta[c] = (float)s1;
     dgamma[c] = (float)s2;
     coef[c] = (float)(s1 / N);          // mean(dz)
@@ -75,7 +97,7 @@ __global__ void k_bn_bwd_finalize(const double* __restrict__ parts, int nparts, 
 
 int launch_bn_bwd_finalize(const double* parts, int nparts, int C, double N, float* dgamma, float* dbeta,
                            float* coef, hipStream_t st) {
-    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(cdiv(C, 64)), dim3(64), 0, st, parts, nparts, C, N, dgamma,
+    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(cdiv(C, kRedCols)), dim3(1024), 0, st, parts, nparts, C, N, dgamma,
                        dbeta, coef);
     LISEC_LAUNCH_CHECK();
     return 0;
@@ -84,7 +106,7 @@ int launch_bn_bwd_finalize(const double* parts, int nparts, int C, double N, flo
 int launch_bn_finalize(const double* partials, int nparts, int C, double N, const float* gamma,
                        const float* beta, float* moving_mean, float* moving_var, int unbiased_moving,
                        float* bnstate, hipStream_t st) {
-    hipLaunchKernelGGL(k_bn_finalize, dim3(cdiv(C, 64)), dim3(64), 0, st, partials, nparts, C, N, gamma,
+    hipLaunchKernelGGL(k_bn_finalize, dim3(cdiv(C, kRedCols)), dim3(1024), 0, st, partials, nparts, C, N, gamma,
                        beta, moving_mean, moving_var, unbiased_moving, bnstate);
     LISEC_LAUNCH_CHECK();
     return 0;
@@ -100,7 +122,7 @@ int launch_bn_fold(const float* gamma, const float* beta, const float* moving_me
 
 int launch_reduce_parts(const double* parts, int nparts, int C, double scale, float* out_f, double* out_d,
                         hipStream_t st) {
-    hipLaunchKernelGGL(k_reduce_parts, dim3(cdiv(C, 256)), dim3(256), 0, st, parts, nparts, C, scale,
+    hipLaunchKernelGGL(k_reduce_parts, dim3(cdiv(C, kRedCols)), dim3(1024), 0, st, parts, nparts, C, scale,
                        out_f, out_d);
     LISEC_LAUNCH_CHECK();
     return 0;

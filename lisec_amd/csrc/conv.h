@@ -12,6 +12,7 @@ struct ConvGeom {
     int pd, ph, pw;
     int Cin, in_stride, Cout, out_stride, CoutP;
     int M;
+    int ps, ps_channels;
 };
 
 int conv_geom_check(const lisec_conv_geom* c, ConvGeom* g);

@@ -172,11 +172,19 @@ k_loss(const float* __restrict__ head, const float* __restrict__ ycls, const flo
     }
 }
 
-__global__ void k_loss_finalize(const double* __restrict__ parts, int nparts, double M, float* __restrict__ out) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        double a = 0.0, b = 0.0;
-        for (int k = 0; k < nparts; ++k) { a += parts[2 * k]; b += parts[2 * k + 1]; }
-        a /= M * 2.0; b /= M * 14.0;
+__global__ void __launch_bounds__(256)
+k_loss_finalize(const double* __restrict__ parts, int nparts, double M, float* __restrict__ out) {
+    __shared__ double red[2][256];
+    double a = 0.0, b = 0.0;
+    for (int k = threadIdx.x; k < nparts; k += 256) { a += parts[2 * k]; b += parts[2 * k + 1]; }
+    red[0][threadIdx.x] = a; red[1][threadIdx.x] = b;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) { red[0][threadIdx.x] += red[0][threadIdx.x + o]; red[1][threadIdx.x] += red[1][threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        a = red[0][0] / (M * 2.0); b = red[1][0] / (M * 14.0);
         out[0] = (float)(a + b); out[1] = (float)a; out[2] = (float)b;
     }
 }
@@ -291,7 +299,7 @@ extern "C" int lisec_rpn_loss(const float* head, const float* y_cls, const float
     double* parts = static_cast<double*>(workspace);
     int nb = ew_blocks(M * 16);
     hipLaunchKernelGGL(k_loss, dim3(nb), dim3(kEwThreads), 0, st, head, y_cls, y_reg, M, kind, grad_scale, dhead, parts);
-    hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(64), 0, st, parts, nb, (double)M, loss_out);
+    hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(256), 0, st, parts, nb, (double)M, loss_out);
     LISEC_LAUNCH_CHECK();
     return LISEC_OK;
 }

@@ -179,8 +179,12 @@ k_igemm(ConvGeom g, const float* __restrict__ in, const float* __restrict__ wp,
     // ---- epilogue: C layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     const int col = lane & 31;
     const int nA = n0 + col, nB = n0 + 32 + col;
-    const float biasA = (bias && nA < g.Cout) ? bias[nA] : 0.f;
-    const float biasB = (bias && nB < g.Cout) ? bias[nB] : 0.f;
+    // pixel-shuffle store (kernel == stride transposed conv): the 64-column slab lies inside one tap
+    const int ps_tap = g.ps ? n0 / g.ps_channels : 0;
+    const int ps_kh = g.ps ? ps_tap / g.ps : 0, ps_kw = g.ps ? ps_tap - ps_kh * g.ps : 0;
+    const int ncA = g.ps ? nA - ps_tap * g.ps_channels : nA, ncB = g.ps ? nB - ps_tap * g.ps_channels : nB;
+    const float biasA = (bias && nA < g.Cout) ? bias[ncA] : 0.f;
+    const float biasB = (bias && nB < g.Cout) ? bias[ncB] : 0.f;
     const bool orelu = (flags & LISEC_CONV_OUT_RELU) != 0, accum = (flags & LISEC_CONV_ACCUMULATE) != 0;
     float sumA = 0.f, sqA = 0.f, sumB = 0.f, sqB = 0.f;
 #pragma unroll
@@ -188,15 +192,20 @@ k_igemm(ConvGeom g, const float* __restrict__ in, const float* __restrict__ wp,
         const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         const int m = m0 + wave * 32 + row;
         if (m < g.M) {
-            float* o = out + (size_t)m * g.out_stride;
+            size_t orow = (size_t)m;
+            if (g.ps) {
+                const int h = m / g.Wo, w = m - h * g.Wo;
+                orow = (size_t)(h * g.ps + ps_kh) * (g.Wo * g.ps) + (w * g.ps + ps_kw);
+            }
+            float* o = out + orow * g.out_stride;
             float va = acc0[r] + biasA, vb = acc1[r] + biasB;
             if (accum) {
-                if (nA < g.Cout) va += o[nA];
-                if (nB < g.Cout) vb += o[nB];
+                if (nA < g.Cout) va += o[ncA];
+                if (nB < g.Cout) vb += o[ncB];
             }
             if (orelu) { va = fmaxf(va, 0.f); vb = fmaxf(vb, 0.f); }
-            if (nA < g.Cout) o[nA] = va;
-            if (nB < g.Cout) o[nB] = vb;
+            if (nA < g.Cout) o[ncA] = va;
+            if (nB < g.Cout) o[ncB] = vb;
             sumA += va; sqA = fmaf(va, va, sqA);
             sumB += vb; sqB = fmaf(vb, vb, sqB);
         }
@@ -252,7 +261,15 @@ int conv_geom_check(const lisec_conv_geom* c, ConvGeom* g) {
     LISEC_CHECK_ARG(c->KD >= 1 && c->KH >= 1 && c->KW >= 1 && c->KD * c->KH * c->KW <= 64, "bad kernel size");
     LISEC_CHECK_ARG(c->Cin >= 4 && c->Cin % 4 == 0 && c->in_stride >= c->Cin && c->in_stride % 4 == 0,
                     "Cin/in_stride must be multiples of 4");
-    LISEC_CHECK_ARG(c->Cout >= 1 && c->out_stride >= c->Cout, "bad Cout/out_stride");
+    if (c->ps) {
+        LISEC_CHECK_ARG(c->ps >= 1 && c->ps <= 8 && c->ps_channels > 0 && c->ps_channels % 64 == 0 &&
+                        c->Cout == c->ps * c->ps * c->ps_channels && c->out_stride >= c->ps_channels &&
+                        c->Do == 1 && c->KD * c->KH * c->KW == 1,
+                        "pixel-shuffle store needs a 2D 1x1 geometry with Cout = ps*ps*ps_channels, ps_channels % 64 == 0");
+    } else {
+        LISEC_CHECK_ARG(c->out_stride >= c->Cout, "bad out_stride");
+    }
+    LISEC_CHECK_ARG(c->Cout >= 1, "bad Cout");
     LISEC_CHECK_ARG((long long)c->Do * c->Ho * c->Wo < (1LL << 30), "too many output positions");
     g->Di = c->Di; g->Hi = c->Hi; g->Wi = c->Wi; g->Do = c->Do; g->Ho = c->Ho; g->Wo = c->Wo;
     g->KD = c->KD; g->KH = c->KH; g->KW = c->KW; g->ls_d = ld; g->ls_h = lh; g->ls_w = lw;
@@ -260,6 +277,7 @@ int conv_geom_check(const lisec_conv_geom* c, ConvGeom* g) {
     g->Cin = c->Cin; g->in_stride = c->in_stride; g->Cout = c->Cout; g->out_stride = c->out_stride;
     g->CoutP = (int)align_up(c->Cout, 64);
     g->M = c->Do * c->Ho * c->Wo;
+    g->ps = c->ps; g->ps_channels = c->ps_channels;
     return 0;
 }
 

@@ -84,14 +84,22 @@ k_gather(const int* __restrict__ info, const int* __restrict__ cell_voxel, int n
     }
 }
 
-__global__ void k_virtual_dout(const int* __restrict__ info, int cap, const double* __restrict__ parts,
-                               int nparts, float* __restrict__ dout) {
+__global__ void __launch_bounds__(1024)
+k_virtual_dout(const int* __restrict__ info, int cap, const double* __restrict__ parts, int nparts,
+               float* __restrict__ dout) {
+    __shared__ double red[16][64];
     int V = info[LISEC_VI_NVOX];
     if (V > cap) V = cap;
-    const int c = threadIdx.x;
+    const int c = threadIdx.x & 63, ry = threadIdx.x >> 6;
     double a = 0.0;
-    for (int b = 0; b < nparts; ++b) a += parts[(size_t)b * 64 + c];
-    dout[(size_t)V * 64 + c] = (float)a;
+    for (int b = ry; b < nparts; b += 16) a += parts[(size_t)b * 64 + c];
+    red[ry][c] = a;
+    __syncthreads();
+    for (int o = 8; o > 0; o >>= 1) {
+        if (ry < o) red[ry][c] += red[ry + o][c];
+        __syncthreads();
+    }
+    if (ry == 0) dout[(size_t)V * 64 + c] = (float)red[0][c];
 }
 
 __device__ __forceinline__ void block_stats_out(double s1, double s2, int C, double* parts, int w, int lane) {
@@ -422,7 +430,7 @@ extern "C" int lisec_vfe_backward(const lisec_vfe_params* p, const int32_t* info
     const int gblocks = 1024;
     hipLaunchKernelGGL(k_gather, dim3(gblocks), dim3(256), 0, st, info, cell_voxel, ncells, cap_voxels, dgrid,
                        ws.dout, ws.parts_a);
-    hipLaunchKernelGGL(k_virtual_dout, dim3(1), dim3(64), 0, st, info, cap_voxels, ws.parts_a, gblocks, ws.dout);
+    hipLaunchKernelGGL(k_virtual_dout, dim3(1), dim3(1024), 0, st, info, cap_voxels, ws.parts_a, gblocks, ws.dout);
     LISEC_LAUNCH_CHECK();
     // 2. layer 3 (fcn)
     hipLaunchKernelGGL(k_l3_stats, dim3(kBwdBlocks), dim3(256), 0, st, in, sv.bn3, sv.ymm3, ws.dout, ws.parts_a);

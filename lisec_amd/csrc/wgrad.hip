@@ -25,7 +25,8 @@ constexpr int TILE_FLOATS = BMW * BC;            // 8192 (32 KB)
 template <int MODE, int TG>
 __global__ void __launch_bounds__(kThreads)
 k_wgrad(ConvGeom g, const float* __restrict__ in, const float* __restrict__ in_bn, int flags,
-        const float* __restrict__ dy, int nsplit, int tiles_per_split, float* __restrict__ partial) {
+        const float* __restrict__ dy, const float* __restrict__ dy_bn, int nsplit, int tiles_per_split,
+        float* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sA = smem;
     float* sD = smem + TILE_FLOATS;
@@ -50,6 +51,13 @@ k_wgrad(ConvGeom g, const float* __restrict__ in, const float* __restrict__ in_b
         tsh = *reinterpret_cast<const float4*>(in_bn + g.Cin + cA);
     }
     const float relu_lo = (flags & LISEC_CONV_IN_RELU) ? 0.f : -INFINITY;
+    float4 dsc = make_float4(1, 1, 1, 1), dsh = make_float4(0, 0, 0, 0);
+    if (dy_bn && cokD) {
+        dsc = *reinterpret_cast<const float4*>(dy_bn + cD);
+        dsh = *reinterpret_cast<const float4*>(dy_bn + g.Cout + cD);
+    }
+    const float drelu_lo = (flags & LISEC_CONV_DY_RELU) ? 0.f : -INFINITY;
+    unsigned dvalid = 0;
 
     f32x16 acc[TG];
 #pragma unroll
@@ -99,11 +107,16 @@ k_wgrad(ConvGeom g, const float* __restrict__ in, const float* __restrict__ in_b
         }
     };
     auto load_d = [&](int tile) {
+        dvalid = 0;
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
             int m = tile * BMW + p * 16 + (tid >> 4);
-            rd[p] = (m < g.M && cokD) ? *reinterpret_cast<const float4*>(dy + (size_t)m * g.out_stride + cD)
-                                      : make_float4(0, 0, 0, 0);
+            if (m < g.M && cokD) {
+                rd[p] = *reinterpret_cast<const float4*>(dy + (size_t)m * g.out_stride + cD);
+                dvalid |= 1u << p;
+            } else {
+                rd[p] = make_float4(0, 0, 0, 0);
+            }
         }
     };
     auto store_a = [&]() {
@@ -120,8 +133,15 @@ k_wgrad(ConvGeom g, const float* __restrict__ in, const float* __restrict__ in_b
     };
     auto store_d = [&]() {
 #pragma unroll
-        for (int p = 0; p < 8; ++p)
-            *reinterpret_cast<float4*>(sD + (p * 16 + (tid >> 4)) * BC + piece * 4) = rd[p];
+        for (int p = 0; p < 8; ++p) {
+            float4 v = rd[p];
+            const bool ok = (dvalid >> p) & 1;
+            v.x = ok ? fmaxf(fmaf(v.x, dsc.x, dsh.x), drelu_lo) : 0.f;
+            v.y = ok ? fmaxf(fmaf(v.y, dsc.y, dsh.y), drelu_lo) : 0.f;
+            v.z = ok ? fmaxf(fmaf(v.z, dsc.z, dsh.z), drelu_lo) : 0.f;
+            v.w = ok ? fmaxf(fmaf(v.w, dsc.w, dsh.w), drelu_lo) : 0.f;
+            *reinterpret_cast<float4*>(sD + (p * 16 + (tid >> 4)) * BC + piece * 4) = v;
+        }
     };
 
     // MFMA 32x32x2: A operand lane(i = c, h) <- A_tap[m = 8*kk + 4h + j][c]; B operand lane(h, n) <- dY[m][n]
@@ -236,11 +256,11 @@ WgradPlan make_plan(const ConvGeom& g) {
 
 template <int MODE>
 int launch_wgrad(const ConvGeom& g, const WgradPlan& p, const float* in, const float* in_bn, int flags,
-                 const float* dy, float* partial, hipStream_t st) {
+                 const float* dy, const float* dy_bn, float* partial, hipStream_t st) {
     dim3 grid(p.nsplit * p.ngroups, cdiv(g.Cin, BC), cdiv(g.Cout, BC));
     size_t lds = 2 * TILE_FLOATS * sizeof(float);
 #define LISEC_WG(T) hipLaunchKernelGGL((k_wgrad<MODE, T>), grid, dim3(kThreads), lds, st, g, in, in_bn, flags, dy, \
-                                       p.nsplit, p.tiles_per_split, partial)
+                                       dy_bn, p.nsplit, p.tiles_per_split, partial)
     switch (p.TG) {
         case 1: LISEC_WG(1); break;
         case 2: LISEC_WG(2); break;
@@ -264,8 +284,8 @@ extern "C" size_t lisec_conv_wgrad_workspace_bytes(const lisec_conv_geom* c) {
 }
 
 extern "C" int lisec_conv_wgrad(const lisec_conv_geom* c, const float* in, const float* in_bnstate, int flags,
-                                const float* dy, void* workspace, size_t workspace_bytes, int transpose_out,
-                                float* dW, lisec_stream_t stream_) {
+                                const float* dy, const float* dy_bnstate, void* workspace,
+                                size_t workspace_bytes, int transpose_out, float* dW, lisec_stream_t stream_) {
     ConvGeom g;
     if (int rc = conv_geom_check(c, &g)) return rc;
     LISEC_CHECK_ARG(in && dy && workspace && dW, "NULL pointer");
@@ -278,8 +298,8 @@ extern "C" int lisec_conv_wgrad(const lisec_conv_geom* c, const float* in, const
     }
     hipStream_t st = static_cast<hipStream_t>(stream_);
     float* partial = static_cast<float*>(workspace);
-    int rc = c->mode == 0 ? launch_wgrad<0>(g, p, in, in_bnstate, flags, dy, partial, st)
-                          : launch_wgrad<1>(g, p, in, in_bnstate, flags, dy, partial, st);
+    int rc = c->mode == 0 ? launch_wgrad<0>(g, p, in, in_bnstate, flags, dy, dy_bnstate, partial, st)
+                          : launch_wgrad<1>(g, p, in, in_bnstate, flags, dy, dy_bnstate, partial, st);
     if (rc) return rc;
     const int ntaps = g.KD * g.KH * g.KW;
     long long per = (long long)ntaps * g.Cin * g.Cout;

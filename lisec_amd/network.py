@@ -85,12 +85,20 @@ class LisecNet:
                 src, src_bn, h, w, cin = f"{n}.y{j}", f"{n}.bn{j}", ho, wo, cout
             k, s = DECONVS[b]
             pad = (k - s) // 2
-            g = ops.geom(1, (1, h, w), (1, h * s, w * s), (1, k, k), (1, s, s), (0, pad, pad), cin, 256, out_stride=768)
             if (h * s, w * s) != (Ho, Wo):
                 raise ValueError("deconv output does not match the concat map")
-            self.layers.append(dict(kind="deconv", name=f"up{b+1}", src=src, slot=b, conv=ConvLayer(
-                f"up{b+1}", g, f"up{b+1}.kernel", (k * k, cin, 256, 256 * cin, 1, cin), bias=f"up{b+1}.bias",
-                in_bn=src_bn, in_relu=True)))
+            if k == s:
+                # kernel == stride: no overlap -> a 1x1 GEMM whose columns (tap, n) are pixel-shuffled on store
+                g = ops.geom(0, (1, h, w), (1, h, w), (1, 1, 1), (1, 1, 1), (0, 0, 0), cin, k * k * 256,
+                             out_stride=768, ps=s, ps_channels=256)
+                pack = (1, cin, k * k * 256, 0, 1, cin)
+            else:
+                g = ops.geom(1, (1, h, w), (1, h * s, w * s), (1, k, k), (1, s, s), (0, pad, pad), cin, 256,
+                             out_stride=768)
+                pack = (k * k, cin, 256, 256 * cin, 1, cin)
+            self.layers.append(dict(kind="deconv", name=f"up{b+1}", src=src, slot=b, k=k, s=s, pad=pad, hw=(h, w),
+                                    cin=cin, conv=ConvLayer(f"up{b+1}", g, f"up{b+1}.kernel", pack,
+                                                            bias=f"up{b+1}.bias", in_bn=src_bn, in_relu=True)))
         buf("head", Ho, Wo, 16)
         self.Ho, self.Wo = Ho, Wo
         self.head_geom = ops.geom(0, (1, Ho, Wo), (1, Ho, Wo), (1, 1, 1), (1, 1, 1), (0, 0, 0), 768, 16)
@@ -200,10 +208,16 @@ class LisecNet:
             ws_bytes = max(ws_bytes, ops.wgrad_workspace_bytes(g))
             if L["kind"] == "deconv":
                 # data gradient of a transposed conv = plain strided conv over dY (K = out, N = in)
-                self.dgeom[c.name] = ops.geom(0, (1, g.Ho, g.Wo), (1, g.Hi, g.Wi), (1, g.KH, g.KW),
-                                              (1, g.sh, g.sw), (0, g.ph, g.pw), 256, g.Cin, in_stride=768)
-                self.packed_t[c.name] = (torch.empty(ops.packed_floats(ntaps, 256, g.Cin), dtype=f32, device=dev),
-                                         (ntaps, 256, g.Cin, 256 * g.Cin, g.Cin, 1))
+                k, sd, pad, (h, w), cin = L["k"], L["s"], L["pad"], L["hw"], L["cin"]
+                ntaps = k * k
+                self.dgeom[c.name] = ops.geom(0, (1, Ho, Wo), (1, h, w), (1, k, k), (1, sd, sd), (0, pad, pad),
+                                              256, cin, in_stride=768)
+                self.packed_t[c.name] = (torch.empty(ops.packed_floats(ntaps, 256, cin), dtype=f32, device=dev),
+                                         (ntaps, 256, cin, 256 * cin, cin, 1))
+                if k == sd:
+                    # weight gradient with swapped roles: gather dY (stride s), contract against the input rows
+                    L["wgeom"] = self.dgeom[c.name]
+                    ws_bytes = max(ws_bytes, ops.wgrad_workspace_bytes(L["wgeom"]))
             else:
                 self.dgeom[c.name] = ops.geom(1, (g.Do, g.Ho, g.Wo), (g.Di, g.Hi, g.Wi), (g.KD, g.KH, g.KW),
                                               (g.sd, g.sh, g.sw), (g.pd, g.ph, g.pw), g.Cout, g.Cin)
@@ -268,8 +282,12 @@ class LisecNet:
             if L["kind"] == "deconv":
                 b = L["slot"]
                 dy = d["concat"][:, :, 256 * b:]
-                ops.conv_wgrad(c.g, a[L["src"]], dy, p.grad_view(G, c.wname), self.wgrad_ws,
-                               in_bn=self.bnstate[c.in_bn], flags=ops.IN_RELU, transpose_out=True)
+                if "wgeom" in L:
+                    ops.conv_wgrad(L["wgeom"], dy, a[L["src"]], p.grad_view(G, c.wname), self.wgrad_ws,
+                                   flags=ops.DY_RELU, dy_bn=self.bnstate[c.in_bn])
+                else:
+                    ops.conv_wgrad(c.g, a[L["src"]], dy, p.grad_view(G, c.wname), self.wgrad_ws,
+                                   in_bn=self.bnstate[c.in_bn], flags=ops.IN_RELU, transpose_out=True)
                 ops.colsum(dy, 768, M, 256, p.grad_view(G, c.bias))
                 dgrad_into(c, dy, L["src"])
             elif L["kind"] == "conv":

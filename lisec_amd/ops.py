@@ -7,10 +7,11 @@ import torch
 from . import _lib
 from ._lib import ConvGeom
 
-IN_RELU, OUT_RELU, ACCUMULATE = 1, 2, 4
+IN_RELU, OUT_RELU, ACCUMULATE, DY_RELU = 1, 2, 4, 8
 
 
-def geom(mode, in_dims, out_dims, kernel, stride, pad, cin, cout, in_stride=None, out_stride=None):
+def geom(mode, in_dims, out_dims, kernel, stride, pad, cin, cout, in_stride=None, out_stride=None, ps=0,
+         ps_channels=0):
     """in_dims/out_dims/kernel/stride/pad: 3-tuples (d, h, w)."""
     g = ConvGeom()
     g.mode = mode
@@ -22,6 +23,7 @@ def geom(mode, in_dims, out_dims, kernel, stride, pad, cin, cout, in_stride=None
     g.Cin, g.Cout = cin, cout
     g.in_stride = in_stride if in_stride is not None else cin
     g.out_stride = out_stride if out_stride is not None else cout
+    g.ps, g.ps_channels = ps, ps_channels
     return g
 
 
@@ -70,9 +72,10 @@ def wgrad_workspace_bytes(g):
     return _lib.load().lisec_conv_wgrad_workspace_bytes(ctypes.byref(g))
 
 
-def conv_wgrad(g, x, dy, dW, workspace, in_bn=None, flags=0, transpose_out=False):
+def conv_wgrad(g, x, dy, dW, workspace, in_bn=None, flags=0, transpose_out=False, dy_bn=None):
     _lib.check(_lib.load().lisec_conv_wgrad(ctypes.byref(g), _lib.ptr(x), _lib.ptr(in_bn), flags, _lib.ptr(dy),
-                                            _lib.ptr(workspace), workspace.numel() * workspace.element_size(),
+                                            _lib.ptr(dy_bn), _lib.ptr(workspace),
+                                            workspace.numel() * workspace.element_size(),
                                             1 if transpose_out else 0, _lib.ptr(dW), _lib.current_stream()))
     return dW
 

@@ -73,6 +73,12 @@ def test_wgrad_and_dgrad_conv2d_transpose(k, s, cin):
     _close(dW, w.grad)
     # data gradient wrt a: mode-0 conv over dY with stride s, K = out, N = in
     geo_d = ops.geom(0, (1, Ho, Wo), (1, H, W), (1, k, k), (1, s, s), (0, pad, pad), cout, cin, in_stride=768)
+    if k == s:
+        # kernel == stride: weight gradient with swapped roles (gather dY, contract against relu(bn(x)))
+        ws2 = torch.empty(ops.wgrad_workspace_bytes(geo_d), dtype=torch.uint8, device=DEV)
+        dW2 = torch.full(w.shape, float("nan"), device=DEV)
+        ops.conv_wgrad(geo_d, dcat_d[:, :, 512:], x.detach().to(DEV), dW2, ws2, flags=ops.DY_RELU, dy_bn=bn)
+        _close(dW2, w.grad)
     wp = ops.pack_weights(w.detach().to(DEV), k * k, cout, cin, cout * cin, cin, 1)
     da = torch.full((H, W, cin), float("nan"), device=DEV)
     ops.conv_forward(geo_d, dcat_d[:, :, 512:], wp, da)

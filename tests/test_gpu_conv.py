@@ -101,6 +101,15 @@ def test_conv2d_transpose(k, s, cin):
     ops.conv_forward(geo, x.to(DEV), wp, cat[:, :, 256:], bias=b.to(DEV), in_bn=bn, flags=ops.IN_RELU)
     _close(cat[:, :, 256:512], ref)
     assert (cat[:, :, :256] == 0).all() and (cat[:, :, 512:] == 0).all()
+    if k == s:
+        # kernel == stride: the same layer as a 1x1 GEMM with a pixel-shuffle store (the path LisecNet uses)
+        geo = ops.geom(0, (1, H, W), (1, H, W), (1, 1, 1), (1, 1, 1), (0, 0, 0), cin, k * k * cout,
+                       out_stride=768, ps=s, ps_channels=cout)
+        wp = ops.pack_weights(w.to(DEV), 1, cin, k * k * cout, 0, 1, cin)
+        cat2 = torch.zeros(Ho, Wo, 768, device=DEV)
+        ops.conv_forward(geo, x.to(DEV), wp, cat2[:, :, 512:], bias=b.to(DEV), in_bn=bn, flags=ops.IN_RELU)
+        _close(cat2[:, :, 512:], ref)
+        assert (cat2[:, :, :512] == 0).all()
 
 
 def test_accumulate_and_data_gradient():
