@@ -1,0 +1,28 @@
+"""Drop-in counterpart of the reference's Predict.py: predictMain(samples, outPath, level5Data, model)."""
+import os
+import time
+
+import numpy as np
+
+from . import Constants
+from .model_training import (MaxPoolingVFELayer, RepeatLayer, VFE_preprocessing, combine_lidar_data,  # noqa: F401
+                             load_model, sparse)
+
+
+def predictMain(samples, outPath, level5Data, model, dataDir=None):
+    """For every sample: assemble the lidar sweep, voxelise, run the network in inference mode and save
+    outPath/sample{i}_label.npy (1,100,200,2) and outPath/sample{i}_regress.npy (1,100,200,14), float32
+    (Predict.py:9-40; the reference joins the path with a literal backslash, i.e. Windows only)."""
+    dataDir = dataDir if dataDir is not None else Constants.lyft_data_dir
+    os.makedirs(outPath, exist_ok=True)
+    for i in range(len(samples)):
+        sampleLidarPoints = combine_lidar_data(samples[i], dataDir, level5Data)
+        startTime = time.time()
+        trainVFEPoints = VFE_preprocessing(sampleLidarPoints, Constants.voxelx, Constants.voxely, Constants.voxelz,
+                                           Constants.maxPoints, Constants.nx // 2, Constants.ny // 2, Constants.nz)
+        trainVFEPoints = sparse.reshape(trainVFEPoints, (1,) + trainVFEPoints.shape)     # Predict.py:29
+        print(time.time() - startTime)
+        print('finished ' + str(i))
+        prob, regress = model.predict(trainVFEPoints)                                     # Predict.py:38
+        np.save(os.path.join(outPath, 'sample' + str(i) + '_label.npy'), prob)
+        np.save(os.path.join(outPath, 'sample' + str(i) + '_regress.npy'), regress)

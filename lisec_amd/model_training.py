@@ -1,0 +1,382 @@
+"""Drop-in counterpart of the reference's model_training.py (same public names and argument order):
+
+    get_voxel, VFE_preprocessing, combine_lidar_data, rotate_points, RepeatLayer, MaxPoolingVFELayer,
+    createModel, load_model, optimizers.SGD, train, train_with_model
+
+The Keras graph is replaced by lisec_amd.network.LisecNet (HIP kernels behind the C ABI); lidar sweeps
+stay sparse on the GPU instead of being densified to (8,200,400,35,6) and stacked in host RAM
+(reference model_training.py:279,285).  There is no CPU fallback.
+"""
+import json
+import os
+import time
+
+import numpy as np
+import torch
+
+from . import Constants, _lib
+from .network import LisecNet
+from .params import ParamStore
+from .voxelizer import VoxelSample, Voxelizer
+
+
+# ---------------------------------------------------------------------------------------------------
+# voxeliser front end (reference model_training.py:103-152)
+def get_voxel(point, xSize, ySize, zSize):
+    """Voxel coordinate of a point; voxels are named by their lower corner (model_training.py:103-107)."""
+    from math import floor
+    return (floor(point[0] / xSize), floor(point[1] / ySize), floor(point[2] / zSize))
+
+
+_VOXELIZERS = {}
+
+
+def VFE_preprocessing(points, xSize, ySize, zSize, sampleSize, maxVoxelX, maxVoxelY, maxVoxelZ):
+    """points (n, >=3) -> SparseVoxels, the stand-in for the tf.SparseTensor of dense_shape
+    [maxVoxelZ, 2*maxVoxelX, 2*maxVoxelY, sampleSize, 6] the reference returns (model_training.py:112-152).
+    Deterministic: a voxel holding more than sampleSize points keeps the lowest point indices."""
+    key = (float(xSize), float(ySize), float(zSize), int(sampleSize), int(maxVoxelX), int(maxVoxelY), int(maxVoxelZ))
+    if key not in _VOXELIZERS:
+        _VOXELIZERS[key] = Voxelizer(*key[:3], key[3], *key[4:])
+    return SparseVoxels(_VOXELIZERS[key](points))
+
+
+class SparseVoxels:
+    """Quacks like the SparseTensor the reference builds: .indices (z,x,y,t,f), .values, .dense_shape
+    (materialised on the host only when asked for); carries the device-resident VoxelSample the network eats."""
+
+    def __init__(self, sample):
+        self.sample = sample
+        c = sample.cfg
+        self.dense_shape = [c.maxVoxelZ, 2 * c.maxVoxelX, 2 * c.maxVoxelY, c.sampleSize, 6]
+        self.shape = tuple(self.dense_shape)
+        self._coo = None
+
+    def _materialise(self):
+        if self._coo is None:
+            h = self.sample.to_host()
+            V, T = len(h["coords"]), self.sample.cfg.sampleSize
+            idx = np.empty((V, T, 6, 5), dtype=np.int64)
+            idx[..., :3] = h["coords"][:, None, None, :]
+            idx[..., 3] = np.arange(T)[None, :, None]
+            idx[..., 4] = np.arange(6)[None, None, :]
+            self._coo = (idx.reshape(-1, 5), h["feats"].reshape(-1))
+        return self._coo
+
+    @property
+    def indices(self):
+        return self._materialise()[0]
+
+    @property
+    def values(self):
+        return self._materialise()[1]
+
+
+class sparse:   # noqa: N801  (mirrors `from tensorflow import sparse`)
+    @staticmethod
+    def to_dense(st, default_value=0., validate_indices=False):
+        """tf.sparse.to_dense (model_training.py:279): host numpy array of st.dense_shape.  Only meant for
+        small grids / inspection -- the network consumes the sparse form directly."""
+        dense = np.full(st.dense_shape, default_value, dtype=np.float32)
+        idx, val = st.indices, st.values
+        dense[tuple(idx.T)] = val
+        return dense
+
+    @staticmethod
+    def reshape(st, shape):
+        return st            # (1,) + shape: the batch axis is implicit (Predict.py:29)
+
+
+def dense_to_sample(dense, device=None):
+    """(D,H,W,T,6) dense array -> VoxelSample.  Every row of a non-empty voxel is kept as a real row
+    (zero rows are numerically identical to pad rows), so this is exact for ANY dense input."""
+    device = device or _lib.require_gpu()
+    dense = np.asarray(dense, dtype=np.float32)
+    D, H, W, T, F = dense.shape
+    if F != 6:
+        raise ValueError("last axis must be 6")
+    flat = dense.reshape(D * H * W, T, 6)
+    occ = np.nonzero(np.abs(flat).reshape(len(flat), -1).max(1) > 0)[0]
+    V = len(occ)
+    cfg = _lib.VoxelCfg(1.0, 1.0, 1.0, H // 2, W // 2, D, T)
+    cell_voxel = np.full(D * H * W, -1, np.int32)
+    cell_voxel[occ] = np.arange(V, dtype=np.int32)
+    coords = np.stack([occ // (H * W), (occ // W) % H, occ % W], 1).astype(np.int32)
+    npts = np.full(V, T, np.int32)
+    t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(device=device, dtype=dt)  # noqa: E731
+    n_rows = max(V * T, 1)
+    rows = np.zeros((n_rows, 6), np.float32)
+    rows[:V * T] = flat[occ].reshape(-1, 6)
+    s = VoxelSample(cfg, n_rows, max(V, 1), t(np.array([V, V * T, V * T, T, 0, 0, 0, 0]), torch.int32),
+                    t(cell_voxel, torch.int32), t(coords if V else np.zeros((1, 3)), torch.int32),
+                    t(npts if V else np.zeros(1), torch.int32), t(npts if V else np.zeros(1), torch.int32),
+                    t(np.arange(max(V, 1) + 1) * T, torch.int32), t(rows, torch.float32),
+                    t(np.arange(n_rows), torch.int32))
+    return s
+
+
+# ---------------------------------------------------------------------------------------------------
+# lidar assembly (reference model_training.py:65-98)
+def _quaternion_matrix(q):
+    w, x, y, z = (float(v) for v in q)
+    n = (w * w + x * x + y * y + z * z) ** 0.5
+    w, x, y, z = w / n, x / n, y / n, z / n
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def rotate_points(points, rotation, inverse=False):
+    """Rotate by a (w,x,y,z) quaternion (model_training.py:65-69)."""
+    R = _quaternion_matrix(rotation)
+    if inverse:
+        R = R.T
+    return np.dot(R, np.asarray(points).T).T
+
+
+def combine_lidar_data(sample, dataDir, level5Data):
+    """Every lidar point of a sample in the car frame, float64 (n,3) (model_training.py:73-98)."""
+    sensorTypes = ['LIDAR_TOP', 'LIDAR_FRONT_RIGHT', 'LIDAR_FRONT_LEFT']
+    actual = [s for s in sensorTypes if s in sample['data']]     # not every sample has all three (:75-79)
+    allPoints = []
+    for sensorType in actual:
+        frame = level5Data.get('sample_data', sample['data'][sensorType])
+        sensor = level5Data.get('calibrated_sensor', frame['calibrated_sensor_token'])
+        filePath = os.path.join(dataDir, *frame['filename'].replace('\\', '/').split('/'))
+        raw = np.fromfile(filePath, dtype=np.float32).reshape(-1, 5)[:, :3]          # :87-90
+        pts = rotate_points(raw, sensor['rotation']) + np.array(sensor['translation'])   # :93-94
+        allPoints.append(pts)
+    return np.concatenate(allPoints)
+
+
+# ---------------------------------------------------------------------------------------------------
+# the two custom layers the reference names in custom_objects (model_training.py:32-61)
+class RepeatLayer:
+    """repeat_elements(x, maxPoints, axis=-2): (…,1,C) -> (…,35,C)."""
+
+    def __call__(self, inputs):
+        return torch.repeat_interleave(torch.as_tensor(inputs), Constants.maxPoints, dim=Constants.pointIndex)
+
+    call = __call__
+
+
+class MaxPoolingVFELayer:
+    """max over the point axis, keepdims unless combine=True; pad rows take part (no mask)."""
+
+    def __init__(self, combine=False, **kwargs):
+        self.combineDim = combine
+
+    def __call__(self, inputs):
+        return torch.as_tensor(inputs).max(dim=Constants.pointIndex, keepdim=not self.combineDim).values
+
+    call = __call__
+
+    def get_config(self):
+        return {'combine': self.combineDim}
+
+
+# ---------------------------------------------------------------------------------------------------
+class optimizers:   # noqa: N801  (mirrors `from tensorflow.keras import optimizers`)
+    class SGD:
+        def __init__(self, lr=0.01, decay=0.0, momentum=0.0, nesterov=False, learning_rate=None):
+            self.lr = learning_rate if learning_rate is not None else lr
+            self.decay, self.momentum, self.nesterov = decay, momentum, nesterov
+            if not nesterov:
+                raise NotImplementedError("only the reference's configuration (nesterov=True) is implemented")
+
+
+class History:
+    def __init__(self):
+        self.history = {}
+
+
+class Model:
+    """What createModel returns: the subset of the keras.Model interface the reference uses."""
+
+    def __init__(self, nx, ny, nz, maxPoints, params=None):
+        self.nx, self.ny, self.nz, self.maxPoints = nx, ny, nz, maxPoints
+        self.net = LisecNet(nx, ny, nz, maxPoints, params=params)
+        self.optimizer, self.loss = None, None
+        self.dp = None
+        if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+            from .parallel import DataParallel
+            self.dp = DataParallel(self.net.device)
+            self.dp.broadcast_(self.net.params.theta)
+            self.dp.broadcast_(self.net.params.state)
+
+    # -- compile / fit / predict / save ------------------------------------------------------------
+    def compile(self, optimizer, loss):
+        """compile(optimizer=sgd, loss=['mse','mse']) (model_training.py:296).  A fresh optimizer discards
+        velocity and iteration count, as re-compiling does in the reference (:339-340)."""
+        if isinstance(loss, (list, tuple)):
+            kinds = [str(x).lower() for x in loss]
+            if kinds == ['mse', 'mse']:
+                loss = 'mse'
+            elif kinds == ['cross_entropy', 'smooth_l1'] or kinds == ['smoothl1_ce']:
+                loss = 'smoothl1_ce'
+            else:
+                raise ValueError(f"unsupported loss list {loss}")
+        if loss not in ('mse', 'smoothl1_ce'):
+            raise ValueError(f"unsupported loss {loss}")
+        self.optimizer, self.loss = optimizer, loss
+        self.net._prepare_training()
+        self.net.velocity.zero_()
+        self.net.iterations = 0
+
+    def _as_samples(self, x):
+        if isinstance(x, SparseVoxels):
+            return [x.sample]
+        if isinstance(x, VoxelSample):
+            return [x]
+        if isinstance(x, (list, tuple)):
+            return [s for item in x for s in self._as_samples(item)]
+        arr = np.asarray(x)
+        if arr.ndim == 5:
+            arr = arr[None]
+        if arr.ndim != 6:
+            raise ValueError("expected SparseVoxels / list of them / dense (n,D,H,W,T,6) array")
+        return [dense_to_sample(a, self.net.device) for a in arr]
+
+    def fit(self, x, y, batch_size=1, verbose=1, epochs=1, steps_per_epoch=None, shuffle=True):
+        """fit(x=trainPoints, y=[outClass, outRegress], batch_size=1, epochs=1, steps_per_epoch=180)
+        (model_training.py:299).  batch_size must be 1 (the reference's setting: BatchNormalization
+        statistics are per sample).  With WORLD_SIZE > 1 whole samples are sharded over the ranks and the
+        gradients averaged with one RCCL all-reduce per step."""
+        if self.optimizer is None:
+            raise RuntimeError("compile() the model first")
+        if batch_size != 1:
+            raise NotImplementedError("only batch_size=1, the reference's setting, is implemented")
+        samples = self._as_samples(x)
+        ycls = np.asarray(y[0], dtype=np.float32)
+        yreg = np.asarray(y[1], dtype=np.float32)
+        n = len(samples)
+        if len(ycls) < n or len(yreg) < n:
+            raise ValueError("fewer label maps than samples")
+        idx = list(range(n))
+        if self.dp is not None:
+            idx = self.dp.shard(idx)
+        steps = steps_per_epoch if steps_per_epoch is not None else len(idx)
+        if self.dp is not None and steps_per_epoch is not None:
+            steps = max(1, steps_per_epoch // self.dp.world)
+        dev = self.net.device
+        hist = History()
+        o = self.optimizer
+        for _ in range(epochs):
+            order = list(np.random.permutation(idx)) if shuffle else list(idx)
+            tot = np.zeros(3)
+            t0 = time.time()
+            for st in range(steps):
+                i = int(order[st % len(order)])
+                yc = torch.from_numpy(np.ascontiguousarray(ycls[i])).to(dev)
+                yr = torch.from_numpy(np.ascontiguousarray(yreg[i])).to(dev)
+                self.net.forward(samples[i], training=True)
+                self.net.backward(yc, yr, loss=self.loss)
+                if self.dp is not None:
+                    self.dp.average_(self.net.grad)
+                self.net.apply_gradients(lr=o.lr, decay=o.decay, momentum=o.momentum)
+                tot += self.net.loss_out.cpu().numpy()
+                if verbose:
+                    print(f"\r{st + 1}/{steps} - loss: {tot[0] / (st + 1):.4f}", end="", flush=True)
+            if verbose:
+                print(f" - {time.time() - t0:.1f}s")
+            for key, v in zip(("loss", "ClassificationLayer_loss", "RegressionLayer_loss"), tot / max(steps, 1)):
+                hist.history.setdefault(key, []).append(float(v))
+        return hist
+
+    def predict(self, x):
+        """predict(testVFEPointsDense) -> [prob (n,Ho,Wo,2), regress (n,Ho,Wo,14)] (Predict.py:38);
+        BatchNormalization uses the moving statistics."""
+        probs, regs = [], []
+        for s in self._as_samples(x):
+            cls, reg = self.net.forward(s, training=False)
+            probs.append(cls.cpu().numpy().copy())
+            regs.append(reg.cpu().numpy().copy())
+        return [np.concatenate(probs), np.concatenate(regs)]
+
+    def save(self, path):
+        """model.save(save_path) (model_training.py:302).  libhdf5/h5py are not part of this image: the
+        variables are written as a numpy .npz archive AT `path` (whatever its extension) with the layer-wise
+        names of lisec_amd.params.param_specs(); load_model reads it back.  Keras-HDF5 interchange is a
+        listed next step."""
+        d = self.net.params.to_dict()
+        meta = dict(format="lisec_amd-npz-1", nx=self.nx, ny=self.ny, nz=self.nz, maxPoints=self.maxPoints,
+                    iterations=self.net.iterations)
+        os.makedirs(os.path.dirname(os.path.abspath(path)) or ".", exist_ok=True)
+        with open(path, "wb") as f:
+            np.savez(f, __meta__=np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8), **d)
+
+    def summary(self):
+        n = self.net.params.n_trainable()
+        print(f"LisecNet grid ({self.nz},{self.nx},{self.ny},{self.maxPoints},6) -> "
+              f"({self.nx // 2},{self.ny // 2},2) / ({self.nx // 2},{self.ny // 2},14); trainable params: {n:,}")
+
+
+def createModel(nx, ny, nz, maxPoints):
+    """createModel(Constants.nx, Constants.ny, Constants.nz, Constants.maxPoints) (model_training.py:222-257)."""
+    return Model(nx, ny, nz, maxPoints)
+
+
+def load_model(path, custom_objects=None):
+    """load_model(model_path, custom_objects={'RepeatLayer':…, 'MaxPoolingVFELayer':…}) (:337-338)."""
+    with open(path, "rb") as f:
+        magic = f.read(8)
+    if magic[:4] == b"\x89HDF":
+        raise _lib.LisecError("Keras HDF5 files need h5py/libhdf5, which this image lacks; "
+                              "re-save the weights as .npz with the names of lisec_amd.params.param_specs()")
+    z = np.load(path, allow_pickle=False)
+    meta = json.loads(bytes(z["__meta__"]).decode())
+    dev = _lib.require_gpu()
+    params = ParamStore(dev, init={k: z[k] for k in z.files if k != "__meta__"})
+    m = Model(meta["nx"], meta["ny"], meta["nz"], meta["maxPoints"], params=params)
+    m.net.iterations = int(meta.get("iterations", 0))
+    return m
+
+
+# ---------------------------------------------------------------------------------------------------
+def _preprocess(samples, level5Data, dataDir):
+    points = []
+    for i in range(len(samples)):
+        sampleLidarPoints = combine_lidar_data(samples[i], dataDir, level5Data)
+        startTime = time.time()
+        vfe_points = VFE_preprocessing(sampleLidarPoints, Constants.voxelx, Constants.voxely, Constants.voxelz,
+                                       Constants.maxPoints, Constants.nx // 2, Constants.ny // 2, Constants.nz)
+        points.append(vfe_points)       # stays sparse on the GPU: no to_dense, no 500 GB tf.stack (:279-285)
+        print(time.time() - startTime)
+        print('finished ' + str(i))
+    return points
+
+
+def _load_labels(labels_dir='labels3'):
+    print('loading labels')
+    outClass = np.load(os.path.join(labels_dir, 'labelsClass.npy'), allow_pickle=False)      # :289
+    outRegress = np.load(os.path.join(labels_dir, 'regressClass.npy'), allow_pickle=False)   # :290
+    return outClass, outRegress
+
+
+def train(samples, level5Data, save_path):
+    """train(samples, level5Data, save_path) (model_training.py:260-302)."""
+    trainPoints = _preprocess(samples, level5Data, Constants.lyft_data_dir)
+    outClass, outRegress = _load_labels()
+    model = createModel(Constants.nx, Constants.ny, Constants.nz, Constants.maxPoints)
+    sgd = optimizers.SGD(lr=0.01, decay=1e-6, momentum=0.9, nesterov=True)
+    model.compile(optimizer=sgd, loss=['mse', 'mse'])
+    history = model.fit(x=trainPoints, y=[outClass, outRegress], batch_size=1, verbose=1, epochs=1,
+                        steps_per_epoch=180)
+    print(history.history)
+    model.save(save_path)
+    return model
+
+
+def train_with_model(samples, level5Data, model_path, save_path):
+    """train_with_model(samples, level5Data, model_path, save_path) (model_training.py:305-346)."""
+    trainPoints = _preprocess(samples, level5Data, Constants.lyft_data_dir)
+    outClass, outRegress = _load_labels()
+    model = load_model(model_path, custom_objects={'RepeatLayer': RepeatLayer,
+                                                   'MaxPoolingVFELayer': MaxPoolingVFELayer})
+    sgd = optimizers.SGD(lr=0.01, decay=1e-6, momentum=0.9, nesterov=True)
+    model.compile(optimizer=sgd, loss=['mse', 'mse'])
+    history = model.fit(x=trainPoints, y=[outClass, outRegress], batch_size=1, verbose=1, epochs=1,
+                        steps_per_epoch=180)
+    print(history.history)
+    model.save(save_path)
+    return model

@@ -1,0 +1,103 @@
+"""The reference's Python surface (train / train_with_model / predictMain / createModel / load_model) over
+a fake level5Data and synthetic lidar .bin files -- BASELINE config 1's plumbing (the published weights
+SampleModel/15SampleEpoch0.h5 are stripped from the reference, so a seeded random model stands in)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+class FakeLevel5:
+    """Duck-typed LyftDataset: .get('sample_data'|'calibrated_sensor', token) (model_training.py:81-94)."""
+
+    def __init__(self, root, n_samples, rng):
+        self.tables = {"sample_data": {}, "calibrated_sensor": {}}
+        self.samples = []
+        os.makedirs(os.path.join(root, "lidar"), exist_ok=True)
+        for i in range(n_samples):
+            data = {}
+            for j, sensor in enumerate(["LIDAR_TOP", "LIDAR_FRONT_RIGHT", "LIDAR_FRONT_LEFT"][: 3 - (i % 2)]):
+                n = 6000
+                raw = np.zeros((n, 5), np.float32)
+                raw[:, 0] = rng.uniform(-45, 45, n)
+                raw[:, 1] = rng.uniform(-45, 45, n)
+                raw[:, 2] = rng.uniform(-1.0, 1.2, n)
+                fn = f"lidar/s{i}_{sensor}.bin"
+                raw.tofile(os.path.join(root, fn))
+                tok, cal = f"sd{i}{j}", f"cs{i}{j}"
+                self.tables["sample_data"][tok] = {"filename": fn, "calibrated_sensor_token": cal}
+                ang = 0.1 * j
+                self.tables["calibrated_sensor"][cal] = {"rotation": [np.cos(ang / 2), 0, 0, np.sin(ang / 2)],
+                                                         "translation": [0.5 * j, 0.1, 1.0]}
+                data[sensor] = tok
+            self.samples.append({"data": data})
+
+    def get(self, table, token):
+        return self.tables[table][token]
+
+
+def test_train_save_load_predict_roundtrip(tmp_path, monkeypatch):
+    from lisec_amd import Constants, Predict, model_training
+    rng = np.random.default_rng(0)
+    data_root = tmp_path / "lyft"
+    l5 = FakeLevel5(str(data_root), 3, rng)
+    monkeypatch.setattr(Constants, "lyft_data_dir", str(data_root))
+    monkeypatch.chdir(tmp_path)
+    os.makedirs("labels3")
+    np.save("labels3/labelsClass.npy", rng.integers(0, 3, (3, 100, 200, 2)).astype(np.float64))
+    np.save("labels3/regressClass.npy", rng.normal(0, 1, (3, 100, 200, 14)))
+    np.random.seed(0)
+
+    # rotate_points / combine_lidar_data: float64 (n,3), all three / two sensors concatenated
+    pts = model_training.combine_lidar_data(l5.samples[0], str(data_root), l5)
+    assert pts.dtype == np.float64 and pts.shape == (18000, 3)
+    assert model_training.combine_lidar_data(l5.samples[1], str(data_root), l5).shape == (12000, 3)
+    R = model_training._quaternion_matrix([np.cos(0.05), 0, 0, np.sin(0.05)])
+    assert np.allclose(R @ R.T, np.eye(3)) and np.isclose(R[0, 0], np.cos(0.1))
+
+    save_path = str(tmp_path / "models" / "3SampleEpoch0.h5")
+    model = model_training.train(l5.samples, l5, save_path)          # 180 steps on the Lyft grid
+    assert os.path.exists(save_path)
+    assert model.net.iterations == 180
+    out1 = tmp_path / "pred1"
+    Predict.predictMain(l5.samples[:2], str(out1), l5, model)
+    prob = np.load(out1 / "sample0_label.npy")
+    reg = np.load(out1 / "sample1_regress.npy")
+    assert prob.shape == (1, 100, 200, 2) and prob.dtype == np.float32       # rpnToRegion.py:116-117
+    assert reg.shape == (1, 100, 200, 14) and reg.dtype == np.float32
+    assert np.isfinite(prob).all() and np.isfinite(reg).all()
+
+    # reload -> identical predictions; resume training re-compiles with a fresh SGD (:339-340)
+    model2 = model_training.load_model(save_path, custom_objects={
+        "RepeatLayer": model_training.RepeatLayer, "MaxPoolingVFELayer": model_training.MaxPoolingVFELayer})
+    out2 = tmp_path / "pred2"
+    Predict.predictMain(l5.samples[:2], str(out2), l5, model2)
+    assert np.array_equal(np.load(out2 / "sample0_label.npy"), prob)
+    assert np.array_equal(np.load(out2 / "sample1_regress.npy"), reg)
+
+
+def test_sparse_tensor_surface_and_dense_input():
+    """VFE_preprocessing's result quacks like the reference's SparseTensor; a dense (n,D,H,W,T,6) array is
+    accepted by predict() and gives the same answer as the sparse form."""
+    import torch
+    from lisec_amd import model_training as mt
+    from oracle import voxel_ref
+    rng = np.random.default_rng(2)
+    pts = np.stack([rng.uniform(-4.2, 4.2, 800), rng.uniform(-4.2, 4.2, 800), rng.uniform(0.0, 2.1, 800)], 1)
+    st = mt.VFE_preprocessing(pts, 0.5, 0.25, 0.25, 35, 8, 16, 8)
+    assert st.dense_shape == [8, 16, 32, 35, 6]
+    ref = voxel_ref.voxelize_ref(pts, 0.5, 0.25, 0.25, 35, 8, 16, 8)
+    dense = mt.sparse.to_dense(st, default_value=0., validate_indices=False)
+    assert np.array_equal(dense, voxel_ref.to_dense(ref, (8, 16, 32, 35, 6)))
+    assert st.indices.shape == (len(ref["coords"]) * 35 * 6, 5)
+    model = mt.createModel(16, 32, 8, 35)
+    a = model.predict(st)
+    b = model.predict(dense[None])
+    assert a[0].shape == (1, 8, 16, 2) and a[1].shape == (1, 8, 16, 14)
+    assert np.allclose(a[0], b[0], rtol=1e-4, atol=1e-5) and np.allclose(a[1], b[1], rtol=1e-4, atol=1e-5)
+    x = torch.arange(2 * 1 * 3, dtype=torch.float32).reshape(2, 1, 3)
+    assert mt.RepeatLayer()(x).shape == (2, 35, 3)
+    assert mt.MaxPoolingVFELayer(combine=True)(torch.rand(4, 35, 8)).shape == (4, 8)
+    assert mt.get_voxel((-0.1, 0.3, 0.6), 0.5, 0.25, 0.25) == (-1, 1, 2)
