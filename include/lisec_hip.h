@@ -175,10 +175,14 @@ int lisec_conv_num_mblocks(const lisec_conv_geom* g);
  *   bias        NULL or float[Cout]
  *   stats_partials NULL, or double[num_mblocks][2][Cout]: per-tile sum and sum of squares of the
  *               stored values, the input of lisec_bn_finalize (training-mode batch statistics)
+ *   workspace   NULL, or scratch of lisec_conv_forward_workspace_bytes(g): lets layers with few output
+ *               positions (RPN blocks 2-3) be cut into K slices so that they still fill the 256 CUs; the
+ *               slices are combined in a fixed order (deterministic)
  */
+size_t lisec_conv_forward_workspace_bytes(const lisec_conv_geom* g);
 int lisec_conv_forward(const lisec_conv_geom* g, const float* in, const float* packed_w, const float* bias,
                        const float* in_bnstate, int flags, float* out, double* stats_partials,
-                       lisec_stream_t stream);
+                       void* workspace, size_t workspace_bytes, lisec_stream_t stream);
 
 /* Weight gradient of the contraction described by `g` (the geometry of the FORWARD layer):
  *   dW[tap][c][n] = sum_m f(in[src(m,tap), c]) * dy[m, n]      dy: float32, g->out_stride floats per row

@@ -32,6 +32,57 @@ __device__ __forceinline__ int src_coord(int o, int k, int ls, int pad, int n_in
     return s;
 }
 
+// Strength-reduced gather addressing shared by igemm.hip / wgrad.hip.  For an output position
+// (d,h,w) the source element offset of tap (kd,kh,kw) is  row_base + tap_delta  with
+//   mode 0:  a = o*stride - pad           src = a + k              -> base a,          delta +k
+//   mode 1:  a = o + pad                  src = a/stride - k/stride -> base a/stride,  delta -(k/stride)
+//            (valid only when a - k >= 0 and divisible by the stride, for which the identity is exact)
+// and the tap is valid iff the per-axis bits (kd | kh << 4 | kw << 8) are all set in the row's mask.
+struct RowGather {
+    int off;       // element offset of the row's base position (times in_stride), may be negative
+    int mask;      // valid kd bits 0-3, kh bits 4-7, kw bits 8-11; 0 for rows beyond M
+};
+
+__device__ __forceinline__ int axis_mask(int o, int K, int ls, int pad, int n_in, int mode, int& base) {
+    int m = 0;
+    if (mode == 0) {
+        base = (o << ls) - pad;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) m |= (k < K && base + k >= 0 && base + k < n_in) ? (1 << k) : 0;
+    } else {
+        const int a = o + pad;
+        base = a >> ls;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int t = a - k;
+            m |= (k < K && t >= 0 && (t & ((1 << ls) - 1)) == 0 && (t >> ls) < n_in) ? (1 << k) : 0;
+        }
+    }
+    return m;
+}
+
+__device__ __forceinline__ RowGather row_gather(const ConvGeom& g, int m, int mode, int lane_elem_off) {
+    RowGather r;
+    if (m >= g.M) { r.off = 0; r.mask = 0; return r; }
+    const int HW = g.Ho * g.Wo;
+    const int d = m / HW, rem = m - d * HW;
+    const int h = rem / g.Wo, w = rem - h * g.Wo;
+    int bd, bh, bw;
+    const int md = axis_mask(d, g.KD, g.ls_d, g.pd, g.Di, mode, bd);
+    const int mh = axis_mask(h, g.KH, g.ls_h, g.ph, g.Hi, mode, bh);
+    const int mw = axis_mask(w, g.KW, g.ls_w, g.pw, g.Wi, mode, bw);
+    r.mask = md | (mh << 4) | (mw << 8);
+    r.off = ((bd * g.Hi + bh) * g.Wi + bw) * g.in_stride + lane_elem_off;
+    return r;
+}
+
+// wave-uniform per-tap quantities
+__device__ __forceinline__ int tap_delta(const ConvGeom& g, int kd, int kh, int kw, int mode) {
+    if (mode == 0) return ((kd * g.Hi + kh) * g.Wi + kw) * g.in_stride;
+    return -((((kd >> g.ls_d) * g.Hi + (kh >> g.ls_h)) * g.Wi + (kw >> g.ls_w)) * g.in_stride);
+}
+__device__ __forceinline__ int tap_bits(int kd, int kh, int kw) { return (1 << kd) | (16 << kh) | (256 << kw); }
+
 // XCD-aware bijective tile remap: tiles that are neighbours in memory stay on one XCD's L2
 __device__ __forceinline__ int xcd_remap(int orig, int n) {
     const int q = n >> 3, r = n & 7, xcd = orig & 7;

@@ -32,11 +32,11 @@ constexpr int kThreads = 256;
 constexpr int A_FLOATS = BM * LDA;               // 8704
 constexpr int B_FLOATS = BK * BN;                // 4096
 
-template <int MODE>
+template <int MODE, bool XF>
 __global__ void __launch_bounds__(kThreads)
 k_igemm(ConvGeom g, const float* __restrict__ in, const float* __restrict__ wp,
         const float* __restrict__ bias, const float* __restrict__ in_bn, int flags,
-        float* __restrict__ out, double* __restrict__ stats) {
+        float* __restrict__ out, double* __restrict__ stats, int nsplit, float* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sA = smem;
     float* sB = smem + A_FLOATS;
@@ -51,21 +51,17 @@ k_igemm(ConvGeom g, const float* __restrict__ in, const float* __restrict__ wp,
 
     // ---- rows this thread stages: r = p*16 + tid/16, 16-byte piece tid%16 ----------------------
     const int piece = tid & 15;
-    int rowc[8];
+    RowGather rows[8];
 #pragma unroll
-    for (int p = 0; p < 8; ++p) {
-        int m = m0 + p * 16 + (tid >> 4);
-        if (m < g.M) {
-            int d = m / HW, rem = m - d * HW;
-            int h = rem / g.Wo, w = rem - h * g.Wo;
-            rowc[p] = w | (h << 10) | (d << 20);
-        } else {
-            rowc[p] = -1;
-        }
-    }
+    for (int p = 0; p < 8; ++p) rows[p] = row_gather(g, m0 + p * 16 + (tid >> 4), MODE, piece * 4);
     // tile-uniform depth range for whole-tap skipping
     const int mlast = (m0 + BM - 1 < g.M ? m0 + BM - 1 : g.M - 1);
     const int d_first = m0 / HW, d_last = mlast / HW;
+    int dmask_first;
+    {
+        int tmp;
+        dmask_first = axis_mask(d_first, g.KD, g.ls_d, g.pd, g.Di, MODE, tmp);
+    }
 
     const int ncc = (g.Cin + BK - 1) / BK;
     const int ntaps = g.KD * g.KH * g.KW;
@@ -74,15 +70,8 @@ k_igemm(ConvGeom g, const float* __restrict__ in, const float* __restrict__ wp,
 
     auto live = [&](int s) -> bool {
         if (d_first != d_last) return true;
-        int tap = s / ncc;
-        int kd = tap / (g.KH * g.KW);
-        bool ok = true;
-        (void)src_coord(d_first, kd, g.ls_d, g.pd, g.Di, MODE, ok);
-        return ok;
-    };
-    auto advance = [&](int s) -> int {
-        while (s < nsteps && !live(s)) ++s;
-        return s;
+        const int kd = (s / ncc) / (g.KH * g.KW);
+        return (dmask_first >> kd) & 1;
     };
 
     float4 ra[8];
@@ -95,23 +84,17 @@ k_igemm(ConvGeom g, const float* __restrict__ in, const float* __restrict__ wp,
         const int kw = tap % g.KW, kh = (tap / g.KW) % g.KH, kd = tap / (g.KW * g.KH);
         const int c = cc * BK + piece * 4;
         const bool cok = c < g.Cin;
+        const int soff = tap_delta(g, kd, kh, kw, MODE) + cc * BK;     // wave-uniform
+        const int tbits = cok ? tap_bits(kd, kh, kw) : 0x7fffffff;      // channel slab beyond Cin: nothing valid
         valid_mask = 0;
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
-            bool ok = rowc[p] >= 0 && cok;
-            int w = rowc[p] & 1023, h = (rowc[p] >> 10) & 1023, d = (rowc[p] >> 20) & 1023;
-            int sd = src_coord(d, kd, g.ls_d, g.pd, g.Di, MODE, ok);
-            int sh = src_coord(h, kh, g.ls_h, g.ph, g.Hi, MODE, ok);
-            int sw = src_coord(w, kw, g.ls_w, g.pw, g.Wi, MODE, ok);
-            if (ok) {
-                size_t pos = ((size_t)sd * g.Hi + sh) * g.Wi + sw;
-                ra[p] = *reinterpret_cast<const float4*>(in + pos * g.in_stride + c);
-                valid_mask |= 1u << p;
-            } else {
-                ra[p] = make_float4(0, 0, 0, 0);
-            }
+            const bool ok = (rows[p].mask & tbits) == tbits;
+            const int off = ok ? rows[p].off + soff : 0;                // branch-free: invalid rows read element 0
+            ra[p] = *reinterpret_cast<const float4*>(in + off);
+            valid_mask |= ok ? (1u << p) : 0u;
         }
-        if (in_bn && cok) {
+        if (XF && in_bn && cok) {
             tsc = *reinterpret_cast<const float4*>(in_bn + c);
             tsh = *reinterpret_cast<const float4*>(in_bn + g.Cin + c);
         }
@@ -130,10 +113,14 @@ k_igemm(ConvGeom g, const float* __restrict__ in, const float* __restrict__ wp,
         for (int p = 0; p < 8; ++p) {
             float4 v = ra[p];
             const bool ok = (valid_mask >> p) & 1;
-            v.x = ok ? fmaxf(fmaf(v.x, tsc.x, tsh.x), relu_lo) : 0.f;
-            v.y = ok ? fmaxf(fmaf(v.y, tsc.y, tsh.y), relu_lo) : 0.f;
-            v.z = ok ? fmaxf(fmaf(v.z, tsc.z, tsh.z), relu_lo) : 0.f;
-            v.w = ok ? fmaxf(fmaf(v.w, tsc.w, tsh.w), relu_lo) : 0.f;
+            if (XF) {
+                v.x = ok ? fmaxf(fmaf(v.x, tsc.x, tsh.x), relu_lo) : 0.f;
+                v.y = ok ? fmaxf(fmaf(v.y, tsc.y, tsh.y), relu_lo) : 0.f;
+                v.z = ok ? fmaxf(fmaf(v.z, tsc.z, tsh.z), relu_lo) : 0.f;
+                v.w = ok ? fmaxf(fmaf(v.w, tsc.w, tsh.w), relu_lo) : 0.f;
+            } else {
+                v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+            }
             *reinterpret_cast<float4*>(sA + (p * 16 + (tid >> 4)) * LDA + piece * 4) = v;
         }
         float* bl = sB + ((tid >> 6) * BN + (tid & 63)) * 4;
@@ -147,14 +134,21 @@ k_igemm(ConvGeom g, const float* __restrict__ in, const float* __restrict__ wp,
     const float* aRow = sA + (wave * 32 + (lane & 31)) * LDA + 4 * (lane >> 5);
     const float* bCol = sB + ((lane >> 5) * BN + (lane & 31)) * 4;
 
-    int s = advance(0);
+    // split-K: slice z of the (tap, channel-slab) step list; slices write raw partial tiles
+    const int s_end = nsplit > 1 ? (int)(((long long)(blockIdx.z + 1) * nsteps) / nsplit) : nsteps;
+    const int s_begin = nsplit > 1 ? (int)(((long long)blockIdx.z * nsteps) / nsplit) : 0;
+    auto advance_to = [&](int s) -> int {
+        while (s < s_end && !live(s)) ++s;
+        return s < s_end ? s : nsteps;
+    };
+    int s = advance_to(s_begin);
     if (s < nsteps) {
         issue_loads(s);
         store_lds();
     }
     __syncthreads();
     while (s < nsteps) {
-        const int snext = advance(s + 1);
+        const int snext = advance_to(s + 1);
         if (snext < nsteps) issue_loads(snext);
 #pragma unroll
         for (int kc = 0; kc < BK / 8; ++kc) {
@@ -178,6 +172,18 @@ k_igemm(ConvGeom g, const float* __restrict__ in, const float* __restrict__ wp,
 
     // ---- epilogue: C layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     const int col = lane & 31;
+    if (partial) {
+        float* pz = partial + (size_t)blockIdx.z * g.M * g.CoutP;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (m < g.M) {
+                pz[(size_t)m * g.CoutP + n0 + col] = acc0[r];
+                pz[(size_t)m * g.CoutP + n0 + 32 + col] = acc1[r];
+            }
+        }
+        return;
+    }
     const int nA = n0 + col, nB = n0 + 32 + col;
     // pixel-shuffle store (kernel == stride transposed conv): the 64-column slab lies inside one tap
     const int ps_tap = g.ps ? n0 / g.ps_channels : 0;
@@ -232,6 +238,50 @@ k_igemm(ConvGeom g, const float* __restrict__ in, const float* __restrict__ wp,
     }
 }
 
+// split-K combine: out = sum_z partial[z] + bias (+ out) (relu) ; BatchNormalization partial statistics per
+// 128-row tile (same tile index as the single-pass kernel, so lisec_bn_finalize sees the same layout)
+__global__ void __launch_bounds__(256)
+k_splitk_reduce(const float* __restrict__ partial, int nsplit, int M, int Cout, int CoutP,
+                const float* __restrict__ bias, int flags, float* __restrict__ out, int out_stride,
+                double* __restrict__ stats) {
+    __shared__ float red[2][256][4];
+    constexpr int cq = BN / 4;                       // one 64-channel slab per blockIdx.y
+    const int q = threadIdx.x % cq, rsub = threadIdx.x / cq, rows_per_iter = 256 / cq;
+    const int c = blockIdx.y * BN + q * 4;
+    const bool cok = c < Cout;
+    float4 b = make_float4(0, 0, 0, 0);
+    if (bias && cok) b = *reinterpret_cast<const float4*>(bias + c);
+    const bool orelu = (flags & LISEC_CONV_OUT_RELU) != 0, accum = (flags & LISEC_CONV_ACCUMULATE) != 0;
+    float4 s1 = make_float4(0, 0, 0, 0), s2 = make_float4(0, 0, 0, 0);
+    const int m_begin = blockIdx.x * BM, m_end = m_begin + BM < M ? m_begin + BM : M;
+    for (int m = m_begin + rsub; m < m_end; m += rows_per_iter) {
+        float4 v = b;
+        for (int z = 0; z < nsplit; ++z) {
+            const float4 p = *reinterpret_cast<const float4*>(partial + ((size_t)z * M + m) * CoutP + c);
+            v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+        }
+        if (cok) {
+            float* o = out + (size_t)m * out_stride + c;
+            if (accum) { const float4 e = *reinterpret_cast<const float4*>(o); v.x += e.x; v.y += e.y; v.z += e.z; v.w += e.w; }
+            if (orelu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            *reinterpret_cast<float4*>(o) = v;
+            s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
+            s2.x = fmaf(v.x, v.x, s2.x); s2.y = fmaf(v.y, v.y, s2.y); s2.z = fmaf(v.z, v.z, s2.z); s2.w = fmaf(v.w, v.w, s2.w);
+        }
+    }
+    if (stats) {
+        red[0][threadIdx.x][0] = s1.x; red[0][threadIdx.x][1] = s1.y; red[0][threadIdx.x][2] = s1.z; red[0][threadIdx.x][3] = s1.w;
+        red[1][threadIdx.x][0] = s2.x; red[1][threadIdx.x][1] = s2.y; red[1][threadIdx.x][2] = s2.z; red[1][threadIdx.x][3] = s2.w;
+        __syncthreads();
+        if (threadIdx.x < 2 * BN) {
+            const int which = threadIdx.x / BN, cl = threadIdx.x % BN, ch = blockIdx.y * BN + cl;
+            double a = 0.0;
+            for (int k = 0; k < rows_per_iter; ++k) a += (double)red[which][k * cq + cl / 4][cl % 4];
+            if (ch < Cout) stats[((size_t)blockIdx.x * 2 + which) * Cout + ch] = a;
+        }
+    }
+}
+
 // dst[tap][k/4][n][k%4] (K padded to 64, N padded to 64, zero filled) from an arbitrary strided source
 __global__ void k_pack_weights(const float* __restrict__ src, int ntaps, int K, int N, long long tap_stride,
                                long long k_stride, long long n_stride, int Kp, int Np, float* __restrict__ dst) {
@@ -258,7 +308,9 @@ int conv_geom_check(const lisec_conv_geom* c, ConvGeom* g) {
     LISEC_CHECK_ARG(ld >= 0 && lh >= 0 && lw >= 0, "strides must be 1, 2 or 4");
     LISEC_CHECK_ARG(c->Di > 0 && c->Hi > 0 && c->Wi > 0 && c->Do > 0 && c->Ho > 0 && c->Wo > 0, "bad dims");
     LISEC_CHECK_ARG(c->Do < 1024 && c->Ho < 1024 && c->Wo < 1024, "output dims must be < 1024");
-    LISEC_CHECK_ARG(c->KD >= 1 && c->KH >= 1 && c->KW >= 1 && c->KD * c->KH * c->KW <= 64, "bad kernel size");
+    LISEC_CHECK_ARG(c->KD >= 1 && c->KH >= 1 && c->KW >= 1 && c->KD <= 4 && c->KH <= 4 && c->KW <= 4,
+                    "kernel taps must be in [1,4] per axis");
+    LISEC_CHECK_ARG((long long)c->Di * c->Hi * c->Wi * c->in_stride < (1LL << 31), "gathered tensor too large (int32 offsets)");
     LISEC_CHECK_ARG(c->Cin >= 4 && c->Cin % 4 == 0 && c->in_stride >= c->Cin && c->in_stride % 4 == 0,
                     "Cin/in_stride must be multiples of 4");
     if (c->ps) {
@@ -310,22 +362,53 @@ extern "C" int lisec_conv_num_mblocks(const lisec_conv_geom* c) {
     return cdiv(g.M, BM);
 }
 
+namespace {
+// how many K slices to cut a layer into so that a small-M layer still fills the 256 CUs
+int pick_nsplit(const ConvGeom& g) {
+    if (g.ps || g.Cout % 4 != 0 || g.CoutP > 256) return 1;
+    const long long blocks = (long long)cdiv(g.M, BM) * (g.CoutP / BN);
+    const int nsteps = g.KD * g.KH * g.KW * cdiv(g.Cin, BK);
+    if (blocks >= 192 || nsteps < 6) return 1;
+    int ns = (int)(288 / blocks);             // about one workgroup per CU ...
+    if (ns > nsteps / 3) ns = nsteps / 3;     // ... but at least three K steps per slice
+    if (ns > 8) ns = 8;
+    return ns < 1 ? 1 : ns;
+}
+}  // namespace
+
+extern "C" size_t lisec_conv_forward_workspace_bytes(const lisec_conv_geom* c) {
+    ConvGeom g;
+    if (conv_geom_check(c, &g)) return 0;
+    const int ns = pick_nsplit(g);
+    return ns > 1 ? align_up(sizeof(float) * (size_t)ns * g.M * g.CoutP, 256) : 0;
+}
+
 extern "C" int lisec_conv_forward(const lisec_conv_geom* c, const float* in, const float* packed_w,
                                   const float* bias, const float* in_bnstate, int flags, float* out,
-                                  double* stats_partials, lisec_stream_t stream_) {
+                                  double* stats_partials, void* workspace, size_t workspace_bytes,
+                                  lisec_stream_t stream_) {
     ConvGeom g;
     if (int rc = conv_geom_check(c, &g)) return rc;
     LISEC_CHECK_ARG(in && packed_w && out, "NULL tensor pointer");
     LISEC_CHECK_ARG(((uintptr_t)in & 15) == 0 && ((uintptr_t)packed_w & 15) == 0, "in/weights must be 16-byte aligned");
-    dim3 grid(cdiv(g.M, BM), g.CoutP / BN);
+    int nsplit = workspace ? pick_nsplit(g) : 1;
+    if (nsplit > 1 && workspace_bytes < sizeof(float) * (size_t)nsplit * g.M * g.CoutP) nsplit = 1;
+    float* partial = nsplit > 1 ? static_cast<float*>(workspace) : nullptr;
+    dim3 grid(cdiv(g.M, BM), g.CoutP / BN, nsplit);
     size_t lds = (size_t)(A_FLOATS + B_FLOATS) * sizeof(float);
     hipStream_t st = static_cast<hipStream_t>(stream_);
-    if (c->mode == 0)
-        hipLaunchKernelGGL(k_igemm<0>, grid, dim3(kThreads), lds, st, g, in, packed_w, bias, in_bnstate, flags,
-                           out, stats_partials);
-    else
-        hipLaunchKernelGGL(k_igemm<1>, grid, dim3(kThreads), lds, st, g, in, packed_w, bias, in_bnstate, flags,
-                           out, stats_partials);
+    const bool xf = in_bnstate != nullptr || (flags & LISEC_CONV_IN_RELU);
+#define LISEC_IG(M_, X_) hipLaunchKernelGGL((k_igemm<M_, X_>), grid, dim3(kThreads), lds, st, g, in, packed_w, bias, \
+                                            in_bnstate, flags, out, stats_partials, nsplit, partial)
+    if (c->mode == 0) { if (xf) LISEC_IG(0, true); else LISEC_IG(0, false); }
+    else              { if (xf) LISEC_IG(1, true); else LISEC_IG(1, false); }
+#undef LISEC_IG
     LISEC_LAUNCH_CHECK();
+    if (nsplit > 1) {
+        LISEC_CHECK_ARG(g.out_stride % 4 == 0 && ((uintptr_t)out & 15) == 0, "split-K needs a 16-byte aligned output");
+        hipLaunchKernelGGL(k_splitk_reduce, dim3(cdiv(g.M, BM), g.CoutP / BN), dim3(256), 0, st, partial, nsplit, g.M, g.Cout,
+                           g.CoutP, bias, flags, out, g.out_stride, stats_partials);
+        LISEC_LAUNCH_CHECK();
+    }
     return LISEC_OK;
 }

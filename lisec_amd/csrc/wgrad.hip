@@ -65,45 +65,29 @@ k_wgrad(ConvGeom g, const float* __restrict__ in, const float* __restrict__ in_b
 
     float4 ra[8], rd[8];
     unsigned valid_mask = 0;
-    int rowc[8];
+    RowGather rows[8];
 
     auto decode_rows = [&](int tile) {
 #pragma unroll
-        for (int p = 0; p < 8; ++p) {
-            int m = tile * BMW + p * 16 + (tid >> 4);
-            if (m < g.M) {
-                int d = m / HW, rem = m - d * HW;
-                int h = rem / g.Wo, w = rem - h * g.Wo;
-                rowc[p] = w | (h << 10) | (d << 20);
-            } else {
-                rowc[p] = -1;
-            }
-        }
+        for (int p = 0; p < 8; ++p) rows[p] = row_gather(g, tile * BMW + p * 16 + (tid >> 4), MODE, cA);
     };
     auto tile_live = [&](int tile) -> bool {     // whole tile outside the valid depth range of this tap group
         int mfirst = tile * BMW, mlast = mfirst + BMW - 1 < g.M ? mfirst + BMW - 1 : g.M - 1;
         int df = mfirst / HW, dl = mlast / HW;
         if (df != dl) return true;
-        bool ok = true;
-        (void)src_coord(df, kd, g.ls_d, g.pd, g.Di, MODE, ok);
-        return ok;
+        int tmp;
+        return (axis_mask(df, g.KD, g.ls_d, g.pd, g.Di, MODE, tmp) >> kd) & 1;
     };
     auto load_a = [&](int kw) {
+        const int soff = tap_delta(g, kd, kh, kw, MODE);
+        const int tbits = cokA ? tap_bits(kd, kh, kw) : 0x7fffffff;
         valid_mask = 0;
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
-            bool ok = rowc[p] >= 0 && cokA;
-            int w = rowc[p] & 1023, h = (rowc[p] >> 10) & 1023, d = (rowc[p] >> 20) & 1023;
-            int sd = src_coord(d, kd, g.ls_d, g.pd, g.Di, MODE, ok);
-            int sh = src_coord(h, kh, g.ls_h, g.ph, g.Hi, MODE, ok);
-            int sw = src_coord(w, kw, g.ls_w, g.pw, g.Wi, MODE, ok);
-            if (ok) {
-                size_t pos = ((size_t)sd * g.Hi + sh) * g.Wi + sw;
-                ra[p] = *reinterpret_cast<const float4*>(in + pos * g.in_stride + cA);
-                valid_mask |= 1u << p;
-            } else {
-                ra[p] = make_float4(0, 0, 0, 0);
-            }
+            const bool ok = (rows[p].mask & tbits) == tbits;
+            const int off = ok ? rows[p].off + soff : 0;
+            ra[p] = *reinterpret_cast<const float4*>(in + off);
+            valid_mask |= ok ? (1u << p) : 0u;
         }
     };
     auto load_d = [&](int tile) {

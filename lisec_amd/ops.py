@@ -50,9 +50,25 @@ def num_mblocks(g):
     return n
 
 
-def conv_forward(g, x, wp, out, bias=None, in_bn=None, flags=0, stats=None):
+_SPLITK_WS = {}
+
+
+def conv_workspace(g, device):
+    """Shared split-K scratch for `g` (None when the layer is large enough to run in one pass)."""
+    need = _lib.load().lisec_conv_forward_workspace_bytes(ctypes.byref(g))
+    if need == 0:
+        return None
+    key = str(device)
+    if key not in _SPLITK_WS or _SPLITK_WS[key].numel() < need:
+        _SPLITK_WS[key] = torch.empty(need, dtype=torch.uint8, device=device)
+    return _SPLITK_WS[key]
+
+
+def conv_forward(g, x, wp, out, bias=None, in_bn=None, flags=0, stats=None, splitk=True):
+    ws = conv_workspace(g, out.device) if splitk else None
     _lib.check(_lib.load().lisec_conv_forward(ctypes.byref(g), _lib.ptr(x), _lib.ptr(wp), _lib.ptr(bias),
                                               _lib.ptr(in_bn), flags, _lib.ptr(out), _lib.ptr(stats),
+                                              _lib.ptr(ws), ws.numel() if ws is not None else 0,
                                               _lib.current_stream()))
     return out
 
