@@ -164,6 +164,18 @@ size_t lisec_conv_packed_floats(int ntaps, int K, int N);
 int lisec_conv_pack_weights(const float* src, int ntaps, int K, int N, long long tap_stride,
                             long long k_stride, long long n_stride, float* dst, lisec_stream_t stream);
 
+/* The same repack for many kernels in one launch (the whole network after an optimizer step).  The table
+ * lives in DEVICE memory; start = running sum of ntaps*Kp*Np (Kp, Np = K, N rounded up to 64); total = the
+ * sum over all entries. */
+typedef struct {
+    const float* src;
+    float* dst;
+    long long tap_stride, k_stride, n_stride, start;
+    int ntaps, K, N, Kp, Np, pad_;
+} lisec_pack_desc;
+int lisec_conv_pack_weights_batched(const lisec_pack_desc* device_table, int n, long long total,
+                                    lisec_stream_t stream);
+
 /* Number of 128-row tiles = leading dimension of `stats_partials`. */
 int lisec_conv_num_mblocks(const lisec_conv_geom* g);
 

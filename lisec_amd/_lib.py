@@ -26,6 +26,12 @@ class VfeGrads(Structure):
     _fields_ = [("kernel", c_void_p * 3), ("gamma", c_void_p * 3), ("beta", c_void_p * 3)]
 
 
+class PackDesc(Structure):
+    _fields_ = [("src", c_void_p), ("dst", c_void_p), ("tap_stride", ctypes.c_longlong),
+                ("k_stride", ctypes.c_longlong), ("n_stride", ctypes.c_longlong), ("start", ctypes.c_longlong),
+                ("ntaps", c_int), ("K", c_int), ("N", c_int), ("Kp", c_int), ("Np", c_int), ("pad_", c_int)]
+
+
 class ConvGeom(Structure):
     _fields_ = [(n, c_int) for n in ("mode", "Di", "Hi", "Wi", "Do", "Ho", "Wo", "KD", "KH", "KW",
                                      "sd", "sh", "sw", "pd", "ph", "pw", "Cin", "in_stride", "Cout",
@@ -63,6 +69,8 @@ def _declare(lib):
     lib.lisec_conv_packed_floats.argtypes = [c_int, c_int, c_int]
     lib.lisec_conv_pack_weights.restype = c_int
     lib.lisec_conv_pack_weights.argtypes = [P, c_int, c_int, c_int, LL, LL, LL, P, P]
+    lib.lisec_conv_pack_weights_batched.restype = c_int
+    lib.lisec_conv_pack_weights_batched.argtypes = [P, c_int, LL, P]
     lib.lisec_conv_num_mblocks.restype = c_int
     lib.lisec_conv_num_mblocks.argtypes = [POINTER(ConvGeom)]
     lib.lisec_conv_forward.restype = c_int

@@ -238,6 +238,28 @@ k_igemm(ConvGeom g, const float* __restrict__ in, const float* __restrict__ wp,
     }
 }
 
+// all layers of the network in ONE launch: table of descriptors in device memory, element index -> layer by
+// a search over the running element offsets
+__global__ void k_pack_weights_batched(const lisec_pack_desc* __restrict__ tab, int n, long long total) {
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        int lo = 0, hi = n - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (tab[mid].start <= i) lo = mid; else hi = mid - 1;
+        }
+        const lisec_pack_desc d = tab[lo];
+        const long long e = i - d.start;
+        const int j = (int)(e & 3);
+        long long t = e >> 2;
+        const int nn = (int)(t % d.Np);
+        t /= d.Np;
+        const int kq = (int)(t % (d.Kp / 4));
+        const int tap = (int)(t / (d.Kp / 4));
+        const int k = kq * 4 + j;
+        d.dst[e] = (k < d.K && nn < d.N) ? d.src[tap * d.tap_stride + k * d.k_stride + nn * d.n_stride] : 0.f;
+    }
+}
+
 // split-K combine: out = sum_z partial[z] + bias (+ out) (relu) ; BatchNormalization partial statistics per
 // 128-row tile (same tile index as the single-pass kernel, so lisec_bn_finalize sees the same layout)
 __global__ void __launch_bounds__(256)
@@ -352,6 +374,17 @@ extern "C" int lisec_conv_pack_weights(const float* src, int ntaps, int K, int N
     if (gb > 8192) gb = 8192;
     hipLaunchKernelGGL(k_pack_weights, dim3(gb), dim3(256), 0, static_cast<hipStream_t>(stream_), src, ntaps,
                        K, N, tap_stride, k_stride, n_stride, Kp, Np, dst);
+    LISEC_LAUNCH_CHECK();
+    return LISEC_OK;
+}
+
+extern "C" int lisec_conv_pack_weights_batched(const lisec_pack_desc* device_table, int n, long long total,
+                                               lisec_stream_t stream_) {
+    LISEC_CHECK_ARG(device_table && n > 0 && total > 0, "bad batched pack arguments");
+    int gb = cdiv(total, 256);
+    if (gb > 8192) gb = 8192;
+    hipLaunchKernelGGL(k_pack_weights_batched, dim3(gb), dim3(256), 0, static_cast<hipStream_t>(stream_),
+                       device_table, n, total);
     LISEC_LAUNCH_CHECK();
     return LISEC_OK;
 }

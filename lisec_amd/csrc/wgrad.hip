@@ -197,21 +197,39 @@ k_wgrad(ConvGeom g, const float* __restrict__ in, const float* __restrict__ in_b
     }
 }
 
-// dW = sum over splits (index order).  transpose: write [tap][n][c] (Conv2DTranspose kernels are (kh,kw,out,in))
-__global__ void k_wgrad_reduce(const float* __restrict__ partial, int nsplit, int ntaps, int Cin, int Cout,
-                               int transpose, float* __restrict__ dW) {
-    const long long per = (long long)ntaps * Cin * Cout;
-    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < per; i += (long long)gridDim.x * 256) {
-        float s = 0.f;
-        for (int k = 0; k < nsplit; ++k) s += partial[(size_t)k * per + i];
+// dW = sum over splits (index order).  transpose: write [tap][n][c] (Conv2DTranspose kernels are (kh,kw,out,in)).
+// One thread per float4 of the kernel; the S slab loads of a thread are independent (batched 8 at a time) and
+// added in slab order, so the result does not depend on the launch geometry.
+__global__ void __launch_bounds__(256)
+k_wgrad_reduce(const float* __restrict__ partial, int nsplit, int ntaps, int Cin, int Cout,
+               int transpose, float* __restrict__ dW) {
+    const long long per = (long long)ntaps * Cin * Cout;          // Cout % 4 == 0
+    const long long per4 = per >> 2;
+    for (long long i4 = blockIdx.x * 256LL + threadIdx.x; i4 < per4; i4 += (long long)gridDim.x * 256) {
+        const float4* src = reinterpret_cast<const float4*>(partial) + i4;
+        float4 s = make_float4(0, 0, 0, 0);
+        int k = 0;
+        for (; k + 8 <= nsplit; k += 8) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(k + u) * per4];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+        }
+        for (; k < nsplit; ++k) {
+            const float4 v = src[(size_t)k * per4];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        const long long i = i4 << 2;
         if (!transpose) {
-            dW[i] = s;
+            reinterpret_cast<float4*>(dW)[i4] = s;
         } else {
-            int n = (int)(i % Cout);
+            const int n = (int)(i % Cout);
             long long t = i / Cout;
-            int c = (int)(t % Cin);
-            int tap = (int)(t / Cin);
-            dW[((size_t)tap * Cout + n) * Cin + c] = s;
+            const int c = (int)(t % Cin);
+            const int tap = (int)(t / Cin);
+            float* o = dW + ((size_t)tap * Cout + n) * Cin + c;
+            o[0] = s.x; o[Cin] = s.y; o[2 * (size_t)Cin] = s.z; o[3 * (size_t)Cin] = s.w;
         }
     }
 }
@@ -229,7 +247,7 @@ WgradPlan make_plan(const ConvGeom& g) {
     p.ntiles = cdiv(g.M, BMW);
     int cb = cdiv(g.Cin, BC), nb = cdiv(g.Cout, BC);
     int base = p.ngroups * cb * nb;
-    int want = cdiv(640, base);                 // ~2.5 workgroups per CU in total
+    int want = cdiv(512, base);                 // two workgroups per CU in total
     if (want < 1) want = 1;
     if (want > p.ntiles) want = p.ntiles;
     p.tiles_per_split = cdiv(p.ntiles, want);
@@ -287,7 +305,7 @@ extern "C" int lisec_conv_wgrad(const lisec_conv_geom* c, const float* in, const
     if (rc) return rc;
     const int ntaps = g.KD * g.KH * g.KW;
     long long per = (long long)ntaps * g.Cin * g.Cout;
-    int gb = cdiv(per, 256);
+    int gb = cdiv(per / 4, 256);
     if (gb > 4096) gb = 4096;
     hipLaunchKernelGGL(k_wgrad_reduce, dim3(gb), dim3(256), 0, st, partial, p.nsplit, ntaps, g.Cin, g.Cout,
                        transpose_out, dW);

@@ -130,12 +130,15 @@ class LisecNet:
         if self._packed_version == self.params_version:
             return
         p = self.params
-        for L in self.layers:
-            for key in ("conv", "dense"):
-                if key in L:
-                    c = L[key]
-                    nt, K, N, ts, ks, ns = c.pack
-                    ops.pack_weights(p.view(c.wname), nt, K, N, ts, ks, ns, out=self.packed[c.name])
+        if getattr(self, "_pack_table", None) is None:
+            entries = []
+            for L in self.layers:
+                for key in ("conv", "dense"):
+                    if key in L:
+                        c = L[key]
+                        entries.append((p.view(c.wname), self.packed[c.name]) + tuple(c.pack))
+            self._pack_table = ops.PackTable(entries, self.device)
+        self._pack_table.run()
         self.head_w[:, :2] = p.view("cls.kernel")[0, 0]
         self.head_w[:, 2:] = p.view("reg.kernel")[0, 0]
         self.head_b[:2] = p.view("cls.bias")
@@ -242,13 +245,17 @@ class LisecNet:
         if self._packed_t_version == self.params_version:
             return
         p = self.params
-        for L in self.layers:
-            for key in ("conv", "dense"):
-                if key in L:
-                    c = L[key]
-                    buf, (nt, K, N, ts, ks, ns) = self.packed_t[c.name]
-                    ops.pack_weights(p.view(c.wname), nt, K, N, ts, ks, ns, out=buf)
-        ops.pack_weights(self.head_w, 1, 16, 768, 0, 1, 16, out=self.packed_t["head"][0])
+        if getattr(self, "_pack_table_t", None) is None:
+            entries = []
+            for L in self.layers:
+                for key in ("conv", "dense"):
+                    if key in L:
+                        c = L[key]
+                        buf, spec = self.packed_t[c.name]
+                        entries.append((p.view(c.wname), buf) + tuple(spec))
+            entries.append((self.head_w, self.packed_t["head"][0], 1, 16, 768, 0, 1, 16))
+            self._pack_table_t = ops.PackTable(entries, self.device)
+        self._pack_table_t.run()
         self._packed_t_version = self.params_version
 
     def backward(self, y_cls, y_reg, loss="mse", grad_scale=1.0):

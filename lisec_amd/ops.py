@@ -43,6 +43,29 @@ def pack_weights(src, ntaps, K, N, tap_stride, k_stride, n_stride, out=None):
     return out
 
 
+class PackTable:
+    """Device-resident table for lisec_conv_pack_weights_batched: entries (src, dst, ntaps, K, N, strides)."""
+
+    def __init__(self, entries, device):
+        arr = (_lib.PackDesc * len(entries))()
+        start = 0
+        for d, (src, dst, ntaps, K, N, ts, ks, ns) in zip(arr, entries):
+            Kp, Np = (K + 63) // 64 * 64, (N + 63) // 64 * 64
+            d.src, d.dst = src.data_ptr(), dst.data_ptr()
+            d.tap_stride, d.k_stride, d.n_stride, d.start = ts, ks, ns, start
+            d.ntaps, d.K, d.N, d.Kp, d.Np = ntaps, K, N, Kp, Np
+            assert dst.numel() >= ntaps * Kp * Np
+            start += ntaps * Kp * Np
+        self.total, self.n = start, len(entries)
+        self.keep = [e[0] for e in entries] + [e[1] for e in entries]
+        raw = bytes(arr)
+        self.table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
+
+    def run(self):
+        _lib.check(_lib.load().lisec_conv_pack_weights_batched(_lib.ptr(self.table), self.n, self.total,
+                                                               _lib.current_stream()))
+
+
 def num_mblocks(g):
     n = _lib.load().lisec_conv_num_mblocks(ctypes.byref(g))
     if n < 0:
