@@ -114,6 +114,11 @@ int lisec_vfe_forward(const lisec_vfe_params* p, const int32_t* info, const int3
                       int cap_voxels, int training, float* saved, void* workspace, size_t workspace_bytes,
                       float* grid, lisec_stream_t stream);
 
+/* Re-materialises the dense grid from the `saved` buffer of the last lisec_vfe_forward (the HBM-bound
+ * writer on its own: lets a caller recycle the 164 MB grid buffer, and lets bench.py time the writer). */
+int lisec_vfe_grid_from_saved(const int32_t* info, const int32_t* cell_voxel, int ncells, int cap_voxels,
+                              const float* saved, float* grid, lisec_stream_t stream);
+
 /* Gradients of the VFE variables (what fit() derives for the layers of :231-235), training-mode BN.
  * dgrid: float32[ncells*64], gradient wrt the grid written by lisec_vfe_forward(training=1);
  * saved: the buffer that forward filled.  Outputs are written (not accumulated). */

@@ -255,3 +255,13 @@ extern "C" int lisec_vfe_forward(const lisec_vfe_params* p, const int32_t* info,
     LISEC_LAUNCH_CHECK();
     return LISEC_OK;
 }
+
+extern "C" int lisec_vfe_grid_from_saved(const int32_t* info, const int32_t* cell_voxel, int ncells,
+                                         int cap_voxels, const float* saved, float* grid, lisec_stream_t stream_) {
+    LISEC_CHECK_ARG(info && cell_voxel && saved && grid && ncells > 0 && cap_voxels >= 0, "bad arguments");
+    VfeSaved sv(const_cast<float*>(saved), cap_voxels);
+    hipLaunchKernelGGL(k_vfe_grid, dim3(4096), dim3(256), 0, static_cast<hipStream_t>(stream_), info, cell_voxel,
+                       ncells, cap_voxels, sv.ymm3, sv.bn3, grid);
+    LISEC_LAUNCH_CHECK();
+    return LISEC_OK;
+}

@@ -49,6 +49,15 @@ class VFEStack:
         self._sample = sample
         return grid
 
+    def rewrite_grid(self, out):
+        """Rewrite the dense grid of the last forward from the saved per-voxel statistics."""
+        sample = self._sample
+        D, H, W = sample.grid_shape
+        _lib.check(self.lib.lisec_vfe_grid_from_saved(_lib.ptr(sample.info), _lib.ptr(sample.cell_voxel), D * H * W,
+                                                      sample.cap, _lib.ptr(self._saved), _lib.ptr(out),
+                                                      _lib.current_stream()))
+        return out
+
     def backward(self, dgrid, grad):
         """dgrid: (D,H,W,64) gradient wrt the grid of the last training forward; grad: flat gradient buffer
         laid out like params.theta (VFE entries are overwritten)."""
