@@ -121,7 +121,8 @@ def main():
     from lisec_amd.parallel import DataParallel
     from lisec_amd.voxelizer import Voxelizer
 
-    dp = DataParallel(dev) if world > 1 else None
+    # LISEC_FORCE_DP=1 exercises the RCCL path (init, broadcast, all-reduce, barrier) even with one rank
+    dp = DataParallel(dev) if (world > 1 or os.environ.get("LISEC_FORCE_DP") == "1") else None
     net = LisecNet(Constants.nx, Constants.ny, Constants.nz, Constants.maxPoints, device=dev)
     vox = Voxelizer(Constants.voxelx, Constants.voxely, Constants.voxelz, Constants.maxPoints,
                     Constants.nx // 2, Constants.ny // 2, Constants.nz, device=dev)
@@ -132,6 +133,9 @@ def main():
         dp.broadcast_(net.params.theta)
         dp.broadcast_(net.params.state)
     allreduce = dp.average_ if dp is not None else None
+    if dp is not None and dp.world == 1 and os.environ.get("LISEC_FORCE_DP") == "1":
+        import torch.distributed as dist
+        allreduce = lambda g: dist.all_reduce(g)          # noqa: E731  (world 1: identity, but a real RCCL call)
 
     def step():
         sample = vox(pts)
@@ -167,8 +171,11 @@ def main():
         # algorithmic FLOPs: 2 * positions * 27 taps * 64 * 64; depth-padding taps included
         flops = 2.0 * c.M * 27 * 64 * 64
         tf = flops / (ms * 1e-3) / 1e12
-        roofline = dict(bound="mfma", kernel="k_igemm<0> mid1 Conv3D 64->64 k3 s(2,1,1)", achieved=tf,
-                        peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s", frac=tf / PEAK_F32_MFMA_TFLOPS, traffic=None,
+        # traffic: HBM bytes per launch from rocprofv3 PMC passes of this kernel (profiles/r01_pmc_summary.txt):
+        # FETCH_SIZE 128 107 KiB (x2, the gfx950 correction for wide coalesced reads) + WRITE_SIZE 82 500 KiB
+        roofline = dict(bound="mfma", kernel="k_igemm<0,false> mid1 Conv3D 64->64 k3 s(2,1,1)", achieved=tf,
+                        peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s", frac=tf / PEAK_F32_MFMA_TFLOPS,
+                        traffic=(2 * 128107.0625 + 82500.0) * 1024, traffic_unit="bytes/launch (PMC, offline)",
                         us_per_launch=ms * 1e3, flops_per_launch=flops)
         sample = vox(pts)
 
@@ -177,10 +184,18 @@ def main():
         ms_v = event_time_ms(run_vfe, 20)
         hi = sample.host_info()
         vfe_bytes = 12.0 * 20000 + 24.0 * hi["rows"] + 4.0 * 64 * net.D * net.H * net.W
-        gbs = vfe_bytes / (ms_v * 1e-3) / 1e9
-        roofline_vfe = dict(bound="hbm", kernel="lisec_vfe_forward (3 stage kernels + grid writer)", achieved=gbs,
-                            peak=PEAK_HBM_GBS, unit="GB/s", frac=gbs / PEAK_HBM_GBS, traffic=None,
-                            us_per_call=ms_v * 1e3, bytes_per_call=vfe_bytes)
+        ms_g = event_time_ms(lambda: net.vfe.rewrite_grid(net.act["grid"]), 50)
+        grid_bytes = 4.0 * 64 * net.D * net.H * net.W
+        gbs = grid_bytes / (ms_g * 1e-3) / 1e9
+        # traffic from PMC: WRITE_SIZE 160 000 KiB (= the algorithmic bytes) + FETCH_SIZE 4 875 KiB x2
+        roofline_vfe = dict(bound="hbm", kernel="k_vfe_grid (dense (8,200,400,64) VFE output writer)", achieved=gbs,
+                            peak=PEAK_HBM_GBS, unit="GB/s", frac=gbs / PEAK_HBM_GBS,
+                            traffic=(160000.0 + 2 * 4875.125) * 1024, traffic_unit="bytes/launch (PMC, offline)",
+                            us_per_launch=ms_g * 1e3, bytes_per_launch=grid_bytes,
+                            whole_vfe_forward=dict(us_per_call=ms_v * 1e3, bytes_per_call=vfe_bytes,
+                                                   achieved=vfe_bytes / (ms_v * 1e-3) / 1e9,
+                                                   frac=vfe_bytes / (ms_v * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                                                   launches=7))
         result = {
             "metric": "lyft_samples_per_sec_fwd_bwd", "value": world * args.steps / dt, "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
