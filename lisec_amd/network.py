@@ -238,6 +238,9 @@ class LisecNet:
         self.head_dw = torch.empty(768, 16, dtype=f32, device=dev)
         self.head_db = torch.empty(16, dtype=f32, device=dev)
         self.wgrad_ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        # weight gradients are leaves of the backward graph: they run on a second HIP stream next to the
+        # BN-backward / data-gradient chain (the RPN layers are too small to fill 256 CUs on their own)
+        self.side = torch.cuda.Stream(device=dev)
         self._packed_t_version = -1
         self._train_ready = True
 
@@ -278,6 +281,14 @@ class LisecNet:
         # ---- RPN blocks, last to first -------------------------------------------------------------
         layers = self.layers
         first_write = set()                    # gradient buffers that already hold a contribution
+        main = torch.cuda.current_stream()
+
+        def on_side(fn):
+            ev = torch.cuda.Event()
+            ev.record(main)
+            self.side.wait_event(ev)
+            with torch.cuda.stream(self.side):
+                fn()
 
         def dgrad_into(c, dy, dst_name):
             flags = ops.ACCUMULATE if dst_name in first_write else 0
@@ -290,11 +301,13 @@ class LisecNet:
                 b = L["slot"]
                 dy = d["concat"][:, :, 256 * b:]
                 if "wgeom" in L:
-                    ops.conv_wgrad(L["wgeom"], dy, a[L["src"]], p.grad_view(G, c.wname), self.wgrad_ws,
-                                   flags=ops.DY_RELU, dy_bn=self.bnstate[c.in_bn])
+                    on_side(lambda L=L, c=c, dy=dy: ops.conv_wgrad(
+                        L["wgeom"], dy, a[L["src"]], p.grad_view(G, c.wname), self.wgrad_ws,
+                        flags=ops.DY_RELU, dy_bn=self.bnstate[c.in_bn]))
                 else:
-                    ops.conv_wgrad(c.g, a[L["src"]], dy, p.grad_view(G, c.wname), self.wgrad_ws,
-                                   in_bn=self.bnstate[c.in_bn], flags=ops.IN_RELU, transpose_out=True)
+                    on_side(lambda L=L, c=c, dy=dy: ops.conv_wgrad(
+                        c.g, a[L["src"]], dy, p.grad_view(G, c.wname), self.wgrad_ws,
+                        in_bn=self.bnstate[c.in_bn], flags=ops.IN_RELU, transpose_out=True))
                 ops.colsum(dy, 768, M, 256, p.grad_view(G, c.bias))
                 dgrad_into(c, dy, L["src"])
             elif L["kind"] == "conv":
@@ -303,23 +316,27 @@ class LisecNet:
                 ops.bn_backward(d[dst], C, a[dst], self.bnstate[c.bn], c.M, C, True,
                                 p.grad_view(G, c.bn + ".gamma"), p.grad_view(G, c.bn + ".beta"), d[dst],
                                 dbias=p.grad_view(G, c.bias))
-                ops.conv_wgrad(c.g, a[L["src"]], d[dst], p.grad_view(G, c.wname), self.wgrad_ws,
-                               in_bn=self.bnstate[c.in_bn] if c.in_bn else None,
-                               flags=ops.IN_RELU if c.in_relu else 0)
+                on_side(lambda L=L, c=c, dst=dst: ops.conv_wgrad(
+                    c.g, a[L["src"]], d[dst], p.grad_view(G, c.wname), self.wgrad_ws,
+                    in_bn=self.bnstate[c.in_bn] if c.in_bn else None, flags=ops.IN_RELU if c.in_relu else 0))
                 dgrad_into(c, d[dst], L["src"])
             else:   # mid layer: conv3d -> BN -> Dense(relu)
                 n, dn = L["name"], L["dense"]
                 ops.relu_mask(d[n + ".u"], a[n + ".u"])
-                ops.conv_wgrad(dn.g, a[n + ".y"], d[n + ".u"], p.grad_view(G, dn.wname), self.wgrad_ws,
-                               in_bn=self.bnstate[dn.in_bn])
+                on_side(lambda n=n, dn=dn: ops.conv_wgrad(dn.g, a[n + ".y"], d[n + ".u"], p.grad_view(G, dn.wname),
+                                                          self.wgrad_ws, in_bn=self.bnstate[dn.in_bn]))
                 ops.conv_forward(self.dgeom[dn.name], d[n + ".u"], self.packed_t[dn.name][0], d[n + ".z"])
                 ops.bn_backward(d[n + ".z"], 64, a[n + ".y"], self.bnstate[c.bn], c.M, 64, False,
                                 p.grad_view(G, c.bn + ".gamma"), p.grad_view(G, c.bn + ".beta"), d[n + ".z"],
                                 dbias=p.grad_view(G, c.bias))
-                ops.conv_wgrad(c.g, a[L["src"]], d[n + ".z"], p.grad_view(G, c.wname), self.wgrad_ws)
+                on_side(lambda L=L, c=c, n=n: ops.conv_wgrad(c.g, a[L["src"]], d[n + ".z"], p.grad_view(G, c.wname),
+                                                             self.wgrad_ws))
                 dgrad_into(c, d[n + ".z"], L["src"])
         # ---- VFE -----------------------------------------------------------------------------------
         self.vfe.backward(d["grid"], G)
+        done = torch.cuda.Event()
+        done.record(self.side)
+        main.wait_event(done)                  # every weight gradient has landed before the optimizer reads G
         return self.loss_out
 
     def apply_gradients(self, lr=0.01, decay=1e-6, momentum=0.9):
