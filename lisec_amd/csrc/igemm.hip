@@ -36,7 +36,7 @@ template <int MODE, bool XF>
 __global__ void __launch_bounds__(kThreads)
 k_igemm(ConvGeom g, const float* __restrict__ in, const float* __restrict__ wp,
         const float* __restrict__ bias, const float* __restrict__ in_bn, int flags,
-        float* __restrict__ out, double* __restrict__ stats, int nsplit, float* __restrict__ partial) {
+        float* __restrict__ out, double* __restrict__ stats, int nsplit, float* __restrict__ partial, int tile0) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sA = smem;
     float* sB = smem + A_FLOATS;
@@ -44,7 +44,7 @@ k_igemm(ConvGeom g, const float* __restrict__ in, const float* __restrict__ wp,
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // XCD-aware tile order: consecutive M tiles (which share halo rows) stay on one XCD's L2
-    const int mb = xcd_remap(blockIdx.x, gridDim.x);
+    const int mb = tile0 + xcd_remap(blockIdx.x, gridDim.x);
     const int m0 = mb * BM;
     const int n0 = blockIdx.y * BN;
     const int HW = g.Ho * g.Wo;
@@ -173,13 +173,16 @@ k_igemm(ConvGeom g, const float* __restrict__ in, const float* __restrict__ wp,
     // ---- epilogue: C layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     const int col = lane & 31;
     if (partial) {
-        float* pz = partial + (size_t)blockIdx.z * g.M * g.CoutP;
+        // slabs cover the rows of tiles tile0 .. (the tail of the layer, or all of it)
+        const size_t rows_part = (size_t)gridDim.x * BM;
+        float* pz = partial + (size_t)blockIdx.z * rows_part * g.CoutP;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             if (m < g.M) {
-                pz[(size_t)m * g.CoutP + n0 + col] = acc0[r];
-                pz[(size_t)m * g.CoutP + n0 + 32 + col] = acc1[r];
+                const size_t ml = (size_t)(m - tile0 * BM);
+                pz[ml * g.CoutP + n0 + col] = acc0[r];
+                pz[ml * g.CoutP + n0 + 32 + col] = acc1[r];
             }
         }
         return;
@@ -265,7 +268,7 @@ __global__ void k_pack_weights_batched(const lisec_pack_desc* __restrict__ tab, 
 __global__ void __launch_bounds__(256)
 k_splitk_reduce(const float* __restrict__ partial, int nsplit, int M, int Cout, int CoutP,
                 const float* __restrict__ bias, int flags, float* __restrict__ out, int out_stride,
-                double* __restrict__ stats) {
+                double* __restrict__ stats, int tile0) {
     __shared__ float red[2][256][4];
     constexpr int cq = BN / 4;                       // one 64-channel slab per blockIdx.y
     const int q = threadIdx.x % cq, rsub = threadIdx.x / cq, rows_per_iter = 256 / cq;
@@ -275,11 +278,13 @@ k_splitk_reduce(const float* __restrict__ partial, int nsplit, int M, int Cout, 
     if (bias && cok) b = *reinterpret_cast<const float4*>(bias + c);
     const bool orelu = (flags & LISEC_CONV_OUT_RELU) != 0, accum = (flags & LISEC_CONV_ACCUMULATE) != 0;
     float4 s1 = make_float4(0, 0, 0, 0), s2 = make_float4(0, 0, 0, 0);
-    const int m_begin = blockIdx.x * BM, m_end = m_begin + BM < M ? m_begin + BM : M;
+    const int tile = tile0 + blockIdx.x;
+    const int m_begin = tile * BM, m_end = m_begin + BM < M ? m_begin + BM : M;
+    const size_t rows_part = (size_t)gridDim.x * BM;
     for (int m = m_begin + rsub; m < m_end; m += rows_per_iter) {
         float4 v = b;
         for (int z = 0; z < nsplit; ++z) {
-            const float4 p = *reinterpret_cast<const float4*>(partial + ((size_t)z * M + m) * CoutP + c);
+            const float4 p = *reinterpret_cast<const float4*>(partial + ((size_t)z * rows_part + (m - tile0 * BM)) * CoutP + c);
             v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
         }
         if (cok) {
@@ -299,7 +304,7 @@ k_splitk_reduce(const float* __restrict__ partial, int nsplit, int M, int Cout, 
             const int which = threadIdx.x / BN, cl = threadIdx.x % BN, ch = blockIdx.y * BN + cl;
             double a = 0.0;
             for (int k = 0; k < rows_per_iter; ++k) a += (double)red[which][k * cq + cl / 4][cl % 4];
-            if (ch < Cout) stats[((size_t)blockIdx.x * 2 + which) * Cout + ch] = a;
+            if (ch < Cout) stats[((size_t)tile * 2 + which) * Cout + ch] = a;
         }
     }
 }
@@ -396,24 +401,61 @@ extern "C" int lisec_conv_num_mblocks(const lisec_conv_geom* c) {
 }
 
 namespace {
-// how many K slices to cut a layer into so that a small-M layer still fills the 256 CUs
-int pick_nsplit(const ConvGeom& g) {
-    if (g.ps || g.Cout % 4 != 0 || g.CoutP > 256) return 1;
-    const long long blocks = (long long)cdiv(g.M, BM) * (g.CoutP / BN);
+// Launch plan: layers with few tiles are cut into K slices so that they fill the 256 CUs; layers with
+// many tiles run whole rounds unsplit and only the LAST, partially filled round is K-sliced (otherwise e.g.
+// mid1's 2500 tiles take 4 rounds of 768 resident workgroups for 3.25 rounds of work).
+struct ConvPlan {
+    int tile0_tail;      // first tile of the K-sliced tail (== ntiles: no tail)
+    int nsplit;          // slices of the tail (or of the whole layer when tile0_tail == 0)
+    size_t ws_bytes;
+};
+
+int resident_slots() {
+    static int slots = 0;
+    if (!slots) {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) {
+            int v = 0;
+            if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+        }
+        slots = 3 * cus;         // 51 KB LDS per workgroup -> 3 per CU
+    }
+    return slots;
+}
+
+ConvPlan make_conv_plan(const ConvGeom& g) {
+    ConvPlan p;
+    const int ntiles = cdiv(g.M, BM), nnb = g.CoutP / BN;
+    p.tile0_tail = ntiles; p.nsplit = 1; p.ws_bytes = 0;
     const int nsteps = g.KD * g.KH * g.KW * cdiv(g.Cin, BK);
-    if (blocks >= 192 || nsteps < 6) return 1;
-    int ns = (int)(288 / blocks);             // about one workgroup per CU ...
-    if (ns > nsteps / 3) ns = nsteps / 3;     // ... but at least three K steps per slice
+    if (g.ps || g.Cout % 4 != 0 || g.out_stride % 4 != 0 || nsteps < 6) return p;
+    const int slots = resident_slots();
+    const long long blocks = (long long)ntiles * nnb;
+    int tail_tiles;
+    if (blocks < slots / 4) {                       // small layer: slice all of it
+        tail_tiles = ntiles;
+    } else {
+        const int tiles_per_round = slots / nnb > 0 ? slots / nnb : 1;
+        tail_tiles = ntiles % tiles_per_round;
+        if (ntiles < tiles_per_round) tail_tiles = ntiles;
+    }
+    const long long tail_blocks = (long long)tail_tiles * nnb;
+    if (tail_blocks == 0 || tail_blocks * 10 > (long long)slots * 7) return p;   // tail round >= 70 % full already
+    int ns = (int)(slots / tail_blocks);
+    if (ns > nsteps / 3) ns = nsteps / 3;
     if (ns > 8) ns = 8;
-    return ns < 1 ? 1 : ns;
+    if (ns < 2) return p;
+    p.tile0_tail = ntiles - tail_tiles;
+    p.nsplit = ns;
+    p.ws_bytes = align_up(sizeof(float) * (size_t)ns * tail_tiles * BM * g.CoutP, 256);
+    return p;
 }
 }  // namespace
 
 extern "C" size_t lisec_conv_forward_workspace_bytes(const lisec_conv_geom* c) {
     ConvGeom g;
     if (conv_geom_check(c, &g)) return 0;
-    const int ns = pick_nsplit(g);
-    return ns > 1 ? align_up(sizeof(float) * (size_t)ns * g.M * g.CoutP, 256) : 0;
+    return make_conv_plan(g).ws_bytes;
 }
 
 extern "C" int lisec_conv_forward(const lisec_conv_geom* c, const float* in, const float* packed_w,
@@ -424,24 +466,34 @@ extern "C" int lisec_conv_forward(const lisec_conv_geom* c, const float* in, con
     if (int rc = conv_geom_check(c, &g)) return rc;
     LISEC_CHECK_ARG(in && packed_w && out, "NULL tensor pointer");
     LISEC_CHECK_ARG(((uintptr_t)in & 15) == 0 && ((uintptr_t)packed_w & 15) == 0, "in/weights must be 16-byte aligned");
-    int nsplit = workspace ? pick_nsplit(g) : 1;
-    if (nsplit > 1 && workspace_bytes < sizeof(float) * (size_t)nsplit * g.M * g.CoutP) nsplit = 1;
-    float* partial = nsplit > 1 ? static_cast<float*>(workspace) : nullptr;
-    dim3 grid(cdiv(g.M, BM), g.CoutP / BN, nsplit);
+    ConvPlan plan = make_conv_plan(g);
+    if (!workspace || workspace_bytes < plan.ws_bytes) { plan.tile0_tail = cdiv(g.M, BM); plan.nsplit = 1; }
+    const int ntiles = cdiv(g.M, BM), nnb = g.CoutP / BN;
     size_t lds = (size_t)(A_FLOATS + B_FLOATS) * sizeof(float);
     hipStream_t st = static_cast<hipStream_t>(stream_);
     const bool xf = in_bnstate != nullptr || (flags & LISEC_CONV_IN_RELU);
-#define LISEC_IG(M_, X_) hipLaunchKernelGGL((k_igemm<M_, X_>), grid, dim3(kThreads), lds, st, g, in, packed_w, bias, \
-                                            in_bnstate, flags, out, stats_partials, nsplit, partial)
-    if (c->mode == 0) { if (xf) LISEC_IG(0, true); else LISEC_IG(0, false); }
-    else              { if (xf) LISEC_IG(1, true); else LISEC_IG(1, false); }
+#define LISEC_IG(M_, X_, GRID_, NS_, PART_, T0_) hipLaunchKernelGGL((k_igemm<M_, X_>), GRID_, dim3(kThreads), lds, st, g, in, \
+        packed_w, bias, in_bnstate, flags, out, stats_partials, NS_, PART_, T0_)
+#define LISEC_IG_ALL(GRID_, NS_, PART_, T0_)                                                                   \
+    do {                                                                                                       \
+        if (c->mode == 0) { if (xf) LISEC_IG(0, true, GRID_, NS_, PART_, T0_); else LISEC_IG(0, false, GRID_, NS_, PART_, T0_); } \
+        else              { if (xf) LISEC_IG(1, true, GRID_, NS_, PART_, T0_); else LISEC_IG(1, false, GRID_, NS_, PART_, T0_); } \
+    } while (0)
+    if (plan.tile0_tail > 0) {                       // whole rounds, single pass
+        dim3 grid(plan.tile0_tail, nnb, 1);
+        LISEC_IG_ALL(grid, 1, (float*)nullptr, 0);
+    }
+    if (plan.tile0_tail < ntiles) {                  // K-sliced tail (or the whole small layer)
+        LISEC_CHECK_ARG(((uintptr_t)out & 15) == 0, "split-K needs a 16-byte aligned output");
+        float* partial = static_cast<float*>(workspace);
+        const int tail = ntiles - plan.tile0_tail;
+        dim3 grid(tail, nnb, plan.nsplit);
+        LISEC_IG_ALL(grid, plan.nsplit, partial, plan.tile0_tail);
+        hipLaunchKernelGGL(k_splitk_reduce, dim3(tail, nnb), dim3(256), 0, st, partial, plan.nsplit, g.M, g.Cout,
+                           g.CoutP, bias, flags, out, g.out_stride, stats_partials, plan.tile0_tail);
+    }
+#undef LISEC_IG_ALL
 #undef LISEC_IG
     LISEC_LAUNCH_CHECK();
-    if (nsplit > 1) {
-        LISEC_CHECK_ARG(g.out_stride % 4 == 0 && ((uintptr_t)out & 15) == 0, "split-K needs a 16-byte aligned output");
-        hipLaunchKernelGGL(k_splitk_reduce, dim3(cdiv(g.M, BM), g.CoutP / BN), dim3(256), 0, st, partial, nsplit, g.M, g.Cout,
-                           g.CoutP, bias, flags, out, g.out_stride, stats_partials);
-        LISEC_LAUNCH_CHECK();
-    }
     return LISEC_OK;
 }

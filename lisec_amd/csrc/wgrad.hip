@@ -247,7 +247,8 @@ WgradPlan make_plan(const ConvGeom& g) {
     p.ntiles = cdiv(g.M, BMW);
     int cb = cdiv(g.Cin, BC), nb = cdiv(g.Cout, BC);
     int base = p.ngroups * cb * nb;
-    int want = cdiv(512, base);                 // two workgroups per CU in total
+    int want = cdiv(1536, base);                // ~3 rounds of the 512 resident workgroups: the (kd) groups
+                                                // skip different tiles, short workgroups even the rounds out
     if (want < 1) want = 1;
     if (want > p.ntiles) want = p.ntiles;
     p.tiles_per_split = cdiv(p.ntiles, want);
