@@ -101,6 +101,11 @@ typedef struct {
 /* Size (floats) of the `saved` buffer a forward fills and the backward reads: BN batch statistics
  * and the per-voxel pre-BN max/min of each layer. */
 size_t lisec_vfe_saved_floats(int cap_voxels);
+/* Offsets (in floats) inside `saved` of the compact per-voxel outputs written by every forward:
+ *   VOUT  float[(cap+1)*64]  grid value of voxel v; row V = the constant every empty cell holds
+ *   DELTA float[(cap+1)*64]  VOUT[v] - VOUT[V] */
+enum { LISEC_VFE_SAVED_VOUT = 0, LISEC_VFE_SAVED_DELTA = 1 };
+size_t lisec_vfe_saved_field_offset(int cap_voxels, int field);
 size_t lisec_vfe_workspace_bytes(void);
 
 /*
@@ -128,11 +133,14 @@ typedef struct {
     float* beta[3];
 } lisec_vfe_grads;
 size_t lisec_vfe_backward_workspace_bytes(int cap_voxels, int n_points);
+/* Pass EITHER dgrid (dense gradient of the grid) OR the compact form the sparse backward of the first middle
+ * layer produces: dout_rows float[(cap_voxels+1)*64] with rows [0,V) = gradient at the occupied cells (row V is
+ * written here) and g_all float[64] = sum of the grid gradient over ALL cells. */
 int lisec_vfe_backward(const lisec_vfe_params* p, const int32_t* info, const int32_t* cell_voxel,
                        const int32_t* npts, const int32_t* row_start, const float* rows, int n_points,
                        int ncells, int T, int cap_voxels, const float* saved, const float* dgrid,
-                       const lisec_vfe_grads* grads, void* workspace, size_t workspace_bytes,
-                       lisec_stream_t stream);
+                       float* dout_rows, const float* g_all, const lisec_vfe_grads* grads, void* workspace,
+                       size_t workspace_bytes, lisec_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * 3. Dense contractions on the fp32 matrix cores (implicit GEMM, no im2col buffer).
@@ -192,6 +200,10 @@ int lisec_conv_num_mblocks(const lisec_conv_geom* g);
  *   bias        NULL or float[Cout]
  *   stats_partials NULL, or double[num_mblocks][2][Cout]: per-tile sum and sum of squares of the
  *               stored values, the input of lisec_bn_finalize (training-mode batch statistics)
+ *   row_coords  NULL (dense: every position of the output map), or a ROW LIST: GEMM row m is the output
+ *               position (d,h,w) = row_coords[3m..3m+2] (the voxeliser's `coords`), *row_count rows exist
+ *               (device int, <= row_capacity) and out row m is written compactly at out + m*out_stride.
+ *               Used to evaluate the gradient of the dense VFE grid only at occupied cells.
  *   workspace   NULL, or scratch of lisec_conv_forward_workspace_bytes(g): lets layers with few output
  *               positions (RPN blocks 2-3) be cut into K slices so that they still fill the 256 CUs; the
  *               slices are combined in a fixed order (deterministic)
@@ -199,7 +211,8 @@ int lisec_conv_num_mblocks(const lisec_conv_geom* g);
 size_t lisec_conv_forward_workspace_bytes(const lisec_conv_geom* g);
 int lisec_conv_forward(const lisec_conv_geom* g, const float* in, const float* packed_w, const float* bias,
                        const float* in_bnstate, int flags, float* out, double* stats_partials,
-                       void* workspace, size_t workspace_bytes, lisec_stream_t stream);
+                       void* workspace, size_t workspace_bytes, const int32_t* row_coords,
+                       const int32_t* row_count, int row_capacity, lisec_stream_t stream);
 
 /* Weight gradient of the contraction described by `g` (the geometry of the FORWARD layer):
  *   dW[tap][c][n] = sum_m f(in[src(m,tap), c]) * dy[m, n]      dy: float32, g->out_stride floats per row
@@ -207,11 +220,29 @@ int lisec_conv_forward(const lisec_conv_geom* g, const float* in, const float* p
  * the Conv2DTranspose layout (kh,kw,out,in).  dy_bnstate (optional, float[4*Cout]) applies the same
  * affine (+ReLU with LISEC_CONV_DY_RELU) to the dy operand: the kernel==stride Conv2DTranspose layers
  * swap roles (in = gathered output gradient, dy = the layer's BN+ReLU input).
+ * row_coords/row_count/row_capacity (optional): contraction over a ROW LIST instead of every position: row m
+ * is position row_coords[3m..], `in` is gathered there, dy row m is read at dy + m*out_stride.
  * Deterministic: partial slabs reduced in index order. */
-size_t lisec_conv_wgrad_workspace_bytes(const lisec_conv_geom* g);
+size_t lisec_conv_wgrad_workspace_bytes(const lisec_conv_geom* g, int row_capacity);
 int lisec_conv_wgrad(const lisec_conv_geom* g, const float* in, const float* in_bnstate, int flags,
                      const float* dy, const float* dy_bnstate, void* workspace, size_t workspace_bytes,
-                     int transpose_out, float* dW, lisec_stream_t stream);
+                     int transpose_out, float* dW, const int32_t* row_coords, const int32_t* row_count,
+                     int row_capacity, lisec_stream_t stream);
+
+/* First middle layer, exact sparse backward (see csrc/sparse_grid.hip).
+ *   lisec_conv_tap_sums: S[tap][n] = sum of dy[m][n] over the output positions m of the mode-0 conv `g` whose
+ *     tap reads inside the input map; S: float[ntaps*Cout].
+ *   lisec_const_field_grads: for an input map equal to the constant vector cvec (Cin) everywhere,
+ *     g_all[c] = sum_tap sum_n W[tap][c][n]*S[tap][n]  (sum of the data gradient over ALL input positions)
+ *     dW[tap][c][n] += cvec[c]*S[tap][n]               (W, dW: Keras layout (taps, Cin, Cout); either output
+ *     may be NULL).  cvec_row (optional, device int): the constant is row min(*cvec_row, cvec_row_max) of the
+ *     (rows, Cin) table `cvec` -- the voxel count V only exists on the device. */
+size_t lisec_conv_tap_sums_workspace_bytes(const lisec_conv_geom* g);
+int lisec_conv_tap_sums(const lisec_conv_geom* g, const float* dy, float* S, void* workspace,
+                        size_t workspace_bytes, lisec_stream_t stream);
+int lisec_const_field_grads(const float* W, const float* S, const float* cvec, const int32_t* cvec_row,
+                            int cvec_row_max, int ntaps, int Cin, int Cout, float* dW, float* g_all,
+                            lisec_stream_t stream);
 
 /* BatchNormalization statistics (Keras: axis -1, eps 1e-3, momentum 0.99, biased batch variance).
  * bnstate: float[4*C] {scale = gamma*rsqrt(var+eps), shift = beta - mean*scale, mean, invstd}.

@@ -65,8 +65,16 @@ def _declare(lib):
     lib.lisec_vfe_backward_workspace_bytes.restype = c_size_t
     lib.lisec_vfe_backward_workspace_bytes.argtypes = [c_int, c_int]
     lib.lisec_vfe_backward.restype = c_int
-    lib.lisec_vfe_backward.argtypes = [POINTER(VfeParams), P, P, P, P, P, c_int, c_int, c_int, c_int, P, P,
+    lib.lisec_vfe_backward.argtypes = [POINTER(VfeParams), P, P, P, P, P, c_int, c_int, c_int, c_int, P, P, P, P,
                                        POINTER(VfeGrads), P, c_size_t, P]
+    lib.lisec_vfe_saved_field_offset.restype = c_size_t
+    lib.lisec_vfe_saved_field_offset.argtypes = [c_int, c_int]
+    lib.lisec_conv_tap_sums_workspace_bytes.restype = c_size_t
+    lib.lisec_conv_tap_sums_workspace_bytes.argtypes = [POINTER(ConvGeom)]
+    lib.lisec_conv_tap_sums.restype = c_int
+    lib.lisec_conv_tap_sums.argtypes = [POINTER(ConvGeom), P, P, P, c_size_t, P]
+    lib.lisec_const_field_grads.restype = c_int
+    lib.lisec_const_field_grads.argtypes = [P, P, P, P, c_int, c_int, c_int, c_int, P, P, P]
     lib.lisec_conv_packed_floats.restype = c_size_t
     lib.lisec_conv_packed_floats.argtypes = [c_int, c_int, c_int]
     lib.lisec_conv_pack_weights.restype = c_int
@@ -76,13 +84,13 @@ def _declare(lib):
     lib.lisec_conv_num_mblocks.restype = c_int
     lib.lisec_conv_num_mblocks.argtypes = [POINTER(ConvGeom)]
     lib.lisec_conv_forward.restype = c_int
-    lib.lisec_conv_forward.argtypes = [POINTER(ConvGeom), P, P, P, P, c_int, P, P, P, c_size_t, P]
+    lib.lisec_conv_forward.argtypes = [POINTER(ConvGeom), P, P, P, P, c_int, P, P, P, c_size_t, P, P, c_int, P]
     lib.lisec_conv_forward_workspace_bytes.restype = c_size_t
     lib.lisec_conv_forward_workspace_bytes.argtypes = [POINTER(ConvGeom)]
     lib.lisec_conv_wgrad_workspace_bytes.restype = c_size_t
-    lib.lisec_conv_wgrad_workspace_bytes.argtypes = [POINTER(ConvGeom)]
+    lib.lisec_conv_wgrad_workspace_bytes.argtypes = [POINTER(ConvGeom), c_int]
     lib.lisec_conv_wgrad.restype = c_int
-    lib.lisec_conv_wgrad.argtypes = [POINTER(ConvGeom), P, P, c_int, P, P, P, c_size_t, c_int, P, P]
+    lib.lisec_conv_wgrad.argtypes = [POINTER(ConvGeom), P, P, c_int, P, P, P, c_size_t, c_int, P, P, P, c_int, P]
     lib.lisec_eltwise_workspace_bytes.restype = c_size_t
     lib.lisec_eltwise_workspace_bytes.argtypes = []
     lib.lisec_bn_backward.restype = c_int

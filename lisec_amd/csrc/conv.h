@@ -13,9 +13,21 @@ struct ConvGeom {
     int Cin, in_stride, Cout, out_stride, CoutP;
     int M;
     int ps, ps_channels;
+    // optional row list: GEMM row m is the position (d,h,w) = row_coords[3m..3m+2]; rows >= *row_count are void
+    const int* row_coords;
+    const int* row_count;
 };
 
 int conv_geom_check(const lisec_conv_geom* c, ConvGeom* g);
+
+#ifdef __HIPCC__
+// rows that exist: M, or the device-side count of a row list
+__device__ __forceinline__ int row_limit(const ConvGeom& g) {
+    if (!g.row_coords) return g.M;
+    const int n = *g.row_count;
+    return n < g.M ? n : g.M;
+}
+#endif
 
 #ifdef __HIPCC__
 // source coordinate of output coordinate `o` for kernel tap `k` along one axis
@@ -64,9 +76,16 @@ __device__ __forceinline__ int axis_mask(int o, int K, int ls, int pad, int n_in
 __device__ __forceinline__ RowGather row_gather(const ConvGeom& g, int m, int mode, int lane_elem_off) {
     RowGather r;
     if (m >= g.M) { r.off = 0; r.mask = 0; return r; }
-    const int HW = g.Ho * g.Wo;
-    const int d = m / HW, rem = m - d * HW;
-    const int h = rem / g.Wo, w = rem - h * g.Wo;
+    int d, h, w;
+    if (g.row_coords) {
+        if (m >= *g.row_count) { r.off = 0; r.mask = 0; return r; }
+        d = g.row_coords[3 * m]; h = g.row_coords[3 * m + 1]; w = g.row_coords[3 * m + 2];
+    } else {
+        const int HW = g.Ho * g.Wo;
+        d = m / HW;
+        const int rem = m - d * HW;
+        h = rem / g.Wo; w = rem - h * g.Wo;
+    }
     int bd, bh, bw;
     const int md = axis_mask(d, g.KD, g.ls_d, g.pd, g.Di, mode, bd);
     const int mh = axis_mask(h, g.KH, g.ls_h, g.ph, g.Hi, mode, bh);

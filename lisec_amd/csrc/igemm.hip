@@ -47,6 +47,8 @@ k_igemm(ConvGeom g, const float* __restrict__ in, const float* __restrict__ wp,
     const int mb = tile0 + xcd_remap(blockIdx.x, gridDim.x);
     const int m0 = mb * BM;
     const int n0 = blockIdx.y * BN;
+    const int mlimit = row_limit(g);
+    if (m0 >= mlimit) return;                     // row list shorter than its capacity (whole workgroup)
     const int HW = g.Ho * g.Wo;
 
     // ---- rows this thread stages: r = p*16 + tid/16, 16-byte piece tid%16 ----------------------
@@ -69,7 +71,7 @@ k_igemm(ConvGeom g, const float* __restrict__ in, const float* __restrict__ wp,
     const int KpQ = ncc * (BK / 4);              // packed K quads per tap
 
     auto live = [&](int s) -> bool {
-        if (d_first != d_last) return true;
+        if (g.row_coords || d_first != d_last) return true;
         const int kd = (s / ncc) / (g.KH * g.KW);
         return (dmask_first >> kd) & 1;
     };
@@ -179,7 +181,7 @@ k_igemm(ConvGeom g, const float* __restrict__ in, const float* __restrict__ wp,
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            if (m < g.M) {
+            if (m < mlimit) {
                 const size_t ml = (size_t)(m - tile0 * BM);
                 pz[ml * g.CoutP + n0 + col] = acc0[r];
                 pz[ml * g.CoutP + n0 + 32 + col] = acc1[r];
@@ -200,7 +202,7 @@ k_igemm(ConvGeom g, const float* __restrict__ in, const float* __restrict__ wp,
     for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         const int m = m0 + wave * 32 + row;
-        if (m < g.M) {
+        if (m < mlimit) {
             size_t orow = (size_t)m;
             if (g.ps) {
                 const int h = m / g.Wo, w = m - h * g.Wo;
@@ -357,6 +359,7 @@ int conv_geom_check(const lisec_conv_geom* c, ConvGeom* g) {
     g->CoutP = (int)align_up(c->Cout, 64);
     g->M = c->Do * c->Ho * c->Wo;
     g->ps = c->ps; g->ps_channels = c->ps_channels;
+    g->row_coords = nullptr; g->row_count = nullptr;
     return 0;
 }
 
@@ -461,9 +464,16 @@ extern "C" size_t lisec_conv_forward_workspace_bytes(const lisec_conv_geom* c) {
 extern "C" int lisec_conv_forward(const lisec_conv_geom* c, const float* in, const float* packed_w,
                                   const float* bias, const float* in_bnstate, int flags, float* out,
                                   double* stats_partials, void* workspace, size_t workspace_bytes,
+                                  const int32_t* row_coords, const int32_t* row_count, int row_capacity,
                                   lisec_stream_t stream_) {
     ConvGeom g;
     if (int rc = conv_geom_check(c, &g)) return rc;
+    if (row_coords) {
+        LISEC_CHECK_ARG(row_count && row_capacity > 0 && !stats_partials && !c->ps,
+                        "row list needs a device count, a capacity, and no stats / pixel-shuffle");
+        g.row_coords = row_coords; g.row_count = row_count; g.M = row_capacity;
+        workspace = nullptr;                      // no K slicing: the live row count is only known on the device
+    }
     LISEC_CHECK_ARG(in && packed_w && out, "NULL tensor pointer");
     LISEC_CHECK_ARG(((uintptr_t)in & 15) == 0 && ((uintptr_t)packed_w & 15) == 0, "in/weights must be 16-byte aligned");
     ConvPlan plan = make_conv_plan(g);

@@ -1,0 +1,163 @@
+// Exact shortcuts for the FIRST middle layer's backward pass (gfx950).
+//
+// The grid the first Conv3D reads (model_training.py:235-236) is a constant vector c on every empty cell
+// plus per-voxel values on the V occupied cells (vfe.hip).  Everything downstream of the grid gradient is
+// linear in it and only needs (i) the gradient at the occupied cells and (ii) its SUM over the empty cells,
+// and the weight gradient of that Conv3D splits the same way:
+//     sum_p dGrid[p][c]      = sum_tap sum_n W[tap][c][n] * S[tap][n]
+//     dW[tap][c][n]          = c[c] * S[tap][n]  +  sum_v (grid[p_v][c] - c[c]) * dy[q(p_v,tap)][n]
+// with  S[tap][n] = sum of dy[m][n] over the output positions m whose tap `tap` reads inside the grid.
+// So the 70.8 GFLOP dense data gradient and the 70.8 GFLOP dense weight gradient of that layer become two
+// V-row contractions (row lists in igemm.hip / wgrad.hip) plus the two small kernels below -- the same
+// numbers up to fp32 summation order (what Keras' autograd computes densely, model_training.py:299).
+#include "conv.h"
+
+namespace lisec {
+namespace {
+
+// per output line (d', h'): sums over w' of dy grouped by which kw taps are valid  -> line_s[line][kw][C]
+__global__ void __launch_bounds__(256)
+k_line_sums(ConvGeom g, const float* __restrict__ dy, float* __restrict__ line_s) {
+    __shared__ float red[4][256][4];
+    const int C = g.Cout, cq = C / 4;
+    const int q = threadIdx.x % cq, wsub = threadIdx.x / cq, wlanes = 256 / cq;
+    const int line = blockIdx.x;
+    float4 acc[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[k] = make_float4(0, 0, 0, 0);
+    const float* base = dy + (size_t)line * g.Wo * g.out_stride;
+    for (int w = wsub; w < g.Wo; w += wlanes) {
+        const float4 v = *reinterpret_cast<const float4*>(base + (size_t)w * g.out_stride + q * 4);
+        const int b = (w << g.ls_w) - g.pw;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (k < g.KW && b + k >= 0 && b + k < g.Wi) { acc[k].x += v.x; acc[k].y += v.y; acc[k].z += v.z; acc[k].w += v.w; }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        red[k][threadIdx.x][0] = acc[k].x; red[k][threadIdx.x][1] = acc[k].y;
+        red[k][threadIdx.x][2] = acc[k].z; red[k][threadIdx.x][3] = acc[k].w;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < g.KW * C; i += 256) {
+        const int k = i / C, c = i % C;
+        float s = 0.f;
+        for (int j = 0; j < wlanes; ++j) s += red[k][j * cq + c / 4][c % 4];
+        line_s[((size_t)line * g.KW + k) * C + c] = s;
+    }
+}
+
+// S[tap][c] = sum over the lines (d', h') for which (kd, kh) read inside the grid (fixed order, fp64)
+__global__ void __launch_bounds__(256)
+k_tap_sums(ConvGeom g, const float* __restrict__ line_s, float* __restrict__ S) {
+    __shared__ double red[256];
+    const int C = g.Cout;
+    const int tap = blockIdx.x, kw = tap % g.KW, kh = (tap / g.KW) % g.KH, kd = tap / (g.KW * g.KH);
+    const int nlines = g.Do * g.Ho;
+    const int cgroups = 256 / 64;                       // 4 line-groups x 64 channels per pass
+    for (int c0 = 0; c0 < C; c0 += 64) {
+        const int c = c0 + (threadIdx.x & 63), lg = threadIdx.x >> 6;
+        double a = 0.0;
+        if (c < C) {
+            for (int line = lg; line < nlines; line += cgroups) {
+                const int d = line / g.Ho, h = line - d * g.Ho;
+                const int bd = (d << g.ls_d) - g.pd + kd, bh = (h << g.ls_h) - g.ph + kh;
+                if (bd >= 0 && bd < g.Di && bh >= 0 && bh < g.Hi) a += (double)line_s[((size_t)line * g.KW + kw) * C + c];
+            }
+        }
+        red[threadIdx.x] = a;
+        __syncthreads();
+        if (threadIdx.x < 64 && c < C)
+            S[(size_t)tap * C + c] = (float)(red[threadIdx.x] + red[threadIdx.x + 64] + red[threadIdx.x + 128] + red[threadIdx.x + 192]);
+        __syncthreads();
+    }
+}
+
+// g_all[c] = sum_tap sum_n W[tap][c][n] * S[tap][n]      (one block per c)
+__global__ void __launch_bounds__(256)
+k_const_field_gall(const float* __restrict__ W, const float* __restrict__ S, int ntaps, int Cin, int Cout,
+                   float* __restrict__ g_all) {
+    __shared__ double red[256];
+    const int c = blockIdx.x;
+    double a = 0.0;
+    for (int i = threadIdx.x; i < ntaps * Cout; i += 256) {
+        const int tap = i / Cout, n = i - tap * Cout;
+        a += (double)W[((size_t)tap * Cin + c) * Cout + n] * (double)S[i];
+    }
+    red[threadIdx.x] = a;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) g_all[c] = (float)red[0];
+}
+
+// dW[tap][c][n] += cvec[c] * S[tap][n]
+__global__ void k_const_field_dw(const float* __restrict__ S, const float* __restrict__ cvec,
+                                 const int* __restrict__ cvec_row, int cvec_row_max, int ntaps, int Cin,
+                                 int Cout, float* __restrict__ dW) {
+    if (cvec_row) {                                   // the constant is row *cvec_row of a (rows, Cin) table
+        int r = *cvec_row;
+        if (r > cvec_row_max) r = cvec_row_max;
+        cvec += (size_t)r * Cin;
+    }
+    const long long total = (long long)ntaps * Cin * Cout;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int n = (int)(i % Cout);
+        const long long t = i / Cout;
+        const int c = (int)(t % Cin), tap = (int)(t / Cin);
+        dW[i] = fmaf(cvec[c], S[(size_t)tap * Cout + n], dW[i]);
+    }
+}
+
+}  // namespace
+}  // namespace lisec
+
+using namespace lisec;
+
+extern "C" size_t lisec_conv_tap_sums_workspace_bytes(const lisec_conv_geom* c) {
+    ConvGeom g;
+    if (conv_geom_check(c, &g)) return 0;
+    return align_up(sizeof(float) * (size_t)g.Do * g.Ho * g.KW * g.Cout, 256);
+}
+
+extern "C" int lisec_conv_tap_sums(const lisec_conv_geom* c, const float* dy, float* S, void* workspace,
+                                   size_t workspace_bytes, lisec_stream_t stream_) {
+    ConvGeom g;
+    if (int rc = conv_geom_check(c, &g)) return rc;
+    LISEC_CHECK_ARG(c->mode == 0 && dy && S && workspace, "tap sums: mode-0 geometry and non-NULL pointers required");
+    LISEC_CHECK_ARG(g.Cout % 4 == 0 && g.Cout <= 256 && 256 % (g.Cout / 4) == 0 && g.out_stride % 4 == 0,
+                    "tap sums: Cout/4 must divide 256");
+    if (workspace_bytes < lisec_conv_tap_sums_workspace_bytes(c)) {
+        set_error("tap sums workspace too small");
+        return LISEC_ENOSPC;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream_);
+    float* line_s = static_cast<float*>(workspace);
+    hipLaunchKernelGGL(k_line_sums, dim3(g.Do * g.Ho), dim3(256), 0, st, g, dy, line_s);
+    hipLaunchKernelGGL(k_tap_sums, dim3(g.KD * g.KH * g.KW), dim3(256), 0, st, g, line_s, S);
+    LISEC_LAUNCH_CHECK();
+    return LISEC_OK;
+}
+
+extern "C" int lisec_const_field_grads(const float* W, const float* S, const float* cvec, const int32_t* cvec_row,
+                                       int cvec_row_max, int ntaps, int Cin, int Cout, float* dW, float* g_all,
+                                       lisec_stream_t stream_) {
+    LISEC_CHECK_ARG(S && ntaps > 0 && Cin > 0 && Cout > 0, "bad arguments");
+    hipStream_t st = static_cast<hipStream_t>(stream_);
+    if (g_all) {
+        LISEC_CHECK_ARG(W, "W is needed for g_all");
+        hipLaunchKernelGGL(k_const_field_gall, dim3(Cin), dim3(256), 0, st, W, S, ntaps, Cin, Cout, g_all);
+    }
+    if (dW) {
+        LISEC_CHECK_ARG(cvec, "cvec is needed for dW");
+        long long total = (long long)ntaps * Cin * Cout;
+        int gb = cdiv(total, 256);
+        if (gb > 2048) gb = 2048;
+        hipLaunchKernelGGL(k_const_field_dw, dim3(gb), dim3(256), 0, st, S, cvec, cvec_row, cvec_row_max, ntaps, Cin, Cout, dW);
+    }
+    LISEC_LAUNCH_CHECK();
+    return LISEC_OK;
+}

@@ -188,11 +188,47 @@ k_vfe_grid(const int* __restrict__ info, const int* __restrict__ cell_voxel, int
     }
 }
 
+// compact per-voxel outputs: vout[v] = the grid value of voxel v (v == V: the empty-cell constant),
+// delta[v] = vout[v] - vout[V]  (what the first Conv3D's sparse backward contracts against)
+__global__ void __launch_bounds__(256)
+k_vfe_vout(const int* __restrict__ info, int cap, const float* __restrict__ ymm3, const float* __restrict__ bn3,
+           float* __restrict__ vout, float* __restrict__ delta) {
+    int V = info[LISEC_VI_NVOX];
+    if (V > cap) V = cap;
+    const int q = threadIdx.x & 15;
+    const float4 sc = reinterpret_cast<const float4*>(bn3)[q];
+    const float4 sh = reinterpret_cast<const float4*>(bn3 + 64)[q];
+    auto value = [&](int v) {
+        const float4 mx = reinterpret_cast<const float4*>(ymm3 + (size_t)v * 128)[q];
+        const float4 mn = reinterpret_cast<const float4*>(ymm3 + (size_t)v * 128 + 64)[q];
+        return make_float4(pool_from(mx.x, mn.x, sc.x, sh.x), pool_from(mx.y, mn.y, sc.y, sh.y),
+                           pool_from(mx.z, mn.z, sc.z, sh.z), pool_from(mx.w, mn.w, sc.w, sh.w));
+    };
+    const float4 c = value(V);
+    const long long total = (long long)(V + 1) * 16;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int v = (int)(i >> 4);
+        const float4 o = value(v);
+        reinterpret_cast<float4*>(vout)[i] = o;
+        reinterpret_cast<float4*>(delta)[i] = make_float4(o.x - c.x, o.y - c.y, o.z - c.z, o.w - c.w);
+    }
+}
+
 }  // namespace
 
 }  // namespace lisec
 
 using namespace lisec;
+
+extern "C" size_t lisec_vfe_saved_field_offset(int cap_voxels, int field) {
+    VfeSaved sv(nullptr, cap_voxels < 0 ? 0 : cap_voxels);
+    const float* base = nullptr;
+    switch (field) {
+        case LISEC_VFE_SAVED_VOUT: return (size_t)(sv.vout - base);
+        case LISEC_VFE_SAVED_DELTA: return (size_t)(sv.delta - base);
+        default: return (size_t)-1;
+    }
+}
 
 extern "C" size_t lisec_vfe_saved_floats(int cap_voxels) {
     if (cap_voxels < 0) return 0;
@@ -252,6 +288,11 @@ extern "C" int lisec_vfe_forward(const lisec_vfe_params* p, const int32_t* info,
     }
     hipLaunchKernelGGL(k_vfe_grid, dim3(4096), dim3(256), 0, st, info, cell_voxel, ncells, cap_voxels,
                        sv.ymm3, sv.bn3, grid);
+    {
+        int vb = cdiv((long long)(cap_voxels + 1) * 16, 256);
+        if (vb > 1024) vb = 1024;
+        hipLaunchKernelGGL(k_vfe_vout, dim3(vb), dim3(256), 0, st, info, cap_voxels, sv.ymm3, sv.bn3, sv.vout, sv.delta);
+    }
     LISEC_LAUNCH_CHECK();
     return LISEC_OK;
 }

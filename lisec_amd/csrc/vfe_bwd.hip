@@ -102,6 +102,39 @@ k_virtual_dout(const int* __restrict__ info, int cap, const double* __restrict__
     if (ry == 0) dout[(size_t)V * 64 + c] = (float)red[0][c];
 }
 
+// column sums of the compact gradient rows [0, V) as per-block fp64 parts (rows b, b+G, ... per block)
+__global__ void __launch_bounds__(256)
+k_rows_colsum(const int* __restrict__ info, int cap, const float* __restrict__ dout, double* __restrict__ parts) {
+    __shared__ double red[4][64];
+    int V = info[LISEC_VI_NVOX];
+    if (V > cap) V = cap;
+    const int c = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    double a = 0.0;
+    for (int v = blockIdx.x * 4 + ry; v < V; v += gridDim.x * 4) a += (double)dout[(size_t)v * 64 + c];
+    red[ry][c] = a;
+    __syncthreads();
+    if (ry == 0) parts[(size_t)blockIdx.x * 64 + c] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+}
+
+// virtual voxel: (sum of the grid gradient over ALL cells) - (sum over the occupied cells)
+__global__ void __launch_bounds__(1024)
+k_virtual_from_total(const int* __restrict__ info, int cap, const double* __restrict__ parts, int nparts,
+                     const float* __restrict__ g_all, float* __restrict__ dout) {
+    __shared__ double red[16][64];
+    int V = info[LISEC_VI_NVOX];
+    if (V > cap) V = cap;
+    const int c = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    double a = 0.0;
+    for (int b = ry; b < nparts; b += 16) a += parts[(size_t)b * 64 + c];
+    red[ry][c] = a;
+    __syncthreads();
+    for (int o = 8; o > 0; o >>= 1) {
+        if (ry < o) red[ry][c] += red[ry + o][c];
+        __syncthreads();
+    }
+    if (ry == 0) dout[(size_t)V * 64 + c] = (float)((double)g_all[c] - red[0][c]);
+}
+
 __device__ __forceinline__ void block_stats_out(double s1, double s2, int C, double* parts, int w, int lane) {
     __shared__ double red[2][4][64];
     red[0][w][lane] = s1; red[1][w][lane] = s2;
@@ -410,10 +443,11 @@ extern "C" size_t lisec_vfe_backward_workspace_bytes(int cap_voxels, int n_point
 extern "C" int lisec_vfe_backward(const lisec_vfe_params* p, const int32_t* info, const int32_t* cell_voxel,
                                   const int32_t* npts, const int32_t* row_start, const float* rows, int n_points,
                                   int ncells, int T, int cap_voxels, const float* saved, const float* dgrid,
-                                  const lisec_vfe_grads* g, void* workspace, size_t workspace_bytes,
-                                  lisec_stream_t stream_) {
-    LISEC_CHECK_ARG(p && info && cell_voxel && npts && row_start && rows && saved && dgrid && g && workspace,
-                    "NULL pointer");
+                                  float* dout_rows, const float* g_all, const lisec_vfe_grads* g, void* workspace,
+                                  size_t workspace_bytes, lisec_stream_t stream_) {
+    LISEC_CHECK_ARG(p && info && cell_voxel && npts && row_start && rows && saved && g && workspace, "NULL pointer");
+    LISEC_CHECK_ARG((dgrid != nullptr) != (dout_rows != nullptr), "pass either dgrid or dout_rows");
+    LISEC_CHECK_ARG(!dout_rows || g_all, "dout_rows needs g_all");
     LISEC_CHECK_ARG(ncells > 0 && T >= 1 && T <= 64 && cap_voxels >= 0 && n_points >= 0, "bad sizes");
     for (int i = 0; i < 3; ++i)
         LISEC_CHECK_ARG(p->kernel[i] && g->kernel[i] && g->gamma[i] && g->beta[i], "NULL VFE parameter/gradient pointer");
@@ -427,10 +461,19 @@ extern "C" int lisec_vfe_backward(const lisec_vfe_params* p, const int32_t* info
     VfeIn in{info, npts, row_start, rows, ncells, T, cap_voxels};
     const double N = (double)ncells * (double)T;
     // 1. route the grid gradient to voxels
-    const int gblocks = 1024;
-    hipLaunchKernelGGL(k_gather, dim3(gblocks), dim3(256), 0, st, info, cell_voxel, ncells, cap_voxels, dgrid,
-                       ws.dout, ws.parts_a);
-    hipLaunchKernelGGL(k_virtual_dout, dim3(1), dim3(1024), 0, st, info, cap_voxels, ws.parts_a, gblocks, ws.dout);
+    if (dgrid) {
+        const int gblocks = 1024;
+        hipLaunchKernelGGL(k_gather, dim3(gblocks), dim3(256), 0, st, info, cell_voxel, ncells, cap_voxels, dgrid,
+                           ws.dout, ws.parts_a);
+        hipLaunchKernelGGL(k_virtual_dout, dim3(1), dim3(1024), 0, st, info, cap_voxels, ws.parts_a, gblocks, ws.dout);
+    } else {
+        // rows [0,V) were computed at the occupied cells only; the virtual voxel gets total - occupied
+        ws.dout = dout_rows;
+        const int cb = 256;
+        hipLaunchKernelGGL(k_rows_colsum, dim3(cb), dim3(256), 0, st, info, cap_voxels, dout_rows, ws.parts_a);
+        hipLaunchKernelGGL(k_virtual_from_total, dim3(1), dim3(1024), 0, st, info, cap_voxels, ws.parts_a, cb, g_all,
+                           dout_rows);
+    }
     LISEC_LAUNCH_CHECK();
     // 2. layer 3 (fcn)
     hipLaunchKernelGGL(k_l3_stats, dim3(kBwdBlocks), dim3(256), 0, st, in, sv.bn3, sv.ymm3, ws.dout, ws.parts_a);

@@ -42,6 +42,7 @@ struct VfeWeights {          // per lane: column (lane & (C-1)) of each Dense ke
 
 struct VfeSaved {            // layout of the caller-owned `saved` float buffer (lisec_vfe_saved_floats)
     float *bn1, *bn2, *bn3, *ymm1, *ymm2, *ymm3;
+    float *vout, *delta;     // per-voxel grid value (row V = the empty-cell constant) and vout[v] - vout[V]
     size_t floats;
     VfeSaved(float* base, int cap) {
         size_t o = 0;
@@ -51,6 +52,8 @@ struct VfeSaved {            // layout of the caller-owned `saved` float buffer 
         ymm1 = base + o; o += (size_t)(cap + 1) * 32;
         ymm2 = base + o; o += (size_t)(cap + 1) * 64;
         ymm3 = base + o; o += (size_t)(cap + 1) * 128;
+        vout = base + o; o += (size_t)(cap + 1) * 64;
+        delta = base + o; o += (size_t)(cap + 1) * 64;
         floats = o;
     }
 };

@@ -37,7 +37,8 @@ k_wgrad(ConvGeom g, const float* __restrict__ in, const float* __restrict__ in_b
     const int tap0 = group * TG;                 // taps tap0 .. tap0+TG-1 share (kd, kh)
     const int c0 = blockIdx.y * BC, n0 = blockIdx.z * BC;
     const int HW = g.Ho * g.Wo;
-    const int ntiles = (g.M + BMW - 1) / BMW;
+    const int mlimit = row_limit(g);
+    const int ntiles = (mlimit + BMW - 1) / BMW;
     const int t_begin = split * tiles_per_split;
     const int t_end = t_begin + tiles_per_split < ntiles ? t_begin + tiles_per_split : ntiles;
     const int kd = tap0 / (g.KH * g.KW), kh = (tap0 / g.KW) % g.KH, kw0 = tap0 % g.KW;
@@ -72,6 +73,7 @@ k_wgrad(ConvGeom g, const float* __restrict__ in, const float* __restrict__ in_b
         for (int p = 0; p < 8; ++p) rows[p] = row_gather(g, tile * BMW + p * 16 + (tid >> 4), MODE, cA);
     };
     auto tile_live = [&](int tile) -> bool {     // whole tile outside the valid depth range of this tap group
+        if (g.row_coords) return true;
         int mfirst = tile * BMW, mlast = mfirst + BMW - 1 < g.M ? mfirst + BMW - 1 : g.M - 1;
         int df = mfirst / HW, dl = mlast / HW;
         if (df != dl) return true;
@@ -95,7 +97,7 @@ k_wgrad(ConvGeom g, const float* __restrict__ in, const float* __restrict__ in_b
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
             int m = tile * BMW + p * 16 + (tid >> 4);
-            if (m < g.M && cokD) {
+            if (m < mlimit && cokD) {
                 rd[p] = *reinterpret_cast<const float4*>(dy + (size_t)m * g.out_stride + cD);
                 dvalid |= 1u << p;
             } else {
@@ -280,17 +282,23 @@ int launch_wgrad(const ConvGeom& g, const WgradPlan& p, const float* in, const f
 
 using namespace lisec;
 
-extern "C" size_t lisec_conv_wgrad_workspace_bytes(const lisec_conv_geom* c) {
+extern "C" size_t lisec_conv_wgrad_workspace_bytes(const lisec_conv_geom* c, int row_capacity) {
     ConvGeom g;
     if (conv_geom_check(c, &g)) return 0;
+    if (row_capacity > 0) g.M = row_capacity;
     return make_plan(g).ws_bytes;
 }
 
 extern "C" int lisec_conv_wgrad(const lisec_conv_geom* c, const float* in, const float* in_bnstate, int flags,
                                 const float* dy, const float* dy_bnstate, void* workspace,
-                                size_t workspace_bytes, int transpose_out, float* dW, lisec_stream_t stream_) {
+                                size_t workspace_bytes, int transpose_out, float* dW, const int32_t* row_coords,
+                                const int32_t* row_count, int row_capacity, lisec_stream_t stream_) {
     ConvGeom g;
     if (int rc = conv_geom_check(c, &g)) return rc;
+    if (row_coords) {
+        LISEC_CHECK_ARG(row_count && row_capacity > 0, "row list needs a device count and a capacity");
+        g.row_coords = row_coords; g.row_count = row_count; g.M = row_capacity;
+    }
     LISEC_CHECK_ARG(in && dy && workspace && dW, "NULL pointer");
     LISEC_CHECK_ARG(g.out_stride % 4 == 0 && g.Cout % 4 == 0, "dY channels/stride must be multiples of 4");
     LISEC_CHECK_ARG(((uintptr_t)in & 15) == 0 && ((uintptr_t)dy & 15) == 0, "in/dy must be 16-byte aligned");

@@ -198,7 +198,7 @@ class LisecNet:
         self.velocity = torch.zeros_like(p.theta)
         self.dact = {}
         for name, t in self.act.items():
-            if name.endswith(".u") or name in ("grid", "concat", "head") or ".y" in name:
+            if name.endswith(".u") or name in ("concat", "head") or ".y" in name:
                 self.dact[name] = torch.empty_like(t)
         self.packed_t = {}
         self.dgeom = {}
@@ -233,6 +233,12 @@ class LisecNet:
                 self.packed_t[d.name] = (torch.empty(ops.packed_floats(1, 64, 64), dtype=f32, device=dev),
                                          (1, 64, 64, 0, 1, 64))
                 self.dact[L["name"] + ".z"] = torch.empty_like(self.act[L["name"] + ".y"])
+        # first middle layer: exact sparse backward (csrc/sparse_grid.hip) -- never forms the 164 MB grid gradient
+        first = self.layers[0]["conv"]
+        self.mid1_S = torch.empty(27 * 64, dtype=f32, device=dev)
+        self.g_all = torch.empty(64, dtype=f32, device=dev)
+        self.tapsum_ws = torch.empty(ops.tap_sums_workspace_bytes(first.g), dtype=torch.uint8, device=dev)
+        self.dout_rows = None
         self.head_dgeom = ops.geom(0, (1, Ho, Wo), (1, Ho, Wo), (1, 1, 1), (1, 1, 1), (0, 0, 0), 16, 768)
         self.packed_t["head"] = (torch.empty(ops.packed_floats(1, 16, 768), dtype=f32, device=dev), None)
         self.head_dw = torch.empty(768, 16, dtype=f32, device=dev)
@@ -268,6 +274,14 @@ class LisecNet:
         self._pack_all_t()
         p, a, d, G = self.params, self.act, self.dact, self.grad
         M = self.Ho * self.Wo
+        sample = self.vfe._sample
+        first = self.layers[0]["conv"]
+        need = ops.wgrad_workspace_bytes(self.dgeom[first.name], sample.cap)
+        if need > self.wgrad_ws.numel() or self.dout_rows is None or self.dout_rows.shape[0] < sample.cap + 1:
+            torch.cuda.synchronize()               # (re)size scratch that depends on the cloud's capacity
+            if need > self.wgrad_ws.numel():
+                self.wgrad_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            self.dout_rows = torch.empty((sample.cap + 1, 64), dtype=torch.float32, device=self.device)
         kind = {"mse": 0, "smoothl1_ce": 1}[loss]
         ops.rpn_loss(a["head"], y_cls, y_reg, M, kind, d["head"], self.loss_out, grad_scale=grad_scale)
         # ---- heads (model_training.py:254-255) ---------------------------------------------------
@@ -329,11 +343,28 @@ class LisecNet:
                 ops.bn_backward(d[n + ".z"], 64, a[n + ".y"], self.bnstate[c.bn], c.M, 64, False,
                                 p.grad_view(G, c.bn + ".gamma"), p.grad_view(G, c.bn + ".beta"), d[n + ".z"],
                                 dbias=p.grad_view(G, c.bias))
-                on_side(lambda L=L, c=c, n=n: ops.conv_wgrad(c.g, a[L["src"]], d[n + ".z"], p.grad_view(G, c.wname),
-                                                             self.wgrad_ws))
-                dgrad_into(c, d[n + ".z"], L["src"])
+                if L["src"] == "grid":
+                    # the grid is a constant on the empty cells + V voxel rows: both gradients reduce to V-row
+                    # contractions plus sums of dy over boundary-trimmed boxes (exact; csrc/sparse_grid.hip)
+                    rows = (sample.coords, sample.info, sample.cap)
+                    dg = self.dgeom[c.name]
+                    dW = p.grad_view(G, c.wname)
+                    ops.tap_sums(c.g, d[n + ".z"], self.mid1_S, self.tapsum_ws)
+                    ops.const_field_grads(p.view(c.wname), self.mid1_S, None, 27, 64, 64, g_all=self.g_all)
+                    vout, delta = self.vfe.saved_field("vout"), self.vfe.saved_field("delta")
+
+                    def sparse_wgrad(dg=dg, dW=dW, dz=d[n + ".z"], rows=rows, vout=vout, delta=delta):
+                        ops.conv_wgrad(dg, dz, delta, dW, self.wgrad_ws, transpose_out=True, rows=rows)
+                        ops.const_field_grads(None, self.mid1_S, vout, 27, 64, 64, dW=dW, cvec_row=sample.info,
+                                              cvec_row_max=sample.cap)
+                    on_side(sparse_wgrad)
+                    ops.conv_forward(dg, d[n + ".z"], self.packed_t[c.name][0], self.dout_rows, rows=rows)
+                else:
+                    on_side(lambda L=L, c=c, n=n: ops.conv_wgrad(c.g, a[L["src"]], d[n + ".z"],
+                                                                 p.grad_view(G, c.wname), self.wgrad_ws))
+                    dgrad_into(c, d[n + ".z"], L["src"])
         # ---- VFE -----------------------------------------------------------------------------------
-        self.vfe.backward(d["grid"], G)
+        self.vfe.backward(None, G, dout_rows=self.dout_rows, g_all=self.g_all)
         done = torch.cuda.Event()
         done.record(self.side)
         main.wait_event(done)                  # every weight gradient has landed before the optimizer reads G

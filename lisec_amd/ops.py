@@ -87,12 +87,14 @@ def conv_workspace(g, device):
     return _SPLITK_WS[key]
 
 
-def conv_forward(g, x, wp, out, bias=None, in_bn=None, flags=0, stats=None, splitk=True):
-    ws = conv_workspace(g, out.device) if splitk else None
+def conv_forward(g, x, wp, out, bias=None, in_bn=None, flags=0, stats=None, splitk=True, rows=None):
+    """rows: optional (row_coords int32 (cap,3), row_count int32 device scalar, capacity) row list."""
+    ws = conv_workspace(g, out.device) if (splitk and rows is None) else None
+    rc, rn, cap = rows if rows is not None else (None, None, 0)
     _lib.check(_lib.load().lisec_conv_forward(ctypes.byref(g), _lib.ptr(x), _lib.ptr(wp), _lib.ptr(bias),
                                               _lib.ptr(in_bn), flags, _lib.ptr(out), _lib.ptr(stats),
                                               _lib.ptr(ws), ws.numel() if ws is not None else 0,
-                                              _lib.current_stream()))
+                                              _lib.ptr(rc), _lib.ptr(rn), cap, _lib.current_stream()))
     return out
 
 
@@ -107,15 +109,17 @@ def bn_fold(gamma, beta, moving_mean, moving_var, C, bnstate):
                                          _lib.ptr(moving_var), C, _lib.ptr(bnstate), _lib.current_stream()))
 
 
-def wgrad_workspace_bytes(g):
-    return _lib.load().lisec_conv_wgrad_workspace_bytes(ctypes.byref(g))
+def wgrad_workspace_bytes(g, row_capacity=0):
+    return _lib.load().lisec_conv_wgrad_workspace_bytes(ctypes.byref(g), row_capacity)
 
 
-def conv_wgrad(g, x, dy, dW, workspace, in_bn=None, flags=0, transpose_out=False, dy_bn=None):
+def conv_wgrad(g, x, dy, dW, workspace, in_bn=None, flags=0, transpose_out=False, dy_bn=None, rows=None):
+    rc, rn, cap = rows if rows is not None else (None, None, 0)
     _lib.check(_lib.load().lisec_conv_wgrad(ctypes.byref(g), _lib.ptr(x), _lib.ptr(in_bn), flags, _lib.ptr(dy),
                                             _lib.ptr(dy_bn), _lib.ptr(workspace),
                                             workspace.numel() * workspace.element_size(),
-                                            1 if transpose_out else 0, _lib.ptr(dW), _lib.current_stream()))
+                                            1 if transpose_out else 0, _lib.ptr(dW), _lib.ptr(rc), _lib.ptr(rn), cap,
+                                            _lib.current_stream()))
     return dW
 
 
@@ -160,3 +164,18 @@ def sgd_nesterov_step(theta, grad, velocity, lr_t, momentum):
 
 def scale_(x, s):
     _lib.check(_lib.load().lisec_scale(_lib.ptr(x), x.numel(), s, _lib.current_stream()))
+
+
+def tap_sums(g, dy, S, workspace):
+    _lib.check(_lib.load().lisec_conv_tap_sums(ctypes.byref(g), _lib.ptr(dy), _lib.ptr(S), _lib.ptr(workspace),
+                                               workspace.numel() * workspace.element_size(), _lib.current_stream()))
+
+
+def tap_sums_workspace_bytes(g):
+    return _lib.load().lisec_conv_tap_sums_workspace_bytes(ctypes.byref(g))
+
+
+def const_field_grads(W, S, cvec, ntaps, cin, cout, dW=None, g_all=None, cvec_row=None, cvec_row_max=0):
+    _lib.check(_lib.load().lisec_const_field_grads(_lib.ptr(W), _lib.ptr(S), _lib.ptr(cvec), _lib.ptr(cvec_row),
+                                                   cvec_row_max, ntaps, cin, cout, _lib.ptr(dW), _lib.ptr(g_all),
+                                                   _lib.current_stream()))

@@ -58,9 +58,16 @@ class VFEStack:
                                                       _lib.current_stream()))
         return out
 
-    def backward(self, dgrid, grad):
-        """dgrid: (D,H,W,64) gradient wrt the grid of the last training forward; grad: flat gradient buffer
-        laid out like params.theta (VFE entries are overwritten)."""
+    def saved_field(self, which):
+        """View of the compact per-voxel outputs of the last forward: 'vout' / 'delta', shape (cap+1, 64)."""
+        cap = self._sample.cap
+        off = self.lib.lisec_vfe_saved_field_offset(cap, {"vout": 0, "delta": 1}[which])
+        return self._saved[off:off + (cap + 1) * 64].view(cap + 1, 64)
+
+    def backward(self, dgrid, grad, dout_rows=None, g_all=None):
+        """dgrid: (D,H,W,64) gradient wrt the grid of the last training forward -- or None with the compact
+        form (dout_rows (cap+1,64): gradient at the occupied cells, g_all (64,): its sum over all cells);
+        grad: flat gradient buffer laid out like params.theta (VFE entries are overwritten)."""
         sample, p = self._sample, self.params
         D, H, W = sample.grid_shape
         need = self.lib.lisec_vfe_backward_workspace_bytes(sample.cap, sample.n_points)
@@ -75,5 +82,6 @@ class VFEStack:
         _lib.check(self.lib.lisec_vfe_backward(
             ctypes.byref(cp), _lib.ptr(sample.info), _lib.ptr(sample.cell_voxel), _lib.ptr(sample.npts),
             _lib.ptr(sample.row_start), _lib.ptr(sample.rows), sample.n_points, D * H * W,
-            sample.cfg.sampleSize, sample.cap, _lib.ptr(self._saved), _lib.ptr(dgrid), ctypes.byref(g),
+            sample.cfg.sampleSize, sample.cap, _lib.ptr(self._saved), _lib.ptr(dgrid), _lib.ptr(dout_rows),
+            _lib.ptr(g_all), ctypes.byref(g),
             _lib.ptr(self._bws), self._bws.numel(), _lib.current_stream()))
