@@ -127,6 +127,14 @@ def forward(params, x, training=False, stats=None, taps=None):
     h = h.max(dim=-2).values                               # MaxPoolingVFELayer(combine=True) :235
     if taps is not None:
         taps["vfe_grid"] = h
+    return forward_from_grid(p, h, training, stats, taps)
+
+
+def forward_from_grid(params, h, training=False, stats=None, taps=None):
+    """The graph from the first Conv3D on (model_training.py:236-255); h: (B, D, H, W, 64), the output of
+    MaxPoolingVFELayer(combine=True).  Lets the full Lyft grid be checked on a CPU: the VFE part comes from the
+    sparse-exact oracle (oracle/vfe_sparse_ref.py, proven equal to the dense VFE), the rest is dense."""
+    p = params
     for i, (stride, pad) in enumerate(MID):                # :236-238
         w = p[f"mid{i+1}.conv.kernel"].permute(4, 3, 0, 1, 2)
         y = F.conv3d(h.permute(0, 4, 1, 2, 3), w, p[f"mid{i+1}.conv.bias"], stride=stride, padding=pad)
