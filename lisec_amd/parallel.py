@@ -21,9 +21,11 @@ class DataParallel:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29500")
             if backend is None:
-                backend = "nccl" if self.on_gpu else "gloo"
+                # LISEC_DIST_BACKEND=gloo lets several ranks share ONE GPU in tests (RCCL wants a GPU per rank)
+                backend = os.environ.get("LISEC_DIST_BACKEND") or ("nccl" if self.on_gpu else "gloo")
+            self.backend = backend
             kwargs = {}
-            if self.on_gpu:
+            if self.on_gpu and backend == "nccl":
                 kwargs["device_id"] = self.device
             dist.init_process_group(backend=backend, rank=int(os.environ.get("RANK", "0")),
                                     world_size=int(os.environ.get("WORLD_SIZE", "1")), **kwargs)
@@ -58,7 +60,7 @@ class DataParallel:
         return float(t.item())
 
     def barrier(self):
-        if self.on_gpu:
+        if self.on_gpu and dist.get_backend() == "nccl":
             dist.barrier(device_ids=[self.device.index])
         else:
             dist.barrier()
