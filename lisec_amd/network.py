@@ -328,8 +328,9 @@ class LisecNet:
                 dst = L["dst"]
                 C = c.g.Cout
                 ops.bn_backward(d[dst], C, a[dst], self.bnstate[c.bn], c.M, C, True,
-                                p.grad_view(G, c.bn + ".gamma"), p.grad_view(G, c.bn + ".beta"), d[dst],
-                                dbias=p.grad_view(G, c.bias))
+                                p.grad_view(G, c.bn + ".gamma"), p.grad_view(G, c.bn + ".beta"), d[dst])
+                # the bias of a conv feeding a training-mode BN has gradient sum(dy) == 0 identically (BN removes
+                # the mean); Keras' autograd returns rounding noise there -- the exact 0 stays in self.grad
                 on_side(lambda L=L, c=c, dst=dst: ops.conv_wgrad(
                     c.g, a[L["src"]], d[dst], p.grad_view(G, c.wname), self.wgrad_ws,
                     in_bn=self.bnstate[c.in_bn] if c.in_bn else None, flags=ops.IN_RELU if c.in_relu else 0))
@@ -341,8 +342,7 @@ class LisecNet:
                                                           self.wgrad_ws, in_bn=self.bnstate[dn.in_bn]))
                 ops.conv_forward(self.dgeom[dn.name], d[n + ".u"], self.packed_t[dn.name][0], d[n + ".z"])
                 ops.bn_backward(d[n + ".z"], 64, a[n + ".y"], self.bnstate[c.bn], c.M, 64, False,
-                                p.grad_view(G, c.bn + ".gamma"), p.grad_view(G, c.bn + ".beta"), d[n + ".z"],
-                                dbias=p.grad_view(G, c.bias))
+                                p.grad_view(G, c.bn + ".gamma"), p.grad_view(G, c.bn + ".beta"), d[n + ".z"])
                 if L["src"] == "grid":
                     # the grid is a constant on the empty cells + V voxel rows: both gradients reduce to V-row
                     # contractions plus sums of dy over boundary-trimmed boxes (exact; csrc/sparse_grid.hip)
