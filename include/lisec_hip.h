@@ -85,6 +85,13 @@ int lisec_voxel_rows_to_padded(const int32_t* info, const int32_t* npts, const i
                                const float* rows, int sampleSize, int cap_voxels, float* padded,
                                lisec_stream_t stream);
 
+/* Lidar ingest (rotate_points + translation of combine_lidar_data, model_training.py:65-98):
+ * out[i] = R * raw[i, :3] + t in float64; raw: device float32 rows of raw_stride (5 for Lyft .bin files);
+ * rotation9: HOST row-major 3x3 rotation matrix of the sensor quaternion, translation3: HOST;
+ * out: device float64 (n,3) -- typically a slice of the concatenated cloud handed to lisec_voxelize. */
+int lisec_lidar_transform(const float* raw, int n_points, int raw_stride, const double* rotation9,
+                          const double* translation3, double* out, lisec_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * 2. VFE stack (sparse-exact) -- replaces addVFELayer(6,32) + addVFELayer(32,64) + addFCN(64,64)
  *    + MaxPoolingVFELayer(combine=True) (model_training.py:155-186, :231-235, layers :32-61) on the

@@ -60,6 +60,8 @@ def _declare(lib):
     lib.lisec_vfe_workspace_bytes.restype = c_size_t
     lib.lisec_vfe_workspace_bytes.argtypes = []
     LL = ctypes.c_longlong
+    lib.lisec_lidar_transform.restype = c_int
+    lib.lisec_lidar_transform.argtypes = [P, c_int, c_int, POINTER(c_double), POINTER(c_double), P, P]
     lib.lisec_vfe_grid_from_saved.restype = c_int
     lib.lisec_vfe_grid_from_saved.argtypes = [P, P, c_int, c_int, P, P, P]
     lib.lisec_vfe_backward_workspace_bytes.restype = c_size_t

@@ -149,6 +149,36 @@ def combine_lidar_data(sample, dataDir, level5Data):
     return np.concatenate(allPoints)
 
 
+def combine_lidar_data_gpu(sample, dataDir, level5Data, device=None):
+    """combine_lidar_data with the rotate + translate + concatenate done on the GPU: the raw float32 .bin rows
+    are uploaded once (20 B/point) and the float64 (n,3) cloud never exists on the host.  Returns a device
+    tensor that VFE_preprocessing accepts directly."""
+    import ctypes
+    device = device or _lib.require_gpu()
+    lib = _lib.load()
+    sensorTypes = ['LIDAR_TOP', 'LIDAR_FRONT_RIGHT', 'LIDAR_FRONT_LEFT']
+    frames = []
+    for sensorType in [s for s in sensorTypes if s in sample['data']]:
+        frame = level5Data.get('sample_data', sample['data'][sensorType])
+        sensor = level5Data.get('calibrated_sensor', frame['calibrated_sensor_token'])
+        filePath = os.path.join(dataDir, *frame['filename'].replace('\\', '/').split('/'))
+        raw = np.fromfile(filePath, dtype=np.float32).reshape(-1, 5)
+        frames.append((raw, sensor))
+    total = sum(len(r) for r, _ in frames)
+    out = torch.empty((total, 3), dtype=torch.float64, device=device)
+    at = 0
+    for raw, sensor in frames:
+        d_raw = torch.from_numpy(raw).to(device)
+        R = np.ascontiguousarray(_quaternion_matrix(sensor['rotation']), dtype=np.float64)
+        t = np.ascontiguousarray(np.asarray(sensor['translation'], dtype=np.float64))
+        _lib.check(lib.lisec_lidar_transform(
+            _lib.ptr(d_raw), len(raw), 5, R.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+            t.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), ctypes.c_void_p(out.data_ptr() + at * 24),
+            _lib.current_stream()))
+        at += len(raw)
+    return out
+
+
 # ---------------------------------------------------------------------------------------------------
 # the two custom layers the reference names in custom_objects (model_training.py:32-61)
 class RepeatLayer:

@@ -101,3 +101,21 @@ def test_sparse_tensor_surface_and_dense_input():
     assert mt.RepeatLayer()(x).shape == (2, 35, 3)
     assert mt.MaxPoolingVFELayer(combine=True)(torch.rand(4, 35, 8)).shape == (4, 8)
     assert mt.get_voxel((-0.1, 0.3, 0.6), 0.5, 0.25, 0.25) == (-1, 1, 2)
+
+
+def test_gpu_lidar_ingest_matches_numpy(tmp_path):
+    """combine_lidar_data_gpu == the numpy combine_lidar_data (float64, 1e-12) and feeds the voxeliser."""
+    import torch
+    from lisec_amd import model_training as mt
+    rng = np.random.default_rng(4)
+    root = tmp_path / "lyft"
+    l5 = FakeLevel5(str(root), 2, rng)
+    for smp in l5.samples:
+        ref = mt.combine_lidar_data(smp, str(root), l5)
+        got = mt.combine_lidar_data_gpu(smp, str(root), l5)
+        assert got.dtype == torch.float64 and tuple(got.shape) == ref.shape
+        assert np.allclose(got.cpu().numpy(), ref, rtol=1e-12, atol=1e-12)
+        a = mt.VFE_preprocessing(got, 0.5, 0.25, 0.25, 35, 100, 200, 8).sample.to_host()
+        b = mt.VFE_preprocessing(ref, 0.5, 0.25, 0.25, 35, 100, 200, 8).sample.to_host()
+        # identical clouds up to the last float64 bit -> identical voxels unless a point grazes a cell border
+        assert len(a["coords"]) == len(b["coords"]) and np.array_equal(a["coords"], b["coords"])
