@@ -298,6 +298,36 @@ int lisec_sgd_nesterov_step(float* theta, const float* grad, float* velocity, lo
 /* x *= s  (gradient averaging after the data-parallel all-reduce) */
 int lisec_scale(float* x, long long n, float s, lisec_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * 5. Box geometry either side of the network; float64 like the reference.
+ *    Anchor grid of rpnToRegion.py:75-150 / serialize_data.py:201-232: outX x outY cells of vx x vy metres
+ *    (nx/2, ny/2, 2*voxelx, 2*voxely), two anchors (l, w, h, yaw) per cell.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    int outX, outY;
+    double vx, vy;
+    double anchors[2][4];
+} lisec_rpn_cfg;
+
+/* rpnToRegion (rpnToRegion.py:113-164): decode cls (outX*outY rows of cls_stride floats, 2 used) and reg
+ * (rows of reg_stride floats, 14 used) into boxes, then greedy NMS (nonMaxSuppressionFast, :18-72) with the
+ * rotated IoU of serialize_data.py:138-178.  The reference calls it with maxBoxes=20, overlapThresh=0.
+ * out_boxes: double[(max_boxes+1)*7], out_probs: double[max_boxes+1], out_count: device int32. */
+size_t lisec_rpn_to_region_workspace_bytes(const lisec_rpn_cfg* cfg, int max_boxes);
+int lisec_rpn_to_region(const lisec_rpn_cfg* cfg, const float* cls, int cls_stride, const float* reg,
+                        int reg_stride, double overlap_thresh, int max_boxes, void* workspace,
+                        size_t workspace_bytes, double* out_boxes, double* out_probs, int32_t* out_count,
+                        lisec_stream_t stream);
+
+/* preprocessLabels up to the class/regress maps before balancing (serialize_data.py:194-307).
+ * fixed_boxes: device double[n_boxes*7], ALREADY scaled by fixBoxScaling (:181-191).
+ * valid/overlap: double[outX*outY*2], out_regress: double[outX*outY*14] (all overwritten), indexed with the
+ * reference's wrap-around of negative voxel indices. */
+size_t lisec_rpn_labels_workspace_bytes(int n_boxes);
+int lisec_rpn_labels(const lisec_rpn_cfg* cfg, const double* fixed_boxes, int n_boxes, double iou_lo, double iou_hi,
+                     void* workspace, size_t workspace_bytes, double* valid, double* overlap, double* out_regress,
+                     lisec_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

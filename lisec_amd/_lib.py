@@ -26,6 +26,11 @@ class VfeGrads(Structure):
     _fields_ = [("kernel", c_void_p * 3), ("gamma", c_void_p * 3), ("beta", c_void_p * 3)]
 
 
+class RpnCfg(Structure):
+    _fields_ = [("outX", c_int), ("outY", c_int), ("vx", c_double), ("vy", c_double),
+                ("anchors", (c_double * 4) * 2)]
+
+
 class PackDesc(Structure):
     _fields_ = [("src", c_void_p), ("dst", c_void_p), ("tap_stride", ctypes.c_longlong),
                 ("k_stride", ctypes.c_longlong), ("n_stride", ctypes.c_longlong), ("start", ctypes.c_longlong),
@@ -60,6 +65,14 @@ def _declare(lib):
     lib.lisec_vfe_workspace_bytes.restype = c_size_t
     lib.lisec_vfe_workspace_bytes.argtypes = []
     LL = ctypes.c_longlong
+    lib.lisec_rpn_to_region_workspace_bytes.restype = c_size_t
+    lib.lisec_rpn_to_region_workspace_bytes.argtypes = [POINTER(RpnCfg), c_int]
+    lib.lisec_rpn_to_region.restype = c_int
+    lib.lisec_rpn_to_region.argtypes = [POINTER(RpnCfg), P, c_int, P, c_int, c_double, c_int, P, c_size_t, P, P, P, P]
+    lib.lisec_rpn_labels_workspace_bytes.restype = c_size_t
+    lib.lisec_rpn_labels_workspace_bytes.argtypes = [c_int]
+    lib.lisec_rpn_labels.restype = c_int
+    lib.lisec_rpn_labels.argtypes = [POINTER(RpnCfg), P, c_int, c_double, c_double, P, c_size_t, P, P, P, P]
     lib.lisec_lidar_transform.restype = c_int
     lib.lisec_lidar_transform.argtypes = [P, c_int, c_int, POINTER(c_double), POINTER(c_double), P, P]
     lib.lisec_vfe_grid_from_saved.restype = c_int

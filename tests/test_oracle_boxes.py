@@ -1,0 +1,78 @@
+"""Box-geometry oracle: rotated-rectangle IoU against analytic cases and an independent Monte-Carlo
+estimate (shapely, which the reference delegates to, is absent: serialize_data.py:138-146)."""
+import math
+
+import numpy as np
+
+from oracle import boxes_ref as B
+
+
+def test_axis_aligned_known_answers():
+    a = [0, 0, 1, 2.0, 4.0, 1.0, 0.0]          # l=2 along y?  corners: width along x (w=4), length along y (l=2)
+    c = B.box_corners(a)
+    xs, ys = [p[0] for p in c], [p[1] for p in c]
+    assert math.isclose(max(xs) - min(xs), 4.0) and math.isclose(max(ys) - min(ys), 2.0)
+    b = [1.0, 0.5, 1, 2.0, 4.0, 1.0, 0.0]
+    area = B.convex_intersection_area(B.box_corners(a), B.box_corners(b))
+    assert math.isclose(area, 3.0 * 1.5, rel_tol=1e-12)
+    # z: full height used as half extent, not clamped (serialize_data.py:144-146)
+    inter = 4.5 * (min(1 + 1, 1 + 1) - max(1 - 1, 1 - 1))
+    assert math.isclose(B.calculate_iou(a, b), inter / (8 + 8 - inter), rel_tol=1e-12)
+    far = [50.0, 50.0, 1, 2.0, 4.0, 1.0, 0.3]
+    assert B.calculate_iou(a, far) == 0.0
+    hi = [0.2, 0.1, 9.0, 2.0, 4.0, 1.0, 0.1]     # no z overlap -> NEGATIVE iou (quirk kept)
+    assert B.calculate_iou(a, hi) < 0
+    assert math.isclose(B.convex_intersection_area(B.box_corners(a), B.box_corners(a)), 8.0, rel_tol=1e-12)
+
+
+def test_rotated_pairs_vs_monte_carlo():
+    rng = np.random.default_rng(0)
+    for _ in range(25):
+        a = [rng.uniform(-1, 1), rng.uniform(-1, 1), 1, rng.uniform(1, 4), rng.uniform(1, 4), 1.5, rng.uniform(-3.2, 3.2)]
+        b = [rng.uniform(-1, 1), rng.uniform(-1, 1), 1, rng.uniform(1, 4), rng.uniform(1, 4), 1.5, rng.uniform(-3.2, 3.2)]
+        area = B.convex_intersection_area(B.box_corners(a), B.box_corners(b))
+        pts = rng.uniform(-5, 5, (400000, 2))
+
+        def inside(box):
+            th = box[6]
+            u = np.array([math.cos(th), -math.sin(th)])      # width axis, v = length axis
+            v = np.array([math.sin(th), math.cos(th)])
+            d = pts - np.array(box[:2])
+            return (np.abs(d @ u) <= box[4] / 2) & (np.abs(d @ v) <= box[3] / 2)
+        mc = (inside(a) & inside(b)).mean() * 100.0
+        assert abs(area - mc) < 0.25, (area, mc)     # MC sigma ~ 0.03
+
+
+def test_labels_small_scene_and_decode_nms_roundtrip():
+    # two cars; targets: class in {0,1,2}, a positive anchor exists for each box and carries its regression
+    data = np.array([[10.3, -20.2, 0.9, 4.2, 1.9, 1.6, 0.05], [-30.0, 12.0, 1.1, 4.6, 2.0, 1.5, 1.5]])
+    cls, reg = B.preprocess_labels(data, seed=1)
+    assert cls.shape == (100, 200, 2) and reg.shape == (100, 200, 14)
+    assert set(np.unique(cls)) <= {0.0, 1.0, 2.0}
+    pos = np.argwhere(cls == 2)
+    assert 2 <= len(pos) <= 128
+    assert (cls >= 1).sum() <= 256                      # balancing (:310-325)
+    # wrap-around layout (:284-294): a box at x>0 lands at non-negative x index, x<0 at index >= 50
+    assert any(p[0] < 50 for p in pos) and any(p[0] >= 50 for p in pos)
+    # regression channels of a positive anchor: t + 1 (outRegress + repeat(overlap), :335-336)
+    p0 = pos[0]
+    t = reg[p0[0], p0[1], p0[2] * 7:p0[2] * 7 + 7] - 1.0
+    xV = p0[0] if p0[0] < 50 else p0[0] - 100
+    yV = p0[1] if p0[1] < 100 else p0[1] - 200
+    a = [1.6, 3.9, 1.56, 0.0 if p0[2] == 0 else math.pi / 2]
+    bx = t[0] * a[0] + (xV + 0.5)
+    by = t[1] * a[1] + (0.5 * yV + 0.25)
+    scaled = data * np.array([0.5, 0.5, 1, 0.5, 0.5, 1, 1])
+    assert min(np.hypot(scaled[:, 0] - bx, scaled[:, 1] - by)) < 1e-9
+    # decode + NMS on a synthetic RPN output
+    rng = np.random.default_rng(3)
+    prob = rng.uniform(0, 0.1, (100, 200, 2))
+    regress = rng.normal(0, 0.05, (100, 200, 14))
+    prob[40, 100, 0] = 0.99
+    prob[41, 100, 0] = 0.98                             # overlaps the first -> suppressed
+    prob[70, 30, 1] = 0.97
+    boxes = B.decode_boxes(regress)
+    probs = prob.transpose(2, 0, 1).reshape(-1)
+    pick = B.nms(boxes, probs, overlapThresh=0.0, maxBoxes=20)
+    assert len(pick) == 21 and pick[0] == 40 * 200 + 100 and pick[1] == 20000 + 70 * 200 + 30
+    assert (41 * 200 + 100) not in pick
