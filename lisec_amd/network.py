@@ -276,7 +276,8 @@ class LisecNet:
         M = self.Ho * self.Wo
         sample = self.vfe._sample
         first = self.layers[0]["conv"]
-        need = ops.wgrad_workspace_bytes(self.dgeom[first.name], sample.cap)
+        rcap = max(sample.cap, 1)                 # an empty sweep still needs a non-zero row-list capacity
+        need = ops.wgrad_workspace_bytes(self.dgeom[first.name], rcap)
         if need > self.wgrad_ws.numel() or self.dout_rows is None or self.dout_rows.shape[0] < sample.cap + 1:
             torch.cuda.synchronize()               # (re)size scratch that depends on the cloud's capacity
             if need > self.wgrad_ws.numel():
@@ -346,7 +347,7 @@ class LisecNet:
                 if L["src"] == "grid":
                     # the grid is a constant on the empty cells + V voxel rows: both gradients reduce to V-row
                     # contractions plus sums of dy over boundary-trimmed boxes (exact; csrc/sparse_grid.hip)
-                    rows = (sample.coords, sample.info, sample.cap)
+                    rows = (sample.coords, sample.info, rcap)
                     dg = self.dgeom[c.name]
                     dW = p.grad_view(G, c.wname)
                     ops.tap_sums(c.g, d[n + ".z"], self.mid1_S, self.tapsum_ws)

@@ -246,3 +246,45 @@ def test_full_lyft_grid_forward_and_training_step_vs_oracle():
         assert err <= tol, f"grad {name}: err {err:.3e} tol {tol:.3e} (max ref {np.abs(ref).max():.3e})"
         worst = max(worst, err / np.abs(ref).max())
     assert worst < 0.1
+
+
+def test_lyft_grid_r200k_cloud_and_empty_cloud():
+    """A Lyft-size sweep (n = 200 000, crowded voxels well beyond 35 points, model_training.py:116) and the
+    degenerate empty sweep: inference maps vs the hybrid oracle, and a training step that stays finite."""
+    from conftest import LYFT
+    from lisec_amd.network import LisecNet
+    from lisec_amd.params import ParamStore
+    from lisec_amd.voxelizer import Voxelizer
+    from oracle import model_ref as M
+
+    rng = np.random.default_rng(9)
+    n = 200_000
+    az = rng.uniform(0, 2 * np.pi, n)
+    r = 2.0 + 68.0 * rng.uniform(0, 1, n) ** 2
+    pts = np.stack([r * np.cos(az), r * np.sin(az), rng.uniform(-0.2, 2.2, n)], 1).astype(np.float32)
+    op = M.glorot_params(seed=78, randomize_bn=True)
+    dev = torch.device("cuda")
+    net = LisecNet(200, 400, 8, 35, params=ParamStore(dev, init=op))
+    vox = Voxelizer(**LYFT)
+    sample = vox(pts)
+    assert sample.host_info()["max_count"] > 35
+    cls, reg = net.forward(sample, training=False)
+    cls_r, reg_r, _, _ = _hybrid_oracle_lyft(op, pts, training=False)
+    close(cls.cpu().numpy(), cls_r.numpy(), what="class map, R200k")
+    close(reg.cpu().numpy(), reg_r.numpy(), what="regression map, R200k")
+    y_cls = torch.zeros(100, 200, 2, device=dev)
+    y_reg = torch.zeros(100, 200, 14, device=dev)
+    lo = net.train_step(sample, y_cls, y_reg)
+    torch.cuda.synchronize()
+    assert torch.isfinite(lo).all() and torch.isfinite(net.grad).all() and torch.isfinite(net.params.theta).all()
+
+    # empty sweep: every cell is "empty", the network output is position-class constant and finite
+    net2 = LisecNet(200, 400, 8, 35, params=ParamStore(dev, init=op))
+    empty = vox(np.zeros((0, 3), np.float32))
+    cls0, reg0 = net2.forward(empty, training=False)
+    cls0_r, reg0_r, _, _ = _hybrid_oracle_lyft(op, np.zeros((0, 3), np.float32), training=False)
+    close(cls0.cpu().numpy(), cls0_r.numpy(), what="class map, empty sweep")
+    close(reg0.cpu().numpy(), reg0_r.numpy(), what="regression map, empty sweep")
+    lo = net2.train_step(empty, y_cls, y_reg)
+    torch.cuda.synchronize()
+    assert torch.isfinite(lo).all() and torch.isfinite(net2.grad).all()
