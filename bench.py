@@ -39,6 +39,14 @@ def u20k_cloud(seed, n=20000):
     return p.astype(np.float32)
 
 
+def r200k_cloud(seed, n=200000):
+    """Lyft-like sweep (SURVEY 8d 'Cloud R200k'): dense near the sensor, voxels far beyond 35 points."""
+    rng = np.random.default_rng(seed)
+    az = rng.uniform(0, 2 * np.pi, n)
+    r = 2.0 + 68.0 * rng.uniform(0, 1, n) ** 2
+    return np.stack([r * np.cos(az), r * np.sin(az), rng.uniform(-0.2, 2.2, n)], 1).astype(np.float32)
+
+
 def synthetic_targets(seed, Ho, Wo):
     """cls in {0,1,2} with 256 valid anchors, reg ~ N(0,1) on positives."""
     rng = np.random.default_rng(1000 + seed)
@@ -105,6 +113,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cloud", choices=["u20k", "r200k"], default="u20k",
+                    help="u20k: the headline workload (BASELINE configs 2-4); r200k: a Lyft-size sweep")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -126,7 +136,8 @@ def main():
     net = LisecNet(Constants.nx, Constants.ny, Constants.nz, Constants.maxPoints, device=dev)
     vox = Voxelizer(Constants.voxelx, Constants.voxely, Constants.voxelz, Constants.maxPoints,
                     Constants.nx // 2, Constants.ny // 2, Constants.nz, device=dev)
-    pts = torch.from_numpy(u20k_cloud(rank)).to(dev)
+    cloud = u20k_cloud(rank) if args.cloud == "u20k" else r200k_cloud(rank)
+    pts = torch.from_numpy(cloud).to(dev)
     ycls, yreg = synthetic_targets(rank, net.Ho, net.Wo)
     ycls, yreg = torch.from_numpy(ycls).to(dev), torch.from_numpy(yreg).to(dev)
     if dp is not None:
@@ -183,7 +194,7 @@ def main():
             net.vfe.forward(sample, True, out=net.act["grid"])
         ms_v = event_time_ms(run_vfe, 20)
         hi = sample.host_info()
-        vfe_bytes = 12.0 * 20000 + 24.0 * hi["rows"] + 4.0 * 64 * net.D * net.H * net.W
+        vfe_bytes = 12.0 * len(cloud) + 24.0 * hi["rows"] + 4.0 * 64 * net.D * net.H * net.W
         ms_g = event_time_ms(lambda: net.vfe.rewrite_grid(net.act["grid"]), 50)
         grid_bytes = 4.0 * 64 * net.D * net.H * net.W
         gbs = grid_bytes / (ms_g * 1e-3) / 1e9
@@ -201,9 +212,9 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "Lyft grid 8x200x400x35, U20k synthetic cloud, 1 sample/GPU/step, "
+            "config": {"workload": f"Lyft grid 8x200x400x35, {args.cloud.upper()} synthetic cloud, 1 sample/GPU/step, "
                                    "voxelise+VFE+3xConv3D+RPN fwd+bwd, MSE+MSE, SGD-Nesterov",
-                       "global_batch": world, "parallelism": f"dp{world}", "points_per_sample": 20000,
+                       "global_batch": world, "parallelism": f"dp{world}", "points_per_sample": int(len(cloud)),
                        "voxels": hi["V"], "final_loss": loss_val},
             "roofline": roofline, "roofline_vfe": roofline_vfe,
         }
