@@ -199,6 +199,160 @@ k_wgrad(ConvGeom g, const float* __restrict__ in, const float* __restrict__ in_b
     }
 }
 
+
+// ---- halo variant: stride-1 (along w) 3-tap convolutions, dense positions -------------------------------------
+// A tile is a run of up to 128 consecutive w' inside ONE output line (d',h'); for the workgroup's (kd,kh) the
+// three kw taps read the same source line shifted by one position, so the source rows w0-pw .. w0-pw+len+1 are
+// staged ONCE (zero outside the map) and tap kw reads LDS rows j+kw: half the global->LDS traffic of the generic
+// kernel, no per-row address arithmetic, and 3x longer MFMA runs between barriers.  The contraction runs over the
+// rows, so a short tail tile (W' = 400 = 3*128 + 16) only shortens the loop.
+constexpr int HALO_ROWS = BMW + 2;
+
+template <bool XF>
+__global__ void __launch_bounds__(kThreads)
+k_wgrad_halo(ConvGeom g, const float* __restrict__ in, const float* __restrict__ in_bn, int flags,
+             const float* __restrict__ dy, int nsplit, int tiles_per_split, float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sA = smem;                                  // [HALO_ROWS (+pad to 8)][64]
+    float* sD = smem + (HALO_ROWS + 6) * BC;           // [128][64]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ngroups = g.KD * g.KH;
+    const int split = blockIdx.x / ngroups, group = blockIdx.x - split * ngroups;
+    const int kd = group / g.KH, kh = group - kd * g.KH;
+    const int c0 = blockIdx.y * BC, n0 = blockIdx.z * BC;
+    const int tpl = (g.Wo + BMW - 1) / BMW;            // tiles per output line
+    const int ntiles = g.Do * g.Ho * tpl;
+    const int t_begin = split * tiles_per_split;
+    const int t_end = t_begin + tiles_per_split < ntiles ? t_begin + tiles_per_split : ntiles;
+
+    const int piece = tid & 15, rsub = tid >> 4;       // 16 rows x 16 pieces per pass
+    const int cA = c0 + piece * 4, cD = n0 + piece * 4;
+    const bool cokA = cA < g.Cin, cokD = cD < g.Cout;
+    float4 tsc = make_float4(1, 1, 1, 1), tsh = make_float4(0, 0, 0, 0);
+    if (XF && in_bn && cokA) {
+        tsc = *reinterpret_cast<const float4*>(in_bn + cA);
+        tsh = *reinterpret_cast<const float4*>(in_bn + g.Cin + cA);
+    }
+    const float relu_lo = (flags & LISEC_CONV_IN_RELU) ? 0.f : -INFINITY;
+
+    f32x16 acc0 = {0}, acc1 = {0}, acc2 = {0};
+    float4 ra[9], rd[8];
+    unsigned amask = 0;
+    int cur_len = 0, nxt_len = 0;
+
+    // tile -> (output line, w0, len, source line offset or -1)
+    auto tile_info = [&](int tile, int& w0, int& len, long long& src_line, long long& dy_line) -> bool {
+        const int line = tile / tpl;
+        w0 = (tile - line * tpl) * BMW;
+        len = g.Wo - w0 < BMW ? g.Wo - w0 : BMW;
+        const int d = line / g.Ho, h = line - d * g.Ho;
+        const int sd = (d << g.ls_d) - g.pd + kd, sh = (h << g.ls_h) - g.ph + kh;
+        dy_line = (long long)line * g.Wo;
+        src_line = ((long long)sd * g.Hi + sh) * g.Wi;
+        return sd >= 0 && sd < g.Di && sh >= 0 && sh < g.Hi;
+    };
+    auto next_live = [&](int tile) -> int {
+        int w0, len; long long a, b;
+        while (tile < t_end && !tile_info(tile, w0, len, a, b)) ++tile;
+        return tile;
+    };
+    auto issue = [&](int tile) {
+        int w0, len; long long src_line, dy_line;
+        (void)tile_info(tile, w0, len, src_line, dy_line);
+        nxt_len = len;
+        amask = 0;
+#pragma unroll
+        for (int p = 0; p < 9; ++p) {                  // halo rows: slot s <-> source w = w0 - pw + s
+            const int s_ = p * 16 + rsub;
+            const int sw = w0 - g.pw + s_;
+            const bool ok = cokA && s_ < len + 2 && sw >= 0 && sw < g.Wi;
+            const long long off = ok ? (src_line + sw) * g.in_stride + cA : 0;
+            ra[p] = *reinterpret_cast<const float4*>(in + off);
+            amask |= ok ? (1u << p) : 0u;
+        }
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const int j = p * 16 + rsub;
+            const bool ok = cokD && j < len;
+            const long long off = ok ? (dy_line + w0 + j) * g.out_stride + cD : 0;
+            const float4 v = *reinterpret_cast<const float4*>(dy + off);
+            rd[p] = ok ? v : make_float4(0, 0, 0, 0);
+        }
+    };
+    auto store = [&]() {
+#pragma unroll
+        for (int p = 0; p < 9; ++p) {
+            const int s_ = p * 16 + rsub;
+            if (s_ < HALO_ROWS + 6) {
+                float4 v = ra[p];
+                const bool ok = (amask >> p) & 1;
+                if (XF) {
+                    v.x = ok ? fmaxf(fmaf(v.x, tsc.x, tsh.x), relu_lo) : 0.f;
+                    v.y = ok ? fmaxf(fmaf(v.y, tsc.y, tsh.y), relu_lo) : 0.f;
+                    v.z = ok ? fmaxf(fmaf(v.z, tsc.z, tsh.z), relu_lo) : 0.f;
+                    v.w = ok ? fmaxf(fmaf(v.w, tsc.w, tsh.w), relu_lo) : 0.f;
+                } else {
+                    v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+                }
+                *reinterpret_cast<float4*>(sA + s_ * BC + piece * 4) = v;
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < 8; ++p)
+            *reinterpret_cast<float4*>(sD + (p * 16 + rsub) * BC + piece * 4) = rd[p];
+        cur_len = nxt_len;
+    };
+
+    const float* aCol = sA + (4 * (lane >> 5)) * BC + (wave >> 1) * 32 + (lane & 31);
+    const float* dCol = sD + (4 * (lane >> 5)) * BC + (wave & 1) * 32 + (lane & 31);
+
+    int tile = next_live(t_begin);
+    if (tile < t_end) { issue(tile); store(); }
+    __syncthreads();
+    while (tile < t_end) {
+        const int ntile = next_live(tile + 1);
+        if (ntile < t_end) issue(ntile);
+        const int nk = (cur_len + 7) >> 3;             // rows beyond len are zero in sD: whole 8-row chunks only
+        for (int kk = 0; kk < nk; ++kk) {
+            const float* ap = aCol + kk * 8 * BC;
+            const float* dp = dCol + kk * 8 * BC;
+            const float b0 = dp[0], b1 = dp[BC], b2 = dp[2 * BC], b3 = dp[3 * BC];
+            const float a0 = ap[0], a1 = ap[BC], a2 = ap[2 * BC], a3 = ap[3 * BC], a4 = ap[4 * BC], a5 = ap[5 * BC];
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc1, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b0, acc2, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b1, acc1, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, b1, acc2, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b2, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, b2, acc1, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4, b2, acc2, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, b3, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4, b3, acc1, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a5, b3, acc2, 0, 0, 0);
+        }
+        __syncthreads();
+        if (ntile < t_end) store();
+        __syncthreads();
+        tile = ntile;
+    }
+
+    const int ntaps = g.KD * g.KH * g.KW;
+    const int tap0 = (kd * g.KH + kh) * g.KW;
+    const int n = n0 + (wave & 1) * 32 + (lane & 31);
+#pragma unroll
+    for (int tt = 0; tt < 3; ++tt) {
+        float* base = partial + ((size_t)split * ntaps + tap0 + tt) * g.Cin * g.Cout;
+        const f32x16& acc = tt == 0 ? acc0 : (tt == 1 ? acc1 : acc2);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int c = c0 + (wave >> 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (c < g.Cin && n < g.Cout) base[(size_t)c * g.Cout + n] = acc[r];
+        }
+    }
+}
+
 // dW = sum over splits (index order).  transpose: write [tap][n][c] (Conv2DTranspose kernels are (kh,kw,out,in)).
 // One thread per float4 of the kernel; the S slab loads of a thread are independent (batched 8 at a time) and
 // added in slab order, so the result does not depend on the launch geometry.
@@ -238,15 +392,23 @@ k_wgrad_reduce(const float* __restrict__ partial, int nsplit, int ntaps, int Cin
 
 struct WgradPlan {
     int TG, ngroups, nsplit, tiles_per_split, ntiles;
+    bool halo;
     size_t ws_bytes;
 };
 
-WgradPlan make_plan(const ConvGeom& g) {
+WgradPlan make_plan(const ConvGeom& g, int mode = 0, bool dy_xf = false) {
     WgradPlan p;
     p.TG = g.KW <= 4 ? g.KW : 1;
     if (g.KW % p.TG) p.TG = 1;
     p.ngroups = g.KD * g.KH * (g.KW / p.TG);
     p.ntiles = cdiv(g.M, BMW);
+    // 3 taps along w at stride 1 over every position of the map: the halo kernel (tiles follow the output lines)
+    p.halo = mode == 0 && g.KW == 3 && g.ls_w == 0 && !g.row_coords && !dy_xf && g.Wo >= 8;
+    if (p.halo) {
+        p.TG = 3;
+        p.ngroups = g.KD * g.KH;
+        p.ntiles = g.Do * g.Ho * cdiv(g.Wo, BMW);
+    }
     int cb = cdiv(g.Cin, BC), nb = cdiv(g.Cout, BC);
     int base = p.ngroups * cb * nb;
     int want = cdiv(1536, base);                // ~3 rounds of the 512 resident workgroups: the (kd) groups
@@ -286,7 +448,8 @@ extern "C" size_t lisec_conv_wgrad_workspace_bytes(const lisec_conv_geom* c, int
     ConvGeom g;
     if (conv_geom_check(c, &g)) return 0;
     if (row_capacity > 0) g.M = row_capacity;
-    return make_plan(g).ws_bytes;
+    const size_t a = make_plan(g, c->mode, false).ws_bytes, b = make_plan(g, 1, true).ws_bytes;
+    return a > b ? a : b;
 }
 
 extern "C" int lisec_conv_wgrad(const lisec_conv_geom* c, const float* in, const float* in_bnstate, int flags,
@@ -302,15 +465,28 @@ extern "C" int lisec_conv_wgrad(const lisec_conv_geom* c, const float* in, const
     LISEC_CHECK_ARG(in && dy && workspace && dW, "NULL pointer");
     LISEC_CHECK_ARG(g.out_stride % 4 == 0 && g.Cout % 4 == 0, "dY channels/stride must be multiples of 4");
     LISEC_CHECK_ARG(((uintptr_t)in & 15) == 0 && ((uintptr_t)dy & 15) == 0, "in/dy must be 16-byte aligned");
-    WgradPlan p = make_plan(g);
+    WgradPlan p = make_plan(g, c->mode, dy_bnstate != nullptr || (flags & LISEC_CONV_DY_RELU));
     if (workspace_bytes < p.ws_bytes) {
         set_error("wgrad workspace too small: %zu < %zu", workspace_bytes, p.ws_bytes);
         return LISEC_ENOSPC;
     }
     hipStream_t st = static_cast<hipStream_t>(stream_);
     float* partial = static_cast<float*>(workspace);
-    int rc = c->mode == 0 ? launch_wgrad<0>(g, p, in, in_bnstate, flags, dy, dy_bnstate, partial, st)
+    int rc = 0;
+    if (p.halo) {
+        dim3 grid(p.nsplit * p.ngroups, cdiv(g.Cin, BC), cdiv(g.Cout, BC));
+        size_t lds = (size_t)((HALO_ROWS + 6) * BC + TILE_FLOATS) * sizeof(float);
+        if (in_bnstate || (flags & LISEC_CONV_IN_RELU))
+            hipLaunchKernelGGL(k_wgrad_halo<true>, grid, dim3(kThreads), lds, st, g, in, in_bnstate, flags, dy, p.nsplit,
+                               p.tiles_per_split, partial);
+        else
+            hipLaunchKernelGGL(k_wgrad_halo<false>, grid, dim3(kThreads), lds, st, g, in, in_bnstate, flags, dy, p.nsplit,
+                               p.tiles_per_split, partial);
+        LISEC_LAUNCH_CHECK();
+    } else {
+        rc = c->mode == 0 ? launch_wgrad<0>(g, p, in, in_bnstate, flags, dy, dy_bnstate, partial, st)
                           : launch_wgrad<1>(g, p, in, in_bnstate, flags, dy, dy_bnstate, partial, st);
+    }
     if (rc) return rc;
     const int ntaps = g.KD * g.KH * g.KW;
     long long per = (long long)ntaps * g.Cin * g.Cout;
