@@ -176,15 +176,17 @@ def main():
         c = mid1["conv"]
 
         def run_mid1():
+            # TAG_ROOFLINE: one un-sliced launch under its own symbol (k_igemm<0,false,1>), so the row of that
+            # symbol in the rocprofv3 --stats summary of this command is this layer alone
             ops.conv_forward(c.g, net.act["grid"], net.packed[c.name], net.act["mid1.y"],
-                             bias=net.params.view(c.bias), stats=net.parts)
+                             bias=net.params.view(c.bias), stats=net.parts, flags=ops.TAG_ROOFLINE)
         ms = event_time_ms(run_mid1, 20)
         # algorithmic FLOPs: 2 * positions * 27 taps * 64 * 64; depth-padding taps included
         flops = 2.0 * c.M * 27 * 64 * 64
         tf = flops / (ms * 1e-3) / 1e12
         # traffic: HBM bytes per launch from rocprofv3 PMC passes of this kernel (profiles/r01_pmc_summary.txt):
         # FETCH_SIZE 128 107 KiB (x2, the gfx950 correction for wide coalesced reads) + WRITE_SIZE 82 500 KiB
-        roofline = dict(bound="mfma", kernel="k_igemm<0,false> mid1 Conv3D 64->64 k3 s(2,1,1)", achieved=tf,
+        roofline = dict(bound="mfma", kernel="k_igemm<0,false,1> mid1 Conv3D 64->64 k3 s(2,1,1)", achieved=tf,
                         peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s", frac=tf / PEAK_F32_MFMA_TFLOPS,
                         traffic=(2 * 128107.0625 + 82500.0) * 1024, traffic_unit="bytes/launch (PMC, offline)",
                         us_per_launch=ms * 1e3, flops_per_launch=flops)

@@ -7,7 +7,7 @@ import torch
 from . import _lib
 from ._lib import ConvGeom
 
-IN_RELU, OUT_RELU, ACCUMULATE, DY_RELU = 1, 2, 4, 8
+IN_RELU, OUT_RELU, ACCUMULATE, DY_RELU, TAG_ROOFLINE = 1, 2, 4, 8, 32
 
 
 def geom(mode, in_dims, out_dims, kernel, stride, pad, cin, cout, in_stride=None, out_stride=None, ps=0,
