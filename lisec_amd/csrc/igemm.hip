@@ -154,11 +154,21 @@ k_igemm(ConvGeom g, const float* __restrict__ in, const float* __restrict__ wp,
     while (s < nsteps) {
         const int snext = advance_to(s + 1);
         if (snext < nsteps) issue_loads(snext);
+        // software-pipelined fragment reads: the ds_reads of chunk kc+1 are issued BEFORE the 8 MFMAs of chunk kc
+        // (sched_barrier pins that order; left alone hipcc reuses the fragment registers and issues the reads
+        // after the MFMAs, exposing ~100 cycles of LDS latency per 512 MFMA cycles)
+        float4 a = *reinterpret_cast<const float4*>(aRow);
+        float4 b0 = *reinterpret_cast<const float4*>(bCol);
+        float4 b1 = *reinterpret_cast<const float4*>(bCol + 32 * 4);
 #pragma unroll
         for (int kc = 0; kc < BK / 8; ++kc) {
-            const float4 a = *reinterpret_cast<const float4*>(aRow + kc * 8);
-            const float4 b0 = *reinterpret_cast<const float4*>(bCol + kc * 2 * BN * 4);
-            const float4 b1 = *reinterpret_cast<const float4*>(bCol + kc * 2 * BN * 4 + 32 * 4);
+            float4 an = a, b0n = b0, b1n = b1;
+            if (kc + 1 < BK / 8) {
+                an = *reinterpret_cast<const float4*>(aRow + (kc + 1) * 8);
+                b0n = *reinterpret_cast<const float4*>(bCol + (kc + 1) * 2 * BN * 4);
+                b1n = *reinterpret_cast<const float4*>(bCol + (kc + 1) * 2 * BN * 4 + 32 * 4);
+            }
+            __builtin_amdgcn_sched_barrier(0);                        // reads of chunk kc+1 stay above ...
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1.x, acc1, 0, 0, 0);
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b0.y, acc0, 0, 0, 0);
@@ -167,6 +177,8 @@ k_igemm(ConvGeom g, const float* __restrict__ in, const float* __restrict__ wp,
             acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b1.z, acc1, 0, 0, 0);
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b0.w, acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b1.w, acc1, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);                        // ... the 8 MFMAs of chunk kc
+            a = an; b0 = b0n; b1 = b1n;
         }
         __syncthreads();
         if (snext < nsteps) store_lds();
