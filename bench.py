@@ -123,8 +123,11 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run for --gpus > 1")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # LISEC_BENCH_DEVICE pins every rank to one device index (rehearsing the N > 1 code path on a one-GPU box
+    # together with LISEC_DIST_BACKEND=gloo); the driver's multi-GPU run uses cuda:LOCAL_RANK and RCCL
+    dev_index = int(os.environ.get("LISEC_BENCH_DEVICE", local_rank))
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
 
     from lisec_amd import Constants, ops
     from lisec_amd.network import LisecNet
