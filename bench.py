@@ -146,11 +146,7 @@ def main():
     if dp is not None:
         dp.broadcast_(net.params.theta)
         dp.broadcast_(net.params.state)
-    allreduce = dp.average_ if dp is not None else None
-    if dp is not None and dp.world == 1 and os.environ.get("LISEC_FORCE_DP") == "1":
-        import torch.distributed as dist
-        allreduce = lambda g: dist.all_reduce(g)          # noqa: E731  (world 1: identity, but a real RCCL call)
-
+    allreduce = dp.bucketed() if dp is not None else None
     def step():
         sample = vox(pts)
         return net.train_step(sample, ycls, yreg, loss="mse", allreduce=allreduce)

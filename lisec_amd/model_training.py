@@ -300,9 +300,13 @@ class Model:
                 yc = torch.from_numpy(np.ascontiguousarray(ycls[i])).to(dev)
                 yr = torch.from_numpy(np.ascontiguousarray(yreg[i])).to(dev)
                 self.net.forward(samples[i], training=True)
-                self.net.backward(yc, yr, loss=self.loss)
                 if self.dp is not None:
-                    self.dp.average_(self.net.grad)
+                    avg = self.dp.bucketed()
+                    self.net.backward(yc, yr, loss=self.loss,
+                                      rpn_grads_ready=lambda lo, hi, avg=avg: avg.start_tail(self.net.grad, lo, hi))
+                    avg.finish(self.net.grad)
+                else:
+                    self.net.backward(yc, yr, loss=self.loss)
                 self.net.apply_gradients(lr=o.lr, decay=o.decay, momentum=o.momentum)
                 tot += self.net.loss_out.cpu().numpy()
                 if verbose:

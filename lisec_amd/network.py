@@ -13,6 +13,8 @@ model_training.py:299):
     up_b  : concat[..., 256b:256(b+1)] = deconv(relu(bn(y_{b,q})))
     head  : (M,16) = concat @ [W_cls | W_reg] + bias     (cls = [:, :2], reg = [:, 2:])
 """
+import os
+
 import numpy as np
 import torch
 
@@ -246,7 +248,10 @@ class LisecNet:
         self.wgrad_ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         # weight gradients are leaves of the backward graph: they run on a second HIP stream next to the
         # BN-backward / data-gradient chain (the RPN layers are too small to fill 256 CUs on their own)
-        self.side = torch.cuda.Stream(device=dev)
+        # ROCm multiplexes same-priority streams onto a few hardware queues round-robin, so a plain second stream
+        # can land on the main stream's queue (it does once RCCL has made its own streams) and then nothing
+        # overlaps; a different priority level always gets its own hardware queue.
+        self.side = torch.cuda.Stream(device=dev, priority=int(os.environ.get("LISEC_SIDE_PRIORITY", "-1")))
         self._packed_t_version = -1
         self._train_ready = True
 
@@ -267,9 +272,12 @@ class LisecNet:
         self._pack_table_t.run()
         self._packed_t_version = self.params_version
 
-    def backward(self, y_cls, y_reg, loss="mse", grad_scale=1.0):
+    def backward(self, y_cls, y_reg, loss="mse", grad_scale=1.0, rpn_grads_ready=None):
         """y_cls (Ho,Wo,2), y_reg (Ho,Wo,14): float32 device tensors.  Fills self.grad (layout of theta)
-        and self.loss_out = [total, class, regression].  Must follow forward(training=True)."""
+        and self.loss_out = [total, class, regression].  Must follow forward(training=True).
+        rpn_grads_ready(lo, hi): optional hook, called (inside the second stream's context) as soon as the
+        gradients of every RPN/head variable -- theta[lo:hi], 94 % of the parameters -- are final, while the
+        middle layers and the VFE are still being differentiated: data parallelism starts its all-reduce there."""
         self._prepare_training()
         self._pack_all_t()
         p, a, d, G = self.params, self.act, self.dact, self.grad
@@ -328,6 +336,7 @@ class LisecNet:
             elif L["kind"] == "conv":
                 dst = L["dst"]
                 C = c.g.Cout
+                is_first_rpn = L["name"] == "rpn1.conv0"
                 ops.bn_backward(d[dst], C, a[dst], self.bnstate[c.bn], c.M, C, True,
                                 p.grad_view(G, c.bn + ".gamma"), p.grad_view(G, c.bn + ".beta"), d[dst])
                 # the bias of a conv feeding a training-mode BN has gradient sum(dy) == 0 identically (BN removes
@@ -335,6 +344,9 @@ class LisecNet:
                 on_side(lambda L=L, c=c, dst=dst: ops.conv_wgrad(
                     c.g, a[L["src"]], d[dst], p.grad_view(G, c.wname), self.wgrad_ws,
                     in_bn=self.bnstate[c.in_bn] if c.in_bn else None, flags=ops.IN_RELU if c.in_relu else 0))
+                if is_first_rpn and rpn_grads_ready is not None:
+                    lo = p.offsets["rpn1.conv0.kernel"][1]
+                    on_side(lambda lo=lo: rpn_grads_ready(lo, p.n_theta))
                 dgrad_into(c, d[dst], L["src"])
             else:   # mid layer: conv3d -> BN -> Dense(relu)
                 n, dn = L["name"], L["dense"]
@@ -382,8 +394,13 @@ class LisecNet:
         """One fit() step at batch_size=1: forward (batch statistics) + backward + SGD-Nesterov.
         allreduce: optional callable(grad) that averages the flat gradient across data-parallel ranks."""
         self.forward(sample, training=True)
-        self.backward(y_cls, y_reg, loss=loss)
-        if allreduce is not None:
-            allreduce(self.grad)
+        if allreduce is not None and hasattr(allreduce, "start_tail"):
+            # two buckets: the RPN + head gradients (the tail of theta) are reduced under the rest of the backward
+            self.backward(y_cls, y_reg, loss=loss, rpn_grads_ready=lambda lo, hi: allreduce.start_tail(self.grad, lo, hi))
+            allreduce.finish(self.grad)
+        else:
+            self.backward(y_cls, y_reg, loss=loss)
+            if allreduce is not None:
+                allreduce(self.grad)
         self.apply_gradients()
         return self.loss_out

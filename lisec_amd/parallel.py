@@ -54,6 +54,12 @@ class DataParallel:
             tensor.mul_(1.0 / self.world)
         return tensor
 
+    def bucketed(self):
+        """Gradient averaging in two buckets for LisecNet.train_step: start_tail() launches the all-reduce of the
+        RPN/head gradients asynchronously (from the stream that produced them), finish() reduces the small head of
+        the buffer, waits for the tail and scales everything by 1/world."""
+        return _BucketedAverage(self)
+
     def max_float(self, x):
         t = torch.tensor([x], dtype=torch.float64, device=self.device if self.on_gpu else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -68,3 +74,34 @@ class DataParallel:
     def close(self):
         if self._own_group and dist.is_initialized():
             dist.destroy_process_group()
+
+
+class _BucketedAverage:
+    def __init__(self, dp):
+        self.dp, self.work, self.lo = dp, None, 0
+        # LISEC_FORCE_DP=1: issue the collectives even with a single rank (rehearsal of the RCCL path)
+        self.active = dp.world > 1 or os.environ.get("LISEC_FORCE_DP") == "1"
+
+    def __call__(self, grad):                      # plain single-bucket fallback
+        return self.dp.average_(grad)
+
+    def start_tail(self, grad, lo, hi):
+        if not self.active:
+            return
+        self.lo = lo
+        self.work = dist.all_reduce(grad[lo:hi], op=dist.ReduceOp.SUM, async_op=True)
+
+    def finish(self, grad):
+        if not self.active:
+            return grad
+        if self.work is None:
+            return self.dp.average_(grad)
+        dist.all_reduce(grad[:self.lo], op=dist.ReduceOp.SUM)
+        self.work.wait()                           # the current stream waits for the tail bucket
+        self.work = None
+        if self.dp.on_gpu:
+            from . import ops
+            ops.scale_(grad, 1.0 / self.dp.world)
+        else:
+            grad.mul_(1.0 / self.dp.world)
+        return grad
