@@ -328,16 +328,27 @@ class Model:
         return [np.concatenate(probs), np.concatenate(regs)]
 
     def save(self, path):
-        """model.save(save_path) (model_training.py:302).  libhdf5/h5py are not part of this image: the
-        variables are written as a numpy .npz archive AT `path` (whatever its extension) with the layer-wise
-        names of lisec_amd.params.param_specs(); load_model reads it back.  Keras-HDF5 interchange is a
-        listed next step."""
+        """model.save(save_path) (model_training.py:302): a Keras-layout HDF5 file (model_config, model_weights/<layer>/
+        <layer>/<weight>:0 with Keras' automatic layer names, training_config and the SGD iteration count + momentum
+        accumulators under optimizer_weights), written by lisec_amd.hdf5_lite -- see lisec_amd/keras_h5.py.  A path
+        ending in .npz gets a plain numpy archive with the names of lisec_amd.params.param_specs() instead."""
         d = self.net.params.to_dict()
-        meta = dict(format="lisec_amd-npz-1", nx=self.nx, ny=self.ny, nz=self.nz, maxPoints=self.maxPoints,
-                    iterations=self.net.iterations)
         os.makedirs(os.path.dirname(os.path.abspath(path)) or ".", exist_ok=True)
-        with open(path, "wb") as f:
-            np.savez(f, __meta__=np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8), **d)
+        if str(path).endswith(".npz"):
+            meta = dict(format="lisec_amd-npz-1", nx=self.nx, ny=self.ny, nz=self.nz, maxPoints=self.maxPoints,
+                        iterations=self.net.iterations)
+            with open(path, "wb") as f:
+                np.savez(f, __meta__=np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8), **d)
+            return
+        from . import keras_h5
+        opt = vel = None
+        if self.optimizer is not None:
+            o = self.optimizer
+            opt = dict(lr=o.lr, decay=o.decay, momentum=o.momentum, nesterov=o.nesterov)
+            p = self.net.params
+            vel = {n: p.view(n, buf=self.net.velocity).detach().cpu().numpy() for n in p.trainable_names()}
+        keras_h5.save_model(path, d, self.nx, self.ny, self.nz, self.maxPoints, optimizer=opt,
+                            iterations=self.net.iterations, velocity=vel)
 
     def summary(self):
         n = self.net.params.n_trainable()
@@ -351,18 +362,32 @@ def createModel(nx, ny, nz, maxPoints):
 
 
 def load_model(path, custom_objects=None):
-    """load_model(model_path, custom_objects={'RepeatLayer':…, 'MaxPoolingVFELayer':…}) (:337-338)."""
+    """load_model(model_path, custom_objects={'RepeatLayer':…, 'MaxPoolingVFELayer':…}) (:337-338, Predict.py:51-52).
+    Reads Keras HDF5 files (the reference's own checkpoints or Model.save's) and the .npz variant.  Like Keras, a file
+    that carries a training_config comes back compiled, with the saved iteration count and momentum accumulators."""
     with open(path, "rb") as f:
         magic = f.read(8)
-    if magic[:4] == b"\x89HDF":
-        raise _lib.LisecError("Keras HDF5 files need h5py/libhdf5, which this image lacks; "
-                              "re-save the weights as .npz with the names of lisec_amd.params.param_specs()")
-    z = np.load(path, allow_pickle=False)
-    meta = json.loads(bytes(z["__meta__"]).decode())
     dev = _lib.require_gpu()
-    params = ParamStore(dev, init={k: z[k] for k in z.files if k != "__meta__"})
-    m = Model(meta["nx"], meta["ny"], meta["nz"], meta["maxPoints"], params=params)
-    m.net.iterations = int(meta.get("iterations", 0))
+    if magic[:4] != b"\x89HDF":
+        z = np.load(path, allow_pickle=False)
+        meta = json.loads(bytes(z["__meta__"]).decode())
+        params = ParamStore(dev, init={k: z[k] for k in z.files if k != "__meta__"})
+        m = Model(meta["nx"], meta["ny"], meta["nz"], meta["maxPoints"], params=params)
+        m.net.iterations = int(meta.get("iterations", 0))
+        return m
+    from . import keras_h5
+    ck = keras_h5.load_model(path)
+    m = Model(ck["nx"], ck["ny"], ck["nz"], ck["maxPoints"], params=ParamStore(dev, init=ck["params"]))
+    o = ck["optimizer"]
+    if o is not None and o.get("nesterov"):
+        m.compile(optimizer=optimizers.SGD(lr=o["lr"], decay=o["decay"], momentum=o["momentum"], nesterov=True),
+                  loss=['mse', 'mse'])
+        m.net.iterations = ck["iterations"]
+        if ck["velocity"] is not None:
+            p = m.net.params
+            for n in p.trainable_names():
+                if n in ck["velocity"]:
+                    p.view(n, buf=m.net.velocity).copy_(torch.from_numpy(np.ascontiguousarray(ck["velocity"][n])))
     return m
 
 

@@ -77,6 +77,25 @@ def test_train_save_load_predict_roundtrip(tmp_path, monkeypatch):
     assert np.array_equal(np.load(out2 / "sample0_label.npy"), prob)
     assert np.array_equal(np.load(out2 / "sample1_regress.npy"), reg)
 
+    # the checkpoint is a Keras-layout HDF5 file (model_training.py:302): it comes back compiled, with the SGD
+    # iteration count and momentum accumulators, so one more step from either copy is bit-identical
+    import torch
+    from lisec_amd import hdf5_lite
+    with open(save_path, "rb") as f:
+        assert f.read(8) == hdf5_lite.SIGNATURE
+    with hdf5_lite.File(save_path) as f:
+        assert len(f["model_weights"].attrs["layer_names"]) == 113
+        assert f["model_weights/conv3d/conv3d/kernel:0"].shape == (3, 3, 3, 64, 64)
+        assert int(f["optimizer_weights/SGD/iter:0"][()]) == 180
+    assert model2.optimizer is not None and model2.net.iterations == 180
+    assert torch.equal(model2.net.velocity, model.net.velocity)
+    assert torch.equal(model2.net.params.theta, model.net.params.theta)
+    assert torch.equal(model2.net.params.state, model.net.params.state)
+    npz_path = str(tmp_path / "models" / "weights.npz")
+    model.save(npz_path)
+    model3 = model_training.load_model(npz_path)
+    assert torch.equal(model3.net.params.theta, model.net.params.theta) and model3.optimizer is None
+
 
 def test_sparse_tensor_surface_and_dense_input():
     """VFE_preprocessing's result quacks like the reference's SparseTensor; a dense (n,D,H,W,T,6) array is
