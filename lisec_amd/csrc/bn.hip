@@ -4,25 +4,49 @@
 namespace lisec {
 namespace {
 
-// Deterministic parallel column sums of parts[nparts][ld] (double): a 1024-thread block owns 32
-// consecutive columns; 32 row groups stride over the parts, then a fixed-order LDS tree combines them.
-constexpr int kRedCols = 32, kRedRows = 32;
+// Deterministic parallel column sums of parts[nparts][ld] (double): a 1024-thread block owns 16
+// consecutive columns; 64 row groups stride over the parts (loads batched 8 deep, added in index order),
+// then a fixed-order LDS tree combines them.  column_sum2 sums columns `col` and `col + off` in one pass.
+constexpr int kRedCols = 16, kRedRows = 64, kRedBatch = 8;
 
-__device__ __forceinline__ double column_sum(const double* __restrict__ parts, int nparts, size_t ld, int col,
-                                             bool col_ok, double (*red)[kRedCols]) {
+__device__ __forceinline__ void column_sum2(const double* __restrict__ parts, int nparts, size_t ld, int col,
+                                            size_t off, bool two, bool col_ok, double (*red)[kRedCols],
+                                            double& r1, double& r2) {
     const int cx = threadIdx.x % kRedCols, ry = threadIdx.x / kRedCols;
-    double s = 0.0;
-    if (col_ok)
-        for (int b = ry; b < nparts; b += kRedRows) s += parts[(size_t)b * ld + col];
-    red[ry][cx] = s;
+    double s1 = 0.0, s2 = 0.0;
+    if (col_ok) {
+        const double* src = parts + col;
+        int b = ry;
+        for (; b + (kRedBatch - 1) * kRedRows < nparts; b += kRedBatch * kRedRows) {
+            double v[kRedBatch], w[kRedBatch];
+#pragma unroll
+            for (int u = 0; u < kRedBatch; ++u) {
+                const double* q = src + (size_t)(b + u * kRedRows) * ld;
+                v[u] = q[0];
+                w[u] = two ? q[off] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < kRedBatch; ++u) { s1 += v[u]; s2 += w[u]; }
+        }
+        for (; b < nparts; b += kRedRows) {
+            const double* q = src + (size_t)b * ld;
+            s1 += q[0];
+            if (two) s2 += q[off];
+        }
+    }
+    red[ry][cx] = s1;
+    red[kRedRows + ry][cx] = s2;
     __syncthreads();
     for (int o = kRedRows / 2; o > 0; o >>= 1) {
-        if (ry < o) red[ry][cx] += red[ry + o][cx];
+        if (ry < o) {
+            red[ry][cx] += red[ry + o][cx];
+            red[kRedRows + ry][cx] += red[kRedRows + ry + o][cx];
+        }
         __syncthreads();
     }
-    const double r = red[0][cx];
+    r1 = red[0][cx];
+    r2 = red[kRedRows][cx];
     __syncthreads();
-    return r;
 }
 
 __global__ void __launch_bounds__(1024)
@@ -30,11 +54,11 @@ k_bn_finalize(const double* __restrict__ parts, int nparts, int C, double N,
               const float* __restrict__ gamma, const float* __restrict__ beta,
               float* __restrict__ mmean, float* __restrict__ mvar, int unbiased,
               float* __restrict__ st) {
-    __shared__ double red[kRedRows][kRedCols];
+    __shared__ double red[2 * kRedRows][kRedCols];
     const int c = blockIdx.x * kRedCols + threadIdx.x % kRedCols;
     const bool ok = c < C;
-    const double s1 = column_sum(parts, nparts, (size_t)2 * C, c, ok, red);
-    const double s2 = column_sum(parts + C, nparts, (size_t)2 * C, c, ok, red);
+    double s1, s2;
+    column_sum2(parts, nparts, (size_t)2 * C, c, (size_t)C, true, ok, red, s1, s2);
     if (!ok || threadIdx.x >= kRedCols) return;
     double mean = s1 / N;
     double var = s2 / N - mean * mean;            // biased; fp64 so the cancellation is harmless
@@ -68,10 +92,11 @@ __global__ void k_bn_fold(const float* __restrict__ gamma, const float* __restri
 __global__ void __launch_bounds__(1024)
 k_reduce_parts(const double* __restrict__ parts, int nparts, int C, double scale,
                float* __restrict__ out_f, double* __restrict__ out_d) {
-    __shared__ double red[kRedRows][kRedCols];
+    __shared__ double red[2 * kRedRows][kRedCols];
     const int c = blockIdx.x * kRedCols + threadIdx.x % kRedCols;
     const bool ok = c < C;
-    double s = column_sum(parts, nparts, (size_t)C, c, ok, red);
+    double s, unused;
+    column_sum2(parts, nparts, (size_t)C, c, 0, false, ok, red, s, unused);
     if (!ok || threadIdx.x >= kRedCols) return;
     s *= scale;
     if (out_f) out_f[c] = (float)s;
@@ -81,11 +106,11 @@ k_reduce_parts(const double* __restrict__ parts, int nparts, int C, double scale
 __global__ void __launch_bounds__(1024)
 k_bn_bwd_finalize(const double* __restrict__ parts, int nparts, int C, double N,
                   float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ coef) {
-    __shared__ double red[kRedRows][kRedCols];
+    __shared__ double red[2 * kRedRows][kRedCols];
     const int c = blockIdx.x * kRedCols + threadIdx.x % kRedCols;
     const bool ok = c < C;
-    const double s1 = column_sum(parts, nparts, (size_t)2 * C, c, ok, red);
-    const double s2 = column_sum(parts + C, nparts, (size_t)2 * C, c, ok, red);
+    double s1, s2;
+    column_sum2(parts, nparts, (size_t)2 * C, c, (size_t)C, true, ok, red, s1, s2);
     if (!ok || threadIdx.x >= kRedCols) return;
     dbeta[c] = (float)s1;
     dgamma[c] = (float)s2;

@@ -281,13 +281,14 @@ __global__ void k_pack_weights_batched(const lisec_pack_desc* __restrict__ tab, 
 
 // split-K combine: out = sum_z partial[z] + bias (+ out) (relu) ; BatchNormalization partial statistics per
 // 128-row tile (same tile index as the single-pass kernel, so lisec_bn_finalize sees the same layout)
-__global__ void __launch_bounds__(256)
+constexpr int kSkThreads = 1024;
+__global__ void __launch_bounds__(kSkThreads)
 k_splitk_reduce(const float* __restrict__ partial, int nsplit, int M, int Cout, int CoutP,
                 const float* __restrict__ bias, int flags, float* __restrict__ out, int out_stride,
                 double* __restrict__ stats, int tile0) {
-    __shared__ float red[2][256][4];
+    __shared__ float red[2][kSkThreads][4];
     constexpr int cq = BN / 4;                       // one 64-channel slab per blockIdx.y
-    const int q = threadIdx.x % cq, rsub = threadIdx.x / cq, rows_per_iter = 256 / cq;
+    const int q = threadIdx.x % cq, rsub = threadIdx.x / cq, rows_per_iter = kSkThreads / cq;
     const int c = blockIdx.y * BN + q * 4;
     const bool cok = c < Cout;
     float4 b = make_float4(0, 0, 0, 0);
@@ -297,10 +298,20 @@ k_splitk_reduce(const float* __restrict__ partial, int nsplit, int M, int Cout, 
     const int tile = tile0 + blockIdx.x;
     const int m_begin = tile * BM, m_end = m_begin + BM < M ? m_begin + BM : M;
     const size_t rows_part = (size_t)gridDim.x * BM;
+    const size_t zstride = rows_part * CoutP;
     for (int m = m_begin + rsub; m < m_end; m += rows_per_iter) {
         float4 v = b;
-        for (int z = 0; z < nsplit; ++z) {
-            const float4 p = *reinterpret_cast<const float4*>(partial + ((size_t)z * rows_part + (m - tile0 * BM)) * CoutP + c);
+        const float* src = partial + (size_t)(m - tile0 * BM) * CoutP + c;
+        int z = 0;
+        for (; z + 4 <= nsplit; z += 4) {            // slab loads batched 4 deep, added in slab order
+            float4 p[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) p[u] = *reinterpret_cast<const float4*>(src + (size_t)(z + u) * zstride);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { v.x += p[u].x; v.y += p[u].y; v.z += p[u].z; v.w += p[u].w; }
+        }
+        for (; z < nsplit; ++z) {
+            const float4 p = *reinterpret_cast<const float4*>(src + (size_t)z * zstride);
             v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
         }
         if (cok) {
@@ -520,7 +531,7 @@ extern "C" int lisec_conv_forward(const lisec_conv_geom* c, const float* in, con
         const int tail = ntiles - plan.tile0_tail;
         dim3 grid(tail, nnb, plan.nsplit);
         LISEC_IG_ALL(grid, plan.nsplit, partial, plan.tile0_tail);
-        hipLaunchKernelGGL(k_splitk_reduce, dim3(tail, nnb), dim3(256), 0, st, partial, plan.nsplit, g.M, g.Cout,
+        hipLaunchKernelGGL(k_splitk_reduce, dim3(tail, nnb), dim3(kSkThreads), 0, st, partial, plan.nsplit, g.M, g.Cout,
                            g.CoutP, bias, flags, out, g.out_stride, stats_partials, plan.tile0_tail);
     }
 #undef LISEC_IG_ALL
