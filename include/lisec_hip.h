@@ -215,9 +215,19 @@ int lisec_conv_num_mblocks(const lisec_conv_geom* g);
  *               Used to evaluate the gradient of the dense VFE grid only at occupied cells.
  *   workspace   NULL, or scratch of lisec_conv_forward_workspace_bytes(g): lets layers with few output
  *               positions (RPN blocks 2-3) be cut into K slices so that they still fill the 256 CUs; the
- *               slices are combined in a fixed order (deterministic)
+ *               slices are combined in a fixed order (deterministic).  With a row list the plan is made for
+ *               row_capacity rows: size the scratch with lisec_conv_forward_rows_workspace_bytes.
  */
 size_t lisec_conv_forward_workspace_bytes(const lisec_conv_geom* g);
+size_t lisec_conv_forward_rows_workspace_bytes(const lisec_conv_geom* g, int row_capacity);
+/* lisec_conv_forward with an output gate: stored value = out_mask[m][n] > 0 ? value : 0, out_mask laid out like
+ * `out` (same stride).  The data gradient of a layer whose consumer-side activation was a ReLU is gated by that
+ * activation while it is stored (what lisec_relu_mask does in a separate pass).  out_mask NULL = no gate. */
+int lisec_conv_forward_masked(const lisec_conv_geom* g, const float* in, const float* packed_w, const float* bias,
+                              const float* in_bnstate, int flags, float* out, const float* out_mask,
+                              double* stats_partials, void* workspace, size_t workspace_bytes,
+                              const int32_t* row_coords, const int32_t* row_count, int row_capacity,
+                              lisec_stream_t stream);
 int lisec_conv_forward(const lisec_conv_geom* g, const float* in, const float* packed_w, const float* bias,
                        const float* in_bnstate, int flags, float* out, double* stats_partials,
                        void* workspace, size_t workspace_bytes, const int32_t* row_coords,

@@ -100,8 +100,12 @@ def _declare(lib):
     lib.lisec_conv_num_mblocks.argtypes = [POINTER(ConvGeom)]
     lib.lisec_conv_forward.restype = c_int
     lib.lisec_conv_forward.argtypes = [POINTER(ConvGeom), P, P, P, P, c_int, P, P, P, c_size_t, P, P, c_int, P]
+    lib.lisec_conv_forward_masked.restype = c_int
+    lib.lisec_conv_forward_masked.argtypes = [POINTER(ConvGeom), P, P, P, P, c_int, P, P, P, P, c_size_t, P, P, c_int, P]
     lib.lisec_conv_forward_workspace_bytes.restype = c_size_t
     lib.lisec_conv_forward_workspace_bytes.argtypes = [POINTER(ConvGeom)]
+    lib.lisec_conv_forward_rows_workspace_bytes.restype = c_size_t
+    lib.lisec_conv_forward_rows_workspace_bytes.argtypes = [POINTER(ConvGeom), c_int]
     lib.lisec_conv_wgrad_workspace_bytes.restype = c_size_t
     lib.lisec_conv_wgrad_workspace_bytes.argtypes = [POINTER(ConvGeom), c_int]
     lib.lisec_conv_wgrad.restype = c_int

@@ -16,6 +16,8 @@ struct ConvGeom {
     // optional row list: GEMM row m is the position (d,h,w) = row_coords[3m..3m+2]; rows >= *row_count are void
     const int* row_coords;
     const int* row_count;
+    // optional output mask (same layout as out): stored value = mask > 0 ? value : 0 (ReLU gradient gate)
+    const float* out_mask;
 };
 
 int conv_geom_check(const lisec_conv_geom* c, ConvGeom* g);

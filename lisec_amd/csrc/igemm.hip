@@ -228,6 +228,11 @@ k_igemm(ConvGeom g, const float* __restrict__ in, const float* __restrict__ wp,
                 if (nA < g.Cout) va += o[ncA];
                 if (nB < g.Cout) vb += o[ncB];
             }
+            if (g.out_mask) {
+                const float* mk = g.out_mask + orow * g.out_stride;
+                if (nA < g.Cout && !(mk[ncA] > 0.f)) va = 0.f;
+                if (nB < g.Cout && !(mk[ncB] > 0.f)) vb = 0.f;
+            }
             if (orelu) { va = fmaxf(va, 0.f); vb = fmaxf(vb, 0.f); }
             if (nA < g.Cout) o[ncA] = va;
             if (nB < g.Cout) o[ncB] = vb;
@@ -285,8 +290,10 @@ constexpr int kSkThreads = 1024;
 __global__ void __launch_bounds__(kSkThreads)
 k_splitk_reduce(const float* __restrict__ partial, int nsplit, int M, int Cout, int CoutP,
                 const float* __restrict__ bias, int flags, float* __restrict__ out, int out_stride,
-                double* __restrict__ stats, int tile0) {
+                double* __restrict__ stats, int tile0, const int32_t* __restrict__ row_count,
+                const float* __restrict__ out_mask) {
     __shared__ float red[2][kSkThreads][4];
+    if (row_count && *row_count < M) M = *row_count;          // row list shorter than its capacity
     constexpr int cq = BN / 4;                       // one 64-channel slab per blockIdx.y
     const int q = threadIdx.x % cq, rsub = threadIdx.x / cq, rows_per_iter = kSkThreads / cq;
     const int c = blockIdx.y * BN + q * 4;
@@ -297,6 +304,7 @@ k_splitk_reduce(const float* __restrict__ partial, int nsplit, int M, int Cout, 
     float4 s1 = make_float4(0, 0, 0, 0), s2 = make_float4(0, 0, 0, 0);
     const int tile = tile0 + blockIdx.x;
     const int m_begin = tile * BM, m_end = m_begin + BM < M ? m_begin + BM : M;
+    if (m_begin >= M) return;                                  // (never taken with stats: no row list there)
     const size_t rows_part = (size_t)gridDim.x * BM;
     const size_t zstride = rows_part * CoutP;
     for (int m = m_begin + rsub; m < m_end; m += rows_per_iter) {
@@ -317,6 +325,11 @@ k_splitk_reduce(const float* __restrict__ partial, int nsplit, int M, int Cout, 
         if (cok) {
             float* o = out + (size_t)m * out_stride + c;
             if (accum) { const float4 e = *reinterpret_cast<const float4*>(o); v.x += e.x; v.y += e.y; v.z += e.z; v.w += e.w; }
+            if (out_mask) {
+                const float4 mk = *reinterpret_cast<const float4*>(out_mask + (size_t)m * out_stride + c);
+                v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f;
+                v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
+            }
             if (orelu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
             *reinterpret_cast<float4*>(o) = v;
             s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
@@ -384,7 +397,7 @@ int conv_geom_check(const lisec_conv_geom* c, ConvGeom* g) {
     g->CoutP = (int)align_up(c->Cout, 64);
     g->M = c->Do * c->Ho * c->Wo;
     g->ps = c->ps; g->ps_channels = c->ps_channels;
-    g->row_coords = nullptr; g->row_count = nullptr;
+    g->row_coords = nullptr; g->row_count = nullptr; g->out_mask = nullptr;
     return 0;
 }
 
@@ -486,18 +499,37 @@ extern "C" size_t lisec_conv_forward_workspace_bytes(const lisec_conv_geom* c) {
     return make_conv_plan(g).ws_bytes;
 }
 
+extern "C" size_t lisec_conv_forward_rows_workspace_bytes(const lisec_conv_geom* c, int row_capacity) {
+    ConvGeom g;
+    if (conv_geom_check(c, &g) || row_capacity <= 0) return 0;
+    g.M = row_capacity;
+    return make_conv_plan(g).ws_bytes;
+}
+
 extern "C" int lisec_conv_forward(const lisec_conv_geom* c, const float* in, const float* packed_w,
                                   const float* bias, const float* in_bnstate, int flags, float* out,
                                   double* stats_partials, void* workspace, size_t workspace_bytes,
                                   const int32_t* row_coords, const int32_t* row_count, int row_capacity,
                                   lisec_stream_t stream_) {
+    return lisec_conv_forward_masked(c, in, packed_w, bias, in_bnstate, flags, out, nullptr, stats_partials, workspace,
+                                     workspace_bytes, row_coords, row_count, row_capacity, stream_);
+}
+
+extern "C" int lisec_conv_forward_masked(const lisec_conv_geom* c, const float* in, const float* packed_w,
+                                         const float* bias, const float* in_bnstate, int flags, float* out,
+                                         const float* out_mask, double* stats_partials, void* workspace,
+                                         size_t workspace_bytes, const int32_t* row_coords,
+                                         const int32_t* row_count, int row_capacity, lisec_stream_t stream_) {
     ConvGeom g;
     if (int rc = conv_geom_check(c, &g)) return rc;
+    LISEC_CHECK_ARG(!out_mask || (!c->ps && ((uintptr_t)out_mask & 15) == 0),
+                    "out_mask: 16-byte aligned, not with a pixel-shuffle store");
+    g.out_mask = out_mask;
     if (row_coords) {
         LISEC_CHECK_ARG(row_count && row_capacity > 0 && !stats_partials && !c->ps,
                         "row list needs a device count, a capacity, and no stats / pixel-shuffle");
         g.row_coords = row_coords; g.row_count = row_count; g.M = row_capacity;
-        workspace = nullptr;                      // no K slicing: the live row count is only known on the device
+        // K slicing is planned for the capacity; workgroups past the device-side row count exit at once
     }
     LISEC_CHECK_ARG(in && packed_w && out, "NULL tensor pointer");
     LISEC_CHECK_ARG(((uintptr_t)in & 15) == 0 && ((uintptr_t)packed_w & 15) == 0, "in/weights must be 16-byte aligned");
@@ -532,7 +564,7 @@ extern "C" int lisec_conv_forward(const lisec_conv_geom* c, const float* in, con
         dim3 grid(tail, nnb, plan.nsplit);
         LISEC_IG_ALL(grid, plan.nsplit, partial, plan.tile0_tail);
         hipLaunchKernelGGL(k_splitk_reduce, dim3(tail, nnb), dim3(kSkThreads), 0, st, partial, plan.nsplit, g.M, g.Cout,
-                           g.CoutP, bias, flags, out, g.out_stride, stats_partials, plan.tile0_tail);
+                           g.CoutP, bias, flags, out, g.out_stride, stats_partials, plan.tile0_tail, g.row_count, g.out_mask);
     }
 #undef LISEC_IG_ALL
 #undef LISEC_IG

@@ -48,28 +48,45 @@ k_line_sums(ConvGeom g, const float* __restrict__ dy, float* __restrict__ line_s
     }
 }
 
-// S[tap][c] = sum over the lines (d', h') for which (kd, kh) read inside the grid (fixed order, fp64)
-__global__ void __launch_bounds__(256)
+// S[tap][c] = sum over the lines (d', h') for which (kd, kh) read inside the grid (fixed order, fp64):
+// 16 line groups x 64 channels per block, loads batched 4 deep (a line outside the tap's range counts as 0)
+constexpr int kTapLanes = 16;
+__global__ void __launch_bounds__(1024)
 k_tap_sums(ConvGeom g, const float* __restrict__ line_s, float* __restrict__ S) {
-    __shared__ double red[256];
+    __shared__ double red[kTapLanes][64];
     const int C = g.Cout;
     const int tap = blockIdx.x, kw = tap % g.KW, kh = (tap / g.KW) % g.KH, kd = tap / (g.KW * g.KH);
     const int nlines = g.Do * g.Ho;
-    const int cgroups = 256 / 64;                       // 4 line-groups x 64 channels per pass
+    const int cl = threadIdx.x & 63, lg = threadIdx.x >> 6;
+    auto inside = [&](int line) -> bool {
+        const int d = line / g.Ho, h = line - d * g.Ho;
+        const int bd = (d << g.ls_d) - g.pd + kd, bh = (h << g.ls_h) - g.ph + kh;
+        return bd >= 0 && bd < g.Di && bh >= 0 && bh < g.Hi;
+    };
     for (int c0 = 0; c0 < C; c0 += 64) {
-        const int c = c0 + (threadIdx.x & 63), lg = threadIdx.x >> 6;
+        const int c = c0 + cl;
         double a = 0.0;
         if (c < C) {
-            for (int line = lg; line < nlines; line += cgroups) {
-                const int d = line / g.Ho, h = line - d * g.Ho;
-                const int bd = (d << g.ls_d) - g.pd + kd, bh = (h << g.ls_h) - g.ph + kh;
-                if (bd >= 0 && bd < g.Di && bh >= 0 && bh < g.Hi) a += (double)line_s[((size_t)line * g.KW + kw) * C + c];
+            const float* src = line_s + (size_t)kw * C + c;
+            const size_t ld = (size_t)g.KW * C;
+            int line = lg;
+            for (; line + 3 * kTapLanes < nlines; line += 4 * kTapLanes) {
+                float v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = src[(size_t)(line + u * kTapLanes) * ld];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) a += inside(line + u * kTapLanes) ? (double)v[u] : 0.0;
             }
+            for (; line < nlines; line += kTapLanes)
+                if (inside(line)) a += (double)src[(size_t)line * ld];
         }
-        red[threadIdx.x] = a;
+        red[lg][cl] = a;
         __syncthreads();
-        if (threadIdx.x < 64 && c < C)
-            S[(size_t)tap * C + c] = (float)(red[threadIdx.x] + red[threadIdx.x + 64] + red[threadIdx.x + 128] + red[threadIdx.x + 192]);
+        if (lg == 0 && c < C) {
+            double t = red[0][cl];
+            for (int l = 1; l < kTapLanes; ++l) t += red[l][cl];
+            S[(size_t)tap * C + c] = (float)t;
+        }
         __syncthreads();
     }
 }
@@ -137,7 +154,7 @@ extern "C" int lisec_conv_tap_sums(const lisec_conv_geom* c, const float* dy, fl
     hipStream_t st = static_cast<hipStream_t>(stream_);
     float* line_s = static_cast<float*>(workspace);
     hipLaunchKernelGGL(k_line_sums, dim3(g.Do * g.Ho), dim3(256), 0, st, g, dy, line_s);
-    hipLaunchKernelGGL(k_tap_sums, dim3(g.KD * g.KH * g.KW), dim3(256), 0, st, g, line_s, S);
+    hipLaunchKernelGGL(k_tap_sums, dim3(g.KD * g.KH * g.KW), dim3(1024), 0, st, g, line_s, S);
     LISEC_LAUNCH_CHECK();
     return LISEC_OK;
 }

@@ -390,6 +390,48 @@ k_wgrad_reduce(const float* __restrict__ partial, int nsplit, int ntaps, int Cin
     }
 }
 
+// Many slabs over a small kernel (the 64x64 Dense layers: > 1000 slabs of 16 KB): 32 lanes stride over the slabs of
+// 8 float4 outputs per block (loads batched 8 deep), combined in lane order through LDS.
+__global__ void __launch_bounds__(256)
+k_wgrad_reduce_lanes(const float* __restrict__ partial, int nsplit, int ntaps, int Cin, int Cout,
+                     int transpose, float* __restrict__ dW) {
+    __shared__ float4 red[32][8];
+    const long long per4 = ((long long)ntaps * Cin * Cout) >> 2;
+    const int tx = threadIdx.x & 7, ty = threadIdx.x >> 3;
+    const long long i4 = blockIdx.x * 8LL + tx;
+    float4 s = make_float4(0, 0, 0, 0);
+    if (i4 < per4) {
+        const float4* src = reinterpret_cast<const float4*>(partial) + i4;
+        int k = ty;
+        for (; k + 7 * 32 < nsplit; k += 8 * 32) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(k + 32 * u) * per4];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+        }
+        for (; k < nsplit; k += 32) {
+            const float4 v = src[(size_t)k * per4];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+    }
+    red[ty][tx] = s;
+    __syncthreads();
+    if (ty != 0 || i4 >= per4) return;
+    for (int l = 1; l < 32; ++l) { const float4 v = red[l][tx]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+    const long long i = i4 << 2;
+    if (!transpose) {
+        reinterpret_cast<float4*>(dW)[i4] = s;
+    } else {
+        const int n = (int)(i % Cout);
+        long long t = i / Cout;
+        const int c = (int)(t % Cin);
+        const int tap = (int)(t / Cin);
+        float* o = dW + ((size_t)tap * Cout + n) * Cin + c;
+        o[0] = s.x; o[Cin] = s.y; o[2 * (size_t)Cin] = s.z; o[3 * (size_t)Cin] = s.w;
+    }
+}
+
 struct WgradPlan {
     int TG, ngroups, nsplit, tiles_per_split, ntiles;
     bool halo;
@@ -492,8 +534,12 @@ extern "C" int lisec_conv_wgrad(const lisec_conv_geom* c, const float* in, const
     long long per = (long long)ntaps * g.Cin * g.Cout;
     int gb = cdiv(per / 4, 256);
     if (gb > 4096) gb = 4096;
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3(gb), dim3(256), 0, st, partial, p.nsplit, ntaps, g.Cin, g.Cout,
-                       transpose_out, dW);
+    if (gb < 64 && p.nsplit >= 128)
+        hipLaunchKernelGGL(k_wgrad_reduce_lanes, dim3(cdiv(per / 4, 8)), dim3(256), 0, st, partial, p.nsplit, ntaps,
+                           g.Cin, g.Cout, transpose_out, dW);
+    else
+        hipLaunchKernelGGL(k_wgrad_reduce, dim3(gb), dim3(256), 0, st, partial, p.nsplit, ntaps, g.Cin, g.Cout,
+                           transpose_out, dW);
     LISEC_LAUNCH_CHECK();
     return LISEC_OK;
 }

@@ -315,7 +315,10 @@ class LisecNet:
 
         def dgrad_into(c, dy, dst_name):
             flags = ops.ACCUMULATE if dst_name in first_write else 0
-            ops.conv_forward(self.dgeom[c.name], dy, self.packed_t[c.name][0], d[dst_name], flags=flags)
+            # the output of a middle block went through Dense(relu) (model_training.py:195): its gradient is gated
+            # by that activation while the data gradient is stored (single consumer, so no ACCUMULATE there)
+            mask = a[dst_name] if dst_name.endswith(".u") else None
+            ops.conv_forward(self.dgeom[c.name], dy, self.packed_t[c.name][0], d[dst_name], flags=flags, out_mask=mask)
             first_write.add(dst_name)
 
         for L in reversed(layers):
@@ -350,7 +353,6 @@ class LisecNet:
                 dgrad_into(c, d[dst], L["src"])
             else:   # mid layer: conv3d -> BN -> Dense(relu)
                 n, dn = L["name"], L["dense"]
-                ops.relu_mask(d[n + ".u"], a[n + ".u"])
                 on_side(lambda n=n, dn=dn: ops.conv_wgrad(dn.g, a[n + ".y"], d[n + ".u"], p.grad_view(G, dn.wname),
                                                           self.wgrad_ws, in_bn=self.bnstate[dn.in_bn]))
                 ops.conv_forward(self.dgeom[dn.name], d[n + ".u"], self.packed_t[dn.name][0], d[n + ".z"])

@@ -76,9 +76,11 @@ def num_mblocks(g):
 _SPLITK_WS = {}
 
 
-def conv_workspace(g, device):
+def conv_workspace(g, device, row_capacity=0):
     """Shared split-K scratch for `g` (None when the layer is large enough to run in one pass)."""
-    need = _lib.load().lisec_conv_forward_workspace_bytes(ctypes.byref(g))
+    lib = _lib.load()
+    need = (lib.lisec_conv_forward_rows_workspace_bytes(ctypes.byref(g), row_capacity) if row_capacity > 0
+            else lib.lisec_conv_forward_workspace_bytes(ctypes.byref(g)))
     if need == 0:
         return None
     key = str(device)
@@ -87,14 +89,16 @@ def conv_workspace(g, device):
     return _SPLITK_WS[key]
 
 
-def conv_forward(g, x, wp, out, bias=None, in_bn=None, flags=0, stats=None, splitk=True, rows=None):
-    """rows: optional (row_coords int32 (cap,3), row_count int32 device scalar, capacity) row list."""
-    ws = conv_workspace(g, out.device) if (splitk and rows is None) else None
+def conv_forward(g, x, wp, out, bias=None, in_bn=None, flags=0, stats=None, splitk=True, rows=None, out_mask=None):
+    """rows: optional (row_coords int32 (cap,3), row_count int32 device scalar, capacity) row list.
+    out_mask: optional tensor laid out like `out`; values are stored as 0 where out_mask <= 0."""
     rc, rn, cap = rows if rows is not None else (None, None, 0)
-    _lib.check(_lib.load().lisec_conv_forward(ctypes.byref(g), _lib.ptr(x), _lib.ptr(wp), _lib.ptr(bias),
-                                              _lib.ptr(in_bn), flags, _lib.ptr(out), _lib.ptr(stats),
-                                              _lib.ptr(ws), ws.numel() if ws is not None else 0,
-                                              _lib.ptr(rc), _lib.ptr(rn), cap, _lib.current_stream()))
+    ws = conv_workspace(g, out.device, cap) if splitk else None
+    _lib.check(_lib.load().lisec_conv_forward_masked(ctypes.byref(g), _lib.ptr(x), _lib.ptr(wp), _lib.ptr(bias),
+                                                     _lib.ptr(in_bn), flags, _lib.ptr(out), _lib.ptr(out_mask),
+                                                     _lib.ptr(stats), _lib.ptr(ws),
+                                                     ws.numel() if ws is not None else 0,
+                                                     _lib.ptr(rc), _lib.ptr(rn), cap, _lib.current_stream()))
     return out
 
 

@@ -131,3 +131,26 @@ def test_accumulate_and_data_gradient():
     dx = base.to(DEV).clone()
     ops.conv_forward(geo, dy.to(DEV), wp, dx, flags=ops.ACCUMULATE)
     _close(dx, x.grad + base)
+
+
+@pytest.mark.parametrize("shape", [(4, 10, 14), (1, 25, 50)])
+def test_output_mask_gates_the_stored_gradient(shape):
+    """lisec_conv_forward_masked: stored value = mask > 0 ? value : 0 -- the ReLU gate of a Dense(relu) consumer folded
+    into the data-gradient store (single pass and the K-sliced path, whose combine kernel applies the gate)."""
+    from lisec_amd import ops
+    g = torch.Generator().manual_seed(5)
+    D, H, W = shape
+    Cin = Cout = 64
+    k, stride, pad = (3, 3, 3), (1, 1, 1), (1, 1, 1)
+    w = torch.randn(*k, Cin, Cout, generator=g) * 0.1
+    dy = torch.randn(D, H, W, Cout, generator=g).to(DEV)
+    mask = torch.randn(D, H, W, Cin, generator=g)
+    mask[mask.abs() < 0.2] = 0.0                                   # exact zeros gate too (mask > 0 is strict)
+    geo = ops.geom(1, (D, H, W), (D, H, W), k, stride, pad, Cout, Cin)
+    wp = ops.pack_weights(w.to(DEV), 27, Cout, Cin, Cin * Cout, 1, Cout)
+    for splitk in (True, False):
+        plain = torch.empty(D, H, W, Cin, device=DEV)
+        gated = torch.full((D, H, W, Cin), float("nan"), device=DEV)
+        ops.conv_forward(geo, dy, wp, plain, splitk=splitk)
+        ops.conv_forward(geo, dy, wp, gated, splitk=splitk, out_mask=mask.to(DEV))
+        assert torch.equal(gated, torch.where(mask.to(DEV) > 0, plain, torch.zeros_like(plain)))
