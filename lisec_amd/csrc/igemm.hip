@@ -482,6 +482,7 @@ ConvPlan make_conv_plan(const ConvGeom& g) {
     }
     const long long tail_blocks = (long long)tail_tiles * nnb;
     if (tail_blocks == 0 || tail_blocks * 10 > (long long)slots * 7) return p;   // tail round >= 70 % full already
+    if (blocks > 2LL * slots) return p;     // >= 3 rounds: the short last round costs less than a sliced launch + combine
     int ns = (int)(slots / tail_blocks);
     if (ns > nsteps / 3) ns = nsteps / 3;
     if (ns > 8) ns = 8;
