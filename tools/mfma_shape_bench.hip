@@ -141,7 +141,9 @@ __global__ void __launch_bounds__(256) k_staged(float* __restrict__ out, const f
     size_t base = ((size_t)blockIdx.x * 128) % (src_floats / 64 - 4096);
     for (int it = 0; it < iters; ++it) {
         asm volatile("" ::: "memory");
+        const bool stageA = STAGE != 5 || (it % 3) == 2;     // STAGE 5: one A tile serves the three kw taps
         if (STAGE >= 3) {
+            if (stageA)
 #pragma unroll
             for (int p = 0; p < 8; ++p)
                 ra[p] = *reinterpret_cast<const float4*>(src + (base + p * 16 + (tid >> 4)) * 64 + piece * 4);
@@ -151,7 +153,7 @@ __global__ void __launch_bounds__(256) k_staged(float* __restrict__ out, const f
             base += 400;                                   // the next tap: one image row further
             if (base + 4096 > src_floats / 64) base = (size_t)blockIdx.x * 128;
         }
-        if (STAGE == 4) {
+        if (STAGE >= 4) {
             float4 a = *reinterpret_cast<const float4*>(aRow);
             float4 b0 = *reinterpret_cast<const float4*>(bCol);
             float4 b1 = *reinterpret_cast<const float4*>(bCol + 32 * 4);
@@ -193,6 +195,7 @@ __global__ void __launch_bounds__(256) k_staged(float* __restrict__ out, const f
         }
         if (STAGE >= 1) __syncthreads();
         if (STAGE >= 2) {
+            if (stageA)
 #pragma unroll
             for (int p = 0; p < 8; ++p)
                 *reinterpret_cast<float4*>(sA + (p * 16 + (tid >> 4)) * LDA + piece * 4) = ra[p];
@@ -369,6 +372,7 @@ int main(int argc, char** argv) {
             run_staged<3>("S3 + global loads", blocks, it, out, src, src_floats);
             run_staged<4>("S4 + pipelined fragment reads (k_igemm)", blocks, it, out, src, src_floats);
             run_dbuf("S5 BK32 LDS double buffer, interleaved", blocks, 2 * it, out, src, src_floats);
+            run_staged<5>("S6 = S4 with the A tile staged every 3rd slab", blocks, it, out, src, src_floats);
         }
     }
     hipFree(src);
