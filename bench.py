@@ -113,6 +113,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--loss", choices=["mse", "smoothl1_ce"], default="mse",
+                    help="mse = the reference's compile(loss=['mse','mse']) (model_training.py:296); smoothl1_ce = the "
+                         "sigmoid cross-entropy + SmoothL1 pair BASELINE.json's config 3 names (same kernels otherwise)")
     ap.add_argument("--cloud", choices=["u20k", "r200k"], default="u20k",
                     help="u20k: the headline workload (BASELINE configs 2-4); r200k: a Lyft-size sweep")
     args = ap.parse_args()
@@ -149,7 +152,7 @@ def main():
     allreduce = dp.bucketed() if dp is not None else None
     def step():
         sample = vox(pts)
-        return net.train_step(sample, ycls, yreg, loss="mse", allreduce=allreduce)
+        return net.train_step(sample, ycls, yreg, loss=args.loss, allreduce=allreduce)
 
     for _ in range(args.warmup):
         step()
@@ -214,7 +217,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"Lyft grid 8x200x400x35, {args.cloud.upper()} synthetic cloud, 1 sample/GPU/step, "
-                                   "voxelise+VFE+3xConv3D+RPN fwd+bwd, MSE+MSE, SGD-Nesterov",
+                                   "voxelise+VFE+3xConv3D+RPN fwd+bwd, "
+                                   + ("MSE+MSE" if args.loss == "mse" else "sigmoid-CE+SmoothL1") + ", SGD-Nesterov",
                        "global_batch": world, "parallelism": f"dp{world}", "points_per_sample": int(len(cloud)),
                        "voxels": hi["V"], "final_loss": loss_val},
             "roofline": roofline, "roofline_vfe": roofline_vfe,
