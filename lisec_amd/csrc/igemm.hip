@@ -32,6 +32,87 @@ constexpr int kThreads = 256;
 constexpr int A_FLOATS = BM * LDA;               // 8704
 constexpr int B_FLOATS = BK * BN;                // 4096
 
+// Epilogue shared by the igemm kernels: raw K-slice slab, or bias (+accumulate, output gate, ReLU) store with the
+// per-tile BatchNormalization partial sums.  C layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+__device__ __forceinline__ void store_tile(const ConvGeom& g, const f32x16& acc0, const f32x16& acc1, float* smem,
+                                           int m0, int n0, int mb, int mlimit, int tile0, int wave, int lane, int tid,
+                                           const float* __restrict__ bias, int flags, float* __restrict__ out,
+                                           double* __restrict__ stats, float* __restrict__ partial) {
+    const int col = lane & 31;
+    if (partial) {
+        // slabs cover the rows of tiles tile0 .. (the tail of the layer, or all of it)
+        const size_t rows_part = (size_t)gridDim.x * BM;
+        float* pz = partial + (size_t)blockIdx.z * rows_part * g.CoutP;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (m < mlimit) {
+                const size_t ml = (size_t)(m - tile0 * BM);
+                pz[ml * g.CoutP + n0 + col] = acc0[r];
+                pz[ml * g.CoutP + n0 + 32 + col] = acc1[r];
+            }
+        }
+        return;
+    }
+    const int nA = n0 + col, nB = n0 + 32 + col;
+    // pixel-shuffle store (kernel == stride transposed conv): the 64-column slab lies inside one tap
+    const int ps_tap = g.ps ? n0 / g.ps_channels : 0;
+    const int ps_kh = g.ps ? ps_tap / g.ps : 0, ps_kw = g.ps ? ps_tap - ps_kh * g.ps : 0;
+    const int ncA = g.ps ? nA - ps_tap * g.ps_channels : nA, ncB = g.ps ? nB - ps_tap * g.ps_channels : nB;
+    const float biasA = (bias && nA < g.Cout) ? bias[ncA] : 0.f;
+    const float biasB = (bias && nB < g.Cout) ? bias[ncB] : 0.f;
+    const bool orelu = (flags & LISEC_CONV_OUT_RELU) != 0, accum = (flags & LISEC_CONV_ACCUMULATE) != 0;
+    float sumA = 0.f, sqA = 0.f, sumB = 0.f, sqB = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int m = m0 + wave * 32 + row;
+        if (m < mlimit) {
+            size_t orow = (size_t)m;
+            if (g.ps) {
+                const int h = m / g.Wo, w = m - h * g.Wo;
+                orow = (size_t)(h * g.ps + ps_kh) * (g.Wo * g.ps) + (w * g.ps + ps_kw);
+            }
+            float* o = out + orow * g.out_stride;
+            float va = acc0[r] + biasA, vb = acc1[r] + biasB;
+            if (accum) {
+                if (nA < g.Cout) va += o[ncA];
+                if (nB < g.Cout) vb += o[ncB];
+            }
+            if (g.out_mask) {
+                const float* mk = g.out_mask + orow * g.out_stride;
+                if (nA < g.Cout && !(mk[ncA] > 0.f)) va = 0.f;
+                if (nB < g.Cout && !(mk[ncB] > 0.f)) vb = 0.f;
+            }
+            if (orelu) { va = fmaxf(va, 0.f); vb = fmaxf(vb, 0.f); }
+            if (nA < g.Cout) o[ncA] = va;
+            if (nB < g.Cout) o[ncB] = vb;
+            sumA += va; sqA = fmaf(va, va, sqA);
+            sumB += vb; sqB = fmaf(vb, vb, sqB);
+        }
+    }
+    if (stats) {
+        // per-channel partial sums of this 128-row tile (BatchNormalization batch statistics)
+        __syncthreads();
+        float* red = smem;                       // [4 waves][4][32]
+        sumA += __shfl_xor(sumA, 32, 64); sqA += __shfl_xor(sqA, 32, 64);
+        sumB += __shfl_xor(sumB, 32, 64); sqB += __shfl_xor(sqB, 32, 64);
+        if (lane < 32) {
+            red[(wave * 4 + 0) * 32 + lane] = sumA; red[(wave * 4 + 1) * 32 + lane] = sqA;
+            red[(wave * 4 + 2) * 32 + lane] = sumB; red[(wave * 4 + 3) * 32 + lane] = sqB;
+        }
+        __syncthreads();
+        if (tid < 128) {
+            const int q = tid >> 5, c = tid & 31;            // q: 0 sumA, 1 sqA, 2 sumB, 3 sqB
+            double v = 0.0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v += (double)red[(k * 4 + q) * 32 + c];
+            const int n = n0 + (q >> 1) * 32 + c;
+            if (n < g.Cout) stats[((size_t)mb * 2 + (q & 1)) * g.Cout + n] = v;
+        }
+    }
+}
+
 // TAG only changes the symbol name: bench.py launches the dominant layer through k_igemm<0,false,1> so that its
 // row in a rocprofv3 --stats summary is that layer alone (same code as TAG 0).
 template <int MODE, bool XF, int TAG = 0>
@@ -186,80 +267,198 @@ k_igemm(ConvGeom g, const float* __restrict__ in, const float* __restrict__ wp,
         s = snext;
     }
 
-    // ---- epilogue: C layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    const int col = lane & 31;
-    if (partial) {
-        // slabs cover the rows of tiles tile0 .. (the tail of the layer, or all of it)
-        const size_t rows_part = (size_t)gridDim.x * BM;
-        float* pz = partial + (size_t)blockIdx.z * rows_part * g.CoutP;
+    store_tile(g, acc0, acc1, smem, m0, n0, mb, mlimit, tile0, wave, lane, tid, bias, flags, out, stats, partial);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// w-halo variant for 3-tap, stride-1, pad-1 contractions along w (Conv3D / Conv2D 3x3 'same' layers and their data
+// gradients, Wo >= 126).  The three kw taps of one (kd, kh) pair read the SAME input line shifted by one position, so
+// the A tile is staged once per (kd, kh, channel slab) as the tile's line segment(s) plus one halo column on each
+// side, and tap kw only moves the fragment base by one LDS row: a third of the global loads, LDS writes and
+// BatchNormalization-on-load work of k_igemm per MFMA.  A 128-row tile touches at most two output lines (Wo >= 126):
+//     halo row j <  a + 2 : line L0,     w_in = w0 - 1 + j              (a = rows of the tile on line L0)
+//     halo row j >= a + 2 : line L0 + 1, w_in = j - (a + 2) - 1
+// and output row r reads halo row  r + (r >= a ? 2 : 0) + f(kw),  f = kw (mode 0) or 2 - kw (mode 1).  Zero padding in w
+// is simply a zero halo row; the (kd, kh) validity is per line, i.e. wave-uniform.  Unsliced launches only.
+constexpr int HALO_MAX_ROWS = BM + 4;                          // two segments, two halo columns each
+constexpr int AH_FLOATS = HALO_MAX_ROWS * LDA;                 // 8976 floats: with the W slab 52 288 B, 3 per CU
+
+template <int MODE, bool XF, int TAG = 0>
+__global__ void __launch_bounds__(kThreads)
+k_igemm_halo(ConvGeom g, const float* __restrict__ in, const float* __restrict__ wp,
+             const float* __restrict__ bias, const float* __restrict__ in_bn, int flags,
+             float* __restrict__ out, double* __restrict__ stats) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sA = smem;
+    float* sB = smem + AH_FLOATS;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int mb = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = mb * BM;
+    const int n0 = blockIdx.y * BN;
+    const int mlimit = g.M;
+
+    // ---- the (at most two) output lines of this tile -----------------------------------------------
+    const int L0 = m0 / g.Wo, w0 = m0 - L0 * g.Wo;
+    const int a = g.Wo - w0 < BM ? g.Wo - w0 : BM;               // rows on line L0
+    const int nlines = g.Do * g.Ho;
+    const int nrows = a < BM ? BM + 4 : BM + 2;                  // staged halo rows
+    const int d0 = L0 / g.Ho, h0 = L0 - d0 * g.Ho;
+    const int L1 = L0 + 1, d1 = L1 / g.Ho, h1 = L1 - d1 * g.Ho;
+    const bool line1 = a < BM && L1 < nlines;
+
+    // ---- staging map of this thread: halo row j = p*16 + tid/16, 16-byte piece tid%16 ----------------
+    const int piece = tid & 15;
+    int woff[9];                                                 // w_in * in_stride + piece*4, < 0: never valid
+    unsigned segbits = 0;                                        // bit p: row p belongs to line L0 + 1
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            if (m < mlimit) {
-                const size_t ml = (size_t)(m - tile0 * BM);
-                pz[ml * g.CoutP + n0 + col] = acc0[r];
-                pz[ml * g.CoutP + n0 + 32 + col] = acc1[r];
+    for (int p = 0; p < 9; ++p) {
+        const int j = p * 16 + (tid >> 4);
+        const bool s1 = j >= a + 2;
+        const int w_in = s1 ? j - (a + 2) - 1 : w0 - 1 + j;
+        const bool ok = j < nrows && w_in >= 0 && w_in < g.Wi;
+        woff[p] = ok ? w_in * g.in_stride + piece * 4 : -1;
+        segbits |= s1 ? (1u << p) : 0u;
+    }
+
+    const int ncc = (g.Cin + BK - 1) / BK;
+    const int ngroups = g.KD * g.KH;
+    const int nsteps = ngroups * ncc * 3;
+    const int KpQ = ncc * (BK / 4);
+
+    // (kd, kh) -> element offset of the source line of each of the two lines, or -1 (outside / not divisible)
+    auto line_base = [&](int d, int h, int kd, int kh, bool exists) -> int {
+        bool ok = exists;
+        const int din = src_coord(d, kd, g.ls_d, g.pd, g.Di, MODE, ok);
+        const int hin = src_coord(h, kh, g.ls_h, g.ph, g.Hi, MODE, ok);
+        return ok ? ((din * g.Hi + hin) * g.Wi) * g.in_stride : -1;
+    };
+    auto group_of = [&](int s, int& kd, int& kh, int& cc, int& kw) {
+        kw = s % 3;
+        const int t = s / 3;
+        cc = t % ncc;
+        const int gi = t / ncc;
+        kh = gi % g.KH; kd = gi / g.KH;
+    };
+    auto live = [&](int s) -> bool {
+        int kd, kh, cc, kw;
+        group_of(s, kd, kh, cc, kw);
+        return line_base(d0, h0, kd, kh, true) >= 0 || line_base(d1, h1, kd, kh, line1) >= 0;
+    };
+
+    float4 ra[9];
+    float4 rb0, rb1, rb2, rb3;
+    float4 tsc = make_float4(1, 1, 1, 1), tsh = make_float4(0, 0, 0, 0);
+    unsigned valid_mask = 0;
+    bool staged_a = false;
+
+    auto issue_loads = [&](int s) {
+        int kd, kh, cc, kw;
+        group_of(s, kd, kh, cc, kw);
+        staged_a = kw == 0;
+        if (staged_a) {
+            const int c = cc * BK + piece * 4;
+            const bool cok = c < g.Cin;
+            const int b0 = line_base(d0, h0, kd, kh, true), b1 = line_base(d1, h1, kd, kh, line1);
+            valid_mask = 0;
+#pragma unroll
+            for (int p = 0; p < 9; ++p) {
+                const int lb = (segbits >> p) & 1 ? b1 : b0;
+                const bool ok = cok && woff[p] >= 0 && lb >= 0;
+                const int off = ok ? lb + woff[p] + cc * BK : 0;        // branch-free: invalid pieces read element 0
+                ra[p] = *reinterpret_cast<const float4*>(in + off);
+                valid_mask |= ok ? (1u << p) : 0u;
+            }
+            if (XF && in_bn && cok) {
+                tsc = *reinterpret_cast<const float4*>(in_bn + c);
+                tsh = *reinterpret_cast<const float4*>(in_bn + g.Cin + c);
             }
         }
-        return;
-    }
-    const int nA = n0 + col, nB = n0 + 32 + col;
-    // pixel-shuffle store (kernel == stride transposed conv): the 64-column slab lies inside one tap
-    const int ps_tap = g.ps ? n0 / g.ps_channels : 0;
-    const int ps_kh = g.ps ? ps_tap / g.ps : 0, ps_kw = g.ps ? ps_tap - ps_kh * g.ps : 0;
-    const int ncA = g.ps ? nA - ps_tap * g.ps_channels : nA, ncB = g.ps ? nB - ps_tap * g.ps_channels : nB;
-    const float biasA = (bias && nA < g.Cout) ? bias[ncA] : 0.f;
-    const float biasB = (bias && nB < g.Cout) ? bias[ncB] : 0.f;
-    const bool orelu = (flags & LISEC_CONV_OUT_RELU) != 0, accum = (flags & LISEC_CONV_ACCUMULATE) != 0;
-    float sumA = 0.f, sqA = 0.f, sumB = 0.f, sqB = 0.f;
+        const int tap = (kd * g.KH + kh) * 3 + kw;
+        const float* wb = wp + ((size_t)(tap * KpQ + cc * (BK / 4)) * g.CoutP + n0) * 4;
+        const float* wl = wb + (size_t)(tid >> 6) * g.CoutP * 4 + (tid & 63) * 4;
+        const size_t wstep = (size_t)4 * g.CoutP * 4;
+        rb0 = *reinterpret_cast<const float4*>(wl);
+        rb1 = *reinterpret_cast<const float4*>(wl + wstep);
+        rb2 = *reinterpret_cast<const float4*>(wl + 2 * wstep);
+        rb3 = *reinterpret_cast<const float4*>(wl + 3 * wstep);
+    };
+    const float relu_lo = (flags & LISEC_CONV_IN_RELU) ? 0.f : -INFINITY;
+    auto store_lds = [&]() {
+        if (staged_a) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        const int m = m0 + wave * 32 + row;
-        if (m < mlimit) {
-            size_t orow = (size_t)m;
-            if (g.ps) {
-                const int h = m / g.Wo, w = m - h * g.Wo;
-                orow = (size_t)(h * g.ps + ps_kh) * (g.Wo * g.ps) + (w * g.ps + ps_kw);
+            for (int p = 0; p < 9; ++p) {
+                float4 v = ra[p];
+                const bool ok = (valid_mask >> p) & 1;
+                if (XF) {
+                    v.x = ok ? fmaxf(fmaf(v.x, tsc.x, tsh.x), relu_lo) : 0.f;
+                    v.y = ok ? fmaxf(fmaf(v.y, tsc.y, tsh.y), relu_lo) : 0.f;
+                    v.z = ok ? fmaxf(fmaf(v.z, tsc.z, tsh.z), relu_lo) : 0.f;
+                    v.w = ok ? fmaxf(fmaf(v.w, tsc.w, tsh.w), relu_lo) : 0.f;
+                } else {
+                    v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+                }
+                const int j = p * 16 + (tid >> 4);
+                if (j < HALO_MAX_ROWS) *reinterpret_cast<float4*>(sA + j * LDA + piece * 4) = v;
             }
-            float* o = out + orow * g.out_stride;
-            float va = acc0[r] + biasA, vb = acc1[r] + biasB;
-            if (accum) {
-                if (nA < g.Cout) va += o[ncA];
-                if (nB < g.Cout) vb += o[ncB];
-            }
-            if (g.out_mask) {
-                const float* mk = g.out_mask + orow * g.out_stride;
-                if (nA < g.Cout && !(mk[ncA] > 0.f)) va = 0.f;
-                if (nB < g.Cout && !(mk[ncB] > 0.f)) vb = 0.f;
-            }
-            if (orelu) { va = fmaxf(va, 0.f); vb = fmaxf(vb, 0.f); }
-            if (nA < g.Cout) o[ncA] = va;
-            if (nB < g.Cout) o[ncB] = vb;
-            sumA += va; sqA = fmaf(va, va, sqA);
-            sumB += vb; sqB = fmaf(vb, vb, sqB);
         }
+        float* bl = sB + ((tid >> 6) * BN + (tid & 63)) * 4;
+        *reinterpret_cast<float4*>(bl) = rb0;
+        *reinterpret_cast<float4*>(bl + 4 * BN * 4) = rb1;
+        *reinterpret_cast<float4*>(bl + 8 * BN * 4) = rb2;
+        *reinterpret_cast<float4*>(bl + 12 * BN * 4) = rb3;
+    };
+
+    f32x16 acc0 = {0}, acc1 = {0};
+    const int r_lane = wave * 32 + (lane & 31);
+    const float* aLane = sA + (r_lane + (r_lane >= a ? 2 : 0)) * LDA + 4 * (lane >> 5);
+    const float* bCol = sB + ((lane >> 5) * BN + (lane & 31)) * 4;
+
+    auto advance_to = [&](int s) -> int {
+        while (s < nsteps && !live(s)) s += 3 - s % 3;           // a dead (kd, kh) pair: skip its three taps
+        return s < nsteps ? s : nsteps;
+    };
+    int s = advance_to(0);
+    if (s < nsteps) {
+        issue_loads(s);
+        store_lds();
     }
-    if (stats) {
-        // per-channel partial sums of this 128-row tile (BatchNormalization batch statistics)
+    __syncthreads();
+    while (s < nsteps) {
+        const int snext = advance_to(s + 1);
+        if (snext < nsteps) issue_loads(snext);
+        const int kw = s % 3;
+        const float* aRow = aLane + (MODE == 0 ? kw : 2 - kw) * LDA;
+        float4 av = *reinterpret_cast<const float4*>(aRow);
+        float4 b0 = *reinterpret_cast<const float4*>(bCol);
+        float4 b1 = *reinterpret_cast<const float4*>(bCol + 32 * 4);
+#pragma unroll
+        for (int kc = 0; kc < BK / 8; ++kc) {
+            float4 an = av, b0n = b0, b1n = b1;
+            if (kc + 1 < BK / 8) {
+                an = *reinterpret_cast<const float4*>(aRow + (kc + 1) * 8);
+                b0n = *reinterpret_cast<const float4*>(bCol + (kc + 1) * 2 * BN * 4);
+                b1n = *reinterpret_cast<const float4*>(bCol + (kc + 1) * 2 * BN * 4 + 32 * 4);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b0.x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b1.x, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b0.y, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b1.y, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b0.z, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b1.z, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b0.w, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b1.w, acc1, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            av = an; b0 = b0n; b1 = b1n;
+        }
         __syncthreads();
-        float* red = smem;                       // [4 waves][4][32]
-        sumA += __shfl_xor(sumA, 32, 64); sqA += __shfl_xor(sqA, 32, 64);
-        sumB += __shfl_xor(sumB, 32, 64); sqB += __shfl_xor(sqB, 32, 64);
-        if (lane < 32) {
-            red[(wave * 4 + 0) * 32 + lane] = sumA; red[(wave * 4 + 1) * 32 + lane] = sqA;
-            red[(wave * 4 + 2) * 32 + lane] = sumB; red[(wave * 4 + 3) * 32 + lane] = sqB;
-        }
+        if (snext < nsteps) store_lds();
         __syncthreads();
-        if (tid < 128) {
-            const int q = tid >> 5, c = tid & 31;            // q: 0 sumA, 1 sqA, 2 sumB, 3 sqB
-            double v = 0.0;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) v += (double)red[(k * 4 + q) * 32 + c];
-            const int n = n0 + (q >> 1) * 32 + c;
-            if (n < g.Cout) stats[((size_t)mb * 2 + (q & 1)) * g.Cout + n] = v;
-        }
+        s = snext;
     }
+    store_tile(g, acc0, acc1, smem, m0, n0, mb, mlimit, 0, wave, lane, tid, bias, flags, out, stats, nullptr);
 }
 
 // all layers of the network in ONE launch: table of descriptors in device memory, element index -> layer by
@@ -547,10 +746,28 @@ extern "C" int lisec_conv_forward_masked(const lisec_conv_geom* c, const float* 
         if (c->mode == 0) { if (xf) LISEC_IG(0, true, GRID_, NS_, PART_, T0_); else LISEC_IG(0, false, GRID_, NS_, PART_, T0_); } \
         else              { if (xf) LISEC_IG(1, true, GRID_, NS_, PART_, T0_); else LISEC_IG(1, false, GRID_, NS_, PART_, T0_); } \
     } while (0)
+    // 3-tap stride-1 pad-1 contraction along w over full lines: the w-halo kernel (one A tile per (kd, kh) pair)
+    const bool halo_geom = !g.row_coords && !g.ps && g.ls_w == 0 && g.KW == 3 && g.pw == 1 && g.Wi == g.Wo &&
+                           g.Wo >= BM - 2 && g.in_stride % 4 == 0;
+    const size_t lds_halo = (size_t)(AH_FLOATS + B_FLOATS) * sizeof(float);
     if ((flags & LISEC_CONV_TAG_ROOFLINE) && c->mode == 0 && !xf) {
         dim3 grid(ntiles, nnb, 1);                   // one launch, every tile, under its own symbol
-        hipLaunchKernelGGL((k_igemm<0, false, 1>), grid, dim3(kThreads), lds, st, g, in, packed_w, bias, in_bnstate,
-                           flags, out, stats_partials, 1, (float*)nullptr, 0);
+        if (halo_geom)
+            hipLaunchKernelGGL((k_igemm_halo<0, false, 1>), grid, dim3(kThreads), lds_halo, st, g, in, packed_w, bias,
+                               in_bnstate, flags, out, stats_partials);
+        else
+            hipLaunchKernelGGL((k_igemm<0, false, 1>), grid, dim3(kThreads), lds, st, g, in, packed_w, bias, in_bnstate,
+                               flags, out, stats_partials, 1, (float*)nullptr, 0);
+        LISEC_LAUNCH_CHECK();
+        return LISEC_OK;
+    }
+    if (halo_geom && plan.tile0_tail == ntiles) {    // unsliced layer
+        dim3 grid(ntiles, nnb, 1);
+#define LISEC_IH(M_, X_) hipLaunchKernelGGL((k_igemm_halo<M_, X_>), grid, dim3(kThreads), lds_halo, st, g, in, packed_w, \
+                                            bias, in_bnstate, flags, out, stats_partials)
+        if (c->mode == 0) { if (xf) LISEC_IH(0, true); else LISEC_IH(0, false); }
+        else              { if (xf) LISEC_IH(1, true); else LISEC_IH(1, false); }
+#undef LISEC_IH
         LISEC_LAUNCH_CHECK();
         return LISEC_OK;
     }

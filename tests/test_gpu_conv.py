@@ -17,7 +17,7 @@ def _close(got, ref, rtol=1e-4):
 
 
 def _conv_case(D, H, W, Cin, Cout, k, stride, pad, in_bn=False, in_relu=False, out_relu=False, bias=True,
-               stats=False, seed=0):
+               stats=False, seed=0, splitk=True):
     from lisec_amd import ops
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(D, H, W, Cin, generator=g)
@@ -48,7 +48,7 @@ def _conv_case(D, H, W, Cin, Cout, k, stride, pad, in_bn=False, in_relu=False, o
         st = torch.zeros(ops.num_mblocks(geo), 2, Cout, dtype=torch.float64, device=DEV)
     flags = (ops.IN_RELU if in_relu else 0) | (ops.OUT_RELU if out_relu else 0)
     ops.conv_forward(geo, x.to(DEV), wp, out, bias=None if b is None else b.to(DEV),
-                     in_bn=None if bn is None else bn.to(DEV), flags=flags, stats=st)
+                     in_bn=None if bn is None else bn.to(DEV), flags=flags, stats=st, splitk=splitk)
     _close(out, ref)
     if stats:
         s = st.sum(0).cpu()
@@ -129,7 +129,7 @@ def test_accumulate_and_data_gradient():
     wp = ops.pack_weights(w.to(DEV), 27, Cout, Cin, Cin * Cout, 1, Cout)       # K = out, N = in
     base = torch.randn(D, H, W, Cin, generator=g)
     dx = base.to(DEV).clone()
-    ops.conv_forward(geo, dy.to(DEV), wp, dx, flags=ops.ACCUMULATE)
+    ops.conv_forward(geo, dy.to(DEV), wp, dx, flags=ops.ACCUMULATE, splitk=False)
     _close(dx, x.grad + base)
 
 
@@ -154,3 +154,42 @@ def test_output_mask_gates_the_stored_gradient(shape):
         ops.conv_forward(geo, dy, wp, plain, splitk=splitk)
         ops.conv_forward(geo, dy, wp, gated, splitk=splitk, out_mask=mask.to(DEV))
         assert torch.equal(gated, torch.where(mask.to(DEV) > 0, plain, torch.zeros_like(plain)))
+
+
+@pytest.mark.parametrize("case", [
+    dict(D=3, H=5, W=130, Cin=64, Cout=64, k=(3, 3, 3), stride=(2, 1, 1), pad=(1, 1, 1)),          # mid1-like, tiles cross lines
+    dict(D=4, H=3, W=400, Cin=64, Cout=64, k=(3, 3, 3), stride=(1, 1, 1), pad=(0, 1, 1)),          # mid2-like
+    dict(D=1, H=7, W=200, Cin=128, Cout=128, k=(1, 3, 3), stride=(1, 1, 1), pad=(0, 1, 1), in_bn=True, in_relu=True),
+    dict(D=1, H=9, W=126, Cin=64, Cout=192, k=(1, 3, 3), stride=(1, 1, 1), pad=(0, 1, 1), out_relu=True),
+    dict(D=2, H=4, W=257, Cin=80, Cout=64, k=(3, 3, 3), stride=(2, 1, 1), pad=(1, 1, 1), in_bn=True),   # ragged channel slab
+])
+def test_w_halo_kernel_forward(case):
+    """Geometries served by k_igemm_halo (3 taps, stride 1, pad 1 along w, Wo >= 126, unsliced): one A tile per (kd, kh).
+    splitk=False keeps these small test layers unsliced, which is what selects the halo kernel."""
+    c = dict(case)
+    _conv_case(c.pop("D"), c.pop("H"), c.pop("W"), c.pop("Cin"), c.pop("Cout"), c.pop("k"), c.pop("stride"), c.pop("pad"),
+               stats=True, splitk=False, **c)
+
+
+@pytest.mark.parametrize("stride,pad,D", [((1, 1, 1), (0, 1, 1), 4), ((2, 1, 1), (1, 1, 1), 4), ((1, 1, 1), (1, 1, 1), 1)])
+def test_w_halo_kernel_data_gradient(stride, pad, D):
+    """mode 1 through the halo kernel: fragment base moves by 2 - kw; the depth stride keeps its divisibility rule."""
+    from lisec_amd import ops
+    g = torch.Generator().manual_seed(3)
+    H, W, Cin, Cout = 3, 200, 64, 64
+    k = (3, 3, 3) if D > 1 else (1, 3, 3)
+    pad = pad if D > 1 else (0, 1, 1)
+    x = torch.randn(D, H, W, Cin, generator=g, requires_grad=True)
+    w = torch.randn(*k, Cin, Cout, generator=g) * 0.1
+    y = F.conv3d(x.permute(3, 0, 1, 2)[None], w.permute(4, 3, 0, 1, 2), None, stride=stride, padding=pad)[0]
+    y = y.permute(1, 2, 3, 0)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    Do, Ho, Wo = y.shape[:3]
+    geo = ops.geom(1, (Do, Ho, Wo), (D, H, W), k, stride, pad, Cout, Cin)
+    ntaps = k[0] * k[1] * k[2]
+    wp = ops.pack_weights(w.to(DEV), ntaps, Cout, Cin, Cin * Cout, 1, Cout)
+    base = torch.randn(D, H, W, Cin, generator=g)
+    dx = base.to(DEV).clone()
+    ops.conv_forward(geo, dy.to(DEV), wp, dx, flags=ops.ACCUMULATE, splitk=False)
+    _close(dx, x.grad + base)
