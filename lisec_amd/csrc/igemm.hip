@@ -287,14 +287,14 @@ template <int MODE, bool XF, int TAG = 0>
 __global__ void __launch_bounds__(kThreads)
 k_igemm_halo(ConvGeom g, const float* __restrict__ in, const float* __restrict__ wp,
              const float* __restrict__ bias, const float* __restrict__ in_bn, int flags,
-             float* __restrict__ out, double* __restrict__ stats) {
+             float* __restrict__ out, double* __restrict__ stats, int nsplit, float* __restrict__ partial, int tile0) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sA = smem;
     float* sB = smem + AH_FLOATS;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int mb = xcd_remap(blockIdx.x, gridDim.x);
+    const int mb = tile0 + xcd_remap(blockIdx.x, gridDim.x);
     const int m0 = mb * BM;
     const int n0 = blockIdx.y * BN;
     const int mlimit = g.M;
@@ -415,11 +415,15 @@ k_igemm_halo(ConvGeom g, const float* __restrict__ in, const float* __restrict__
     const float* aLane = sA + (r_lane + (r_lane >= a ? 2 : 0)) * LDA + 4 * (lane >> 5);
     const float* bCol = sB + ((lane >> 5) * BN + (lane & 31)) * 4;
 
+    // split-K: slice z of the (kd, kh, channel slab) list -- whole A tiles, three taps each
+    const int nstage = ngroups * ncc;
+    const int s_end = nsplit > 1 ? 3 * (int)(((long long)(blockIdx.z + 1) * nstage) / nsplit) : nsteps;
+    const int s_begin = nsplit > 1 ? 3 * (int)(((long long)blockIdx.z * nstage) / nsplit) : 0;
     auto advance_to = [&](int s) -> int {
-        while (s < nsteps && !live(s)) s += 3 - s % 3;           // a dead (kd, kh) pair: skip its three taps
-        return s < nsteps ? s : nsteps;
+        while (s < s_end && !live(s)) s += 3 - s % 3;            // a dead (kd, kh) pair: skip its three taps
+        return s < s_end ? s : nsteps;
     };
-    int s = advance_to(0);
+    int s = advance_to(s_begin);
     if (s < nsteps) {
         issue_loads(s);
         store_lds();
@@ -458,7 +462,7 @@ k_igemm_halo(ConvGeom g, const float* __restrict__ in, const float* __restrict__
         __syncthreads();
         s = snext;
     }
-    store_tile(g, acc0, acc1, smem, m0, n0, mb, mlimit, 0, wave, lane, tid, bias, flags, out, stats, nullptr);
+    store_tile(g, acc0, acc1, smem, m0, n0, mb, mlimit, tile0, wave, lane, tid, bias, flags, out, stats, partial);
 }
 
 // all layers of the network in ONE launch: table of descriptors in device memory, element index -> layer by
@@ -754,36 +758,40 @@ extern "C" int lisec_conv_forward_masked(const lisec_conv_geom* c, const float* 
         dim3 grid(ntiles, nnb, 1);                   // one launch, every tile, under its own symbol
         if (halo_geom)
             hipLaunchKernelGGL((k_igemm_halo<0, false, 1>), grid, dim3(kThreads), lds_halo, st, g, in, packed_w, bias,
-                               in_bnstate, flags, out, stats_partials);
+                               in_bnstate, flags, out, stats_partials, 1, (float*)nullptr, 0);
         else
             hipLaunchKernelGGL((k_igemm<0, false, 1>), grid, dim3(kThreads), lds, st, g, in, packed_w, bias, in_bnstate,
                                flags, out, stats_partials, 1, (float*)nullptr, 0);
         LISEC_LAUNCH_CHECK();
         return LISEC_OK;
     }
-    if (halo_geom && plan.tile0_tail == ntiles) {    // unsliced layer
-        dim3 grid(ntiles, nnb, 1);
-#define LISEC_IH(M_, X_) hipLaunchKernelGGL((k_igemm_halo<M_, X_>), grid, dim3(kThreads), lds_halo, st, g, in, packed_w, \
-                                            bias, in_bnstate, flags, out, stats_partials)
-        if (c->mode == 0) { if (xf) LISEC_IH(0, true); else LISEC_IH(0, false); }
-        else              { if (xf) LISEC_IH(1, true); else LISEC_IH(1, false); }
-#undef LISEC_IH
-        LISEC_LAUNCH_CHECK();
-        return LISEC_OK;
-    }
+    // the halo kernel slices K by whole A tiles: (kd, kh, channel slab) entries
+    const int nstage = g.KD * g.KH * cdiv(g.Cin, BK);
+    const bool halo = halo_geom && plan.nsplit <= nstage;
+#define LISEC_IH(M_, X_, GRID_, NS_, PART_, T0_) hipLaunchKernelGGL((k_igemm_halo<M_, X_>), GRID_, dim3(kThreads), lds_halo, \
+        st, g, in, packed_w, bias, in_bnstate, flags, out, stats_partials, NS_, PART_, T0_)
+#define LISEC_IG_ANY(GRID_, NS_, PART_, T0_)                                                                   \
+    do {                                                                                                       \
+        if (halo) {                                                                                            \
+            if (c->mode == 0) { if (xf) LISEC_IH(0, true, GRID_, NS_, PART_, T0_); else LISEC_IH(0, false, GRID_, NS_, PART_, T0_); } \
+            else              { if (xf) LISEC_IH(1, true, GRID_, NS_, PART_, T0_); else LISEC_IH(1, false, GRID_, NS_, PART_, T0_); } \
+        } else LISEC_IG_ALL(GRID_, NS_, PART_, T0_);                                                           \
+    } while (0)
     if (plan.tile0_tail > 0) {                       // whole rounds, single pass
         dim3 grid(plan.tile0_tail, nnb, 1);
-        LISEC_IG_ALL(grid, 1, (float*)nullptr, 0);
+        LISEC_IG_ANY(grid, 1, (float*)nullptr, 0);
     }
     if (plan.tile0_tail < ntiles) {                  // K-sliced tail (or the whole small layer)
         LISEC_CHECK_ARG(((uintptr_t)out & 15) == 0, "split-K needs a 16-byte aligned output");
         float* partial = static_cast<float*>(workspace);
         const int tail = ntiles - plan.tile0_tail;
         dim3 grid(tail, nnb, plan.nsplit);
-        LISEC_IG_ALL(grid, plan.nsplit, partial, plan.tile0_tail);
+        LISEC_IG_ANY(grid, plan.nsplit, partial, plan.tile0_tail);
         hipLaunchKernelGGL(k_splitk_reduce, dim3(tail, nnb), dim3(kSkThreads), 0, st, partial, plan.nsplit, g.M, g.Cout,
                            g.CoutP, bias, flags, out, g.out_stride, stats_partials, plan.tile0_tail, g.row_count, g.out_mask);
     }
+#undef LISEC_IG_ANY
+#undef LISEC_IH
 #undef LISEC_IG_ALL
 #undef LISEC_IG
     LISEC_LAUNCH_CHECK();

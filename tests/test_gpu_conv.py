@@ -163,16 +163,18 @@ def test_output_mask_gates_the_stored_gradient(shape):
     dict(D=1, H=9, W=126, Cin=64, Cout=192, k=(1, 3, 3), stride=(1, 1, 1), pad=(0, 1, 1), out_relu=True),
     dict(D=2, H=4, W=257, Cin=80, Cout=64, k=(3, 3, 3), stride=(2, 1, 1), pad=(1, 1, 1), in_bn=True),   # ragged channel slab
 ])
-def test_w_halo_kernel_forward(case):
-    """Geometries served by k_igemm_halo (3 taps, stride 1, pad 1 along w, Wo >= 126, unsliced): one A tile per (kd, kh).
-    splitk=False keeps these small test layers unsliced, which is what selects the halo kernel."""
+@pytest.mark.parametrize("splitk", [False, True])
+def test_w_halo_kernel_forward(case, splitk):
+    """Geometries served by k_igemm_halo (3 taps, stride 1, pad 1 along w, Wo >= 126): one A tile per (kd, kh, slab).
+    splitk=True lets the plan cut these small test layers into K slices of whole A tiles + the combine kernel."""
     c = dict(case)
     _conv_case(c.pop("D"), c.pop("H"), c.pop("W"), c.pop("Cin"), c.pop("Cout"), c.pop("k"), c.pop("stride"), c.pop("pad"),
-               stats=True, splitk=False, **c)
+               stats=True, splitk=splitk, **c)
 
 
+@pytest.mark.parametrize("splitk", [False, True])
 @pytest.mark.parametrize("stride,pad,D", [((1, 1, 1), (0, 1, 1), 4), ((2, 1, 1), (1, 1, 1), 4), ((1, 1, 1), (1, 1, 1), 1)])
-def test_w_halo_kernel_data_gradient(stride, pad, D):
+def test_w_halo_kernel_data_gradient(stride, pad, D, splitk):
     """mode 1 through the halo kernel: fragment base moves by 2 - kw; the depth stride keeps its divisibility rule."""
     from lisec_amd import ops
     g = torch.Generator().manual_seed(3)
@@ -191,5 +193,5 @@ def test_w_halo_kernel_data_gradient(stride, pad, D):
     wp = ops.pack_weights(w.to(DEV), ntaps, Cout, Cin, Cin * Cout, 1, Cout)
     base = torch.randn(D, H, W, Cin, generator=g)
     dx = base.to(DEV).clone()
-    ops.conv_forward(geo, dy.to(DEV), wp, dx, flags=ops.ACCUMULATE, splitk=False)
+    ops.conv_forward(geo, dy.to(DEV), wp, dx, flags=ops.ACCUMULATE, splitk=splitk)
     _close(dx, x.grad + base)
