@@ -162,6 +162,10 @@ def test_output_mask_gates_the_stored_gradient(shape):
     dict(D=1, H=7, W=200, Cin=128, Cout=128, k=(1, 3, 3), stride=(1, 1, 1), pad=(0, 1, 1), in_bn=True, in_relu=True),
     dict(D=1, H=9, W=126, Cin=64, Cout=192, k=(1, 3, 3), stride=(1, 1, 1), pad=(0, 1, 1), out_relu=True),
     dict(D=2, H=4, W=257, Cin=80, Cout=64, k=(3, 3, 3), stride=(2, 1, 1), pad=(1, 1, 1), in_bn=True),   # ragged channel slab
+    dict(D=1, H=1, W=126, Cin=64, Cout=16, k=(1, 3, 3), stride=(1, 1, 1), pad=(0, 1, 1)),          # one partial tile, 16 columns
+    dict(D=1, H=3, W=127, Cin=64, Cout=64, k=(1, 3, 3), stride=(1, 1, 1), pad=(0, 1, 1), bias=False),
+    dict(D=1, H=3, W=128, Cin=64, Cout=64, k=(1, 3, 3), stride=(1, 1, 1), pad=(0, 1, 1)),          # tiles == lines
+    dict(D=3, H=2, W=129, Cin=64, Cout=64, k=(3, 3, 3), stride=(1, 1, 1), pad=(1, 1, 1)),
 ])
 @pytest.mark.parametrize("splitk", [False, True])
 def test_w_halo_kernel_forward(case, splitk):
