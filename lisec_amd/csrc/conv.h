@@ -18,6 +18,10 @@ struct ConvGeom {
     const int* row_count;
     // optional output mask (same layout as out): stored value = mask > 0 ? value : 0 (ReLU gradient gate)
     const float* out_mask;
+    // parity-class row order (igemm, mode 1 with stride 2 along h and w, 2D): GEMM row m = class * pc_span + q,
+    // class = (h & 1) * 2 + (w & 1), q = (h >> 1) * (Wo / 2) + (w >> 1) < pc_rows; pc_span = rows per class rounded
+    // up to whole tiles, M = 4 * pc_span.  Every tile then has ONE parity, i.e. one set of taps that divide.
+    int pc_span, pc_rows;
 };
 
 int conv_geom_check(const lisec_conv_geom* c, ConvGeom* g);
@@ -28,6 +32,18 @@ __device__ __forceinline__ int row_limit(const ConvGeom& g) {
     if (!g.row_coords) return g.M;
     const int n = *g.row_count;
     return n < g.M ? n : g.M;
+}
+#endif
+
+#ifdef __HIPCC__
+// parity-class row -> (h, w); false for the padding rows at the end of a class
+__device__ __forceinline__ bool parity_decode(const ConvGeom& g, int m, int& h, int& w) {
+    const int c = m / g.pc_span, q = m - c * g.pc_span;
+    const int Wh = g.Wo >> 1;
+    const int i = q / Wh, j = q - i * Wh;
+    h = 2 * i + (c >> 1);
+    w = 2 * j + (c & 1);
+    return q < g.pc_rows;
 }
 #endif
 
@@ -82,6 +98,9 @@ __device__ __forceinline__ RowGather row_gather(const ConvGeom& g, int m, int mo
     if (g.row_coords) {
         if (m >= *g.row_count) { r.off = 0; r.mask = 0; return r; }
         d = g.row_coords[3 * m]; h = g.row_coords[3 * m + 1]; w = g.row_coords[3 * m + 2];
+    } else if (g.pc_span) {
+        d = 0;
+        if (!parity_decode(g, m, h, w)) { r.off = 0; r.mask = 0; return r; }
     } else {
         const int HW = g.Ho * g.Wo;
         d = m / HW;
