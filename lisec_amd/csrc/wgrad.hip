@@ -211,7 +211,7 @@ constexpr int HALO_ROWS = BMW + 2;
 template <bool XF>
 __global__ void __launch_bounds__(kThreads)
 k_wgrad_halo(ConvGeom g, const float* __restrict__ in, const float* __restrict__ in_bn, int flags,
-             const float* __restrict__ dy, int nsplit, int tiles_per_split, float* __restrict__ partial) {
+             const float* __restrict__ dy, int nsplit, int tiles_per_split, float* __restrict__ partial, int flip) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sA = smem;                                  // [HALO_ROWS (+pad to 8)][64]
     float* sD = smem + (HALO_ROWS + 6) * BC;           // [128][64]
@@ -343,7 +343,9 @@ k_wgrad_halo(ConvGeom g, const float* __restrict__ in, const float* __restrict__
     const int n = n0 + (wave & 1) * 32 + (lane & 31);
 #pragma unroll
     for (int tt = 0; tt < 3; ++tt) {
-        float* base = partial + ((size_t)split * ntaps + tap0 + tt) * g.Cin * g.Cout;
+        // flip: a stride-1 transposed gather (o + p - k) run as the plain one (o - (K-1-p) + k') with k' = K-1-k
+        const int tap = flip ? ((g.KD - 1 - kd) * g.KH + (g.KH - 1 - kh)) * g.KW + (2 - tt) : tap0 + tt;
+        float* base = partial + ((size_t)split * ntaps + tap) * g.Cin * g.Cout;
         const f32x16& acc = tt == 0 ? acc0 : (tt == 1 ? acc1 : acc2);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -490,8 +492,10 @@ extern "C" size_t lisec_conv_wgrad_workspace_bytes(const lisec_conv_geom* c, int
     ConvGeom g;
     if (conv_geom_check(c, &g)) return 0;
     if (row_capacity > 0) g.M = row_capacity;
-    const size_t a = make_plan(g, c->mode, false).ws_bytes, b = make_plan(g, 1, true).ws_bytes;
-    return a > b ? a : b;
+    // the plans lisec_conv_wgrad may pick for this geometry: as given, role-swapped (dy transformed), mirrored to mode 0
+    const size_t a = make_plan(g, c->mode, false).ws_bytes, b = make_plan(g, 1, true).ws_bytes,
+                 m0 = make_plan(g, 0, false).ws_bytes;
+    return a > b ? (a > m0 ? a : m0) : (b > m0 ? b : m0);
 }
 
 extern "C" int lisec_conv_wgrad(const lisec_conv_geom* c, const float* in, const float* in_bnstate, int flags,
@@ -507,7 +511,12 @@ extern "C" int lisec_conv_wgrad(const lisec_conv_geom* c, const float* in, const
     LISEC_CHECK_ARG(in && dy && workspace && dW, "NULL pointer");
     LISEC_CHECK_ARG(g.out_stride % 4 == 0 && g.Cout % 4 == 0, "dY channels/stride must be multiples of 4");
     LISEC_CHECK_ARG(((uintptr_t)in & 15) == 0 && ((uintptr_t)dy & 15) == 0, "in/dy must be 16-byte aligned");
-    WgradPlan p = make_plan(g, c->mode, dy_bnstate != nullptr || (flags & LISEC_CONV_DY_RELU));
+    const bool dy_xf = dy_bnstate != nullptr || (flags & LISEC_CONV_DY_RELU);
+    // a transposed gather with unit strides is the plain gather with mirrored taps and pads K-1-p: the halo kernel
+    // serves it (first deconv: kernel 3, stride 1, 'same')
+    const bool flip = c->mode == 1 && g.ls_d == 0 && g.ls_h == 0 && g.ls_w == 0 && g.KW == 3 && !row_coords && !dy_xf;
+    if (flip) { g.pd = g.KD - 1 - g.pd; g.ph = g.KH - 1 - g.ph; g.pw = g.KW - 1 - g.pw; }
+    WgradPlan p = make_plan(g, flip ? 0 : c->mode, dy_xf);
     if (workspace_bytes < p.ws_bytes) {
         set_error("wgrad workspace too small: %zu < %zu", workspace_bytes, p.ws_bytes);
         return LISEC_ENOSPC;
@@ -520,10 +529,10 @@ extern "C" int lisec_conv_wgrad(const lisec_conv_geom* c, const float* in, const
         size_t lds = (size_t)((HALO_ROWS + 6) * BC + TILE_FLOATS) * sizeof(float);
         if (in_bnstate || (flags & LISEC_CONV_IN_RELU))
             hipLaunchKernelGGL(k_wgrad_halo<true>, grid, dim3(kThreads), lds, st, g, in, in_bnstate, flags, dy, p.nsplit,
-                               p.tiles_per_split, partial);
+                               p.tiles_per_split, partial, flip ? 1 : 0);
         else
             hipLaunchKernelGGL(k_wgrad_halo<false>, grid, dim3(kThreads), lds, st, g, in, in_bnstate, flags, dy, p.nsplit,
-                               p.tiles_per_split, partial);
+                               p.tiles_per_split, partial, flip ? 1 : 0);
         LISEC_LAUNCH_CHECK();
     } else {
         rc = c->mode == 0 ? launch_wgrad<0>(g, p, in, in_bnstate, flags, dy, dy_bnstate, partial, st)
