@@ -455,8 +455,8 @@ WgradPlan make_plan(const ConvGeom& g, int mode = 0, bool dy_xf = false) {
     }
     int cb = cdiv(g.Cin, BC), nb = cdiv(g.Cout, BC);
     int base = p.ngroups * cb * nb;
-    int want = cdiv(1536, base);                // ~3 rounds of the 512 resident workgroups: the (kd) groups
-                                                // skip different tiles, short workgroups even the rounds out
+    int want = cdiv(1024, base);                // ~2 rounds of the 512 resident workgroups (measured: 512-1024 blocks
+                                                // beat 1536+, whose extra slabs cost more in the reduce than they balance)
     if (want < 1) want = 1;
     if (want > p.ntiles) want = p.ntiles;
     p.tiles_per_split = cdiv(p.ntiles, want);
