@@ -490,22 +490,29 @@ k_igemm_halo(ConvGeom g, const float* __restrict__ in, const float* __restrict__
 // all layers of the network in ONE launch: table of descriptors in device memory, element index -> layer by
 // a search over the running element offsets
 __global__ void k_pack_weights_batched(const lisec_pack_desc* __restrict__ tab, int n, long long total) {
-    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    // one float4 of the packed layout (four consecutive k of one column) per thread: 16-byte coalesced stores, and
+    // for (K, N)-major sources (k_stride == N) four coalesced row reads per wave
+    for (long long i4 = blockIdx.x * 256LL + threadIdx.x; i4 < (total >> 2); i4 += (long long)gridDim.x * 256) {
+        const long long i = i4 << 2;
         int lo = 0, hi = n - 1;
         while (lo < hi) {
             const int mid = (lo + hi + 1) >> 1;
             if (tab[mid].start <= i) lo = mid; else hi = mid - 1;
         }
         const lisec_pack_desc d = tab[lo];
-        const long long e = i - d.start;
-        const int j = (int)(e & 3);
-        long long t = e >> 2;
+        long long t = (i - d.start) >> 2;
         const int nn = (int)(t % d.Np);
         t /= d.Np;
         const int kq = (int)(t % (d.Kp / 4));
         const int tap = (int)(t / (d.Kp / 4));
-        const int k = kq * 4 + j;
-        d.dst[e] = (k < d.K && nn < d.N) ? d.src[tap * d.tap_stride + k * d.k_stride + nn * d.n_stride] : 0.f;
+        const float* s0 = d.src + tap * d.tap_stride + (long long)(kq * 4) * d.k_stride + nn * d.n_stride;
+        const bool nok = nn < d.N;
+        float4 v;
+        v.x = (nok && kq * 4 + 0 < d.K) ? s0[0] : 0.f;
+        v.y = (nok && kq * 4 + 1 < d.K) ? s0[d.k_stride] : 0.f;
+        v.z = (nok && kq * 4 + 2 < d.K) ? s0[2 * d.k_stride] : 0.f;
+        v.w = (nok && kq * 4 + 3 < d.K) ? s0[3 * d.k_stride] : 0.f;
+        *reinterpret_cast<float4*>(d.dst + (i - d.start)) = v;
     }
 }
 
@@ -661,7 +668,8 @@ extern "C" int lisec_conv_pack_weights(const float* src, int ntaps, int K, int N
 extern "C" int lisec_conv_pack_weights_batched(const lisec_pack_desc* device_table, int n, long long total,
                                                lisec_stream_t stream_) {
     LISEC_CHECK_ARG(device_table && n > 0 && total > 0, "bad batched pack arguments");
-    int gb = cdiv(total, 256);
+    LISEC_CHECK_ARG(total % 4 == 0, "packed sizes are multiples of 4");
+    int gb = cdiv(total / 4, 256);
     if (gb > 8192) gb = 8192;
     hipLaunchKernelGGL(k_pack_weights_batched, dim3(gb), dim3(256), 0, static_cast<hipStream_t>(stream_),
                        device_table, n, total);
