@@ -291,7 +291,8 @@ int lisec_bn_backward(const float* dA, int da_stride, const float* y, const floa
 /* grad[i] = act[i] > 0 ? grad[i] : 0   (backward of Dense(..., 'relu'), :195) */
 int lisec_relu_mask(float* grad, const float* act, long long n, lisec_stream_t stream);
 
-/* out[c] = sum_m x[m*stride + c]  (bias gradients of Conv2DTranspose / head layers) */
+/* out[c] = sum_m x[m*stride + c]  (bias gradients of Conv2DTranspose / head layers); C divides 256, or is a
+ * multiple of 256 up to 1024 (the 768-channel concat gradient in one pass) */
 int lisec_colsum(const float* x, int stride, long long M, int C, float* out, void* workspace,
                  size_t workspace_bytes, lisec_stream_t stream);
 

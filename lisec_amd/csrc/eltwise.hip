@@ -105,18 +105,20 @@ __global__ void k_relu_mask(float* __restrict__ g, const float* __restrict__ u, 
 __global__ void __launch_bounds__(kEwThreads)
 k_colsum(const float* __restrict__ x, int stride, long long M, int C, double* __restrict__ parts) {
     __shared__ float red[kEwThreads];
-    const int cols = C < kEwThreads ? C : kEwThreads;       // C <= 256 here
+    // C <= 256 dividing 256: one slab; C a multiple of 256: blockIdx.y walks the 256-column slabs
+    const int cols = C < kEwThreads ? C : kEwThreads;
+    const int c0 = blockIdx.y * kEwThreads;
     const int c = threadIdx.x % cols, rsub = threadIdx.x / cols, rows_per_iter = kEwThreads / cols;
     float s = 0.f;
     if (rsub < rows_per_iter)
         for (long long r = (long long)blockIdx.x * rows_per_iter + rsub; r < M; r += (long long)gridDim.x * rows_per_iter)
-            s += x[r * stride + c];
+            s += x[r * stride + c0 + c];
     red[threadIdx.x] = rsub < rows_per_iter ? s : 0.f;
     __syncthreads();
     if (threadIdx.x < cols) {
         double a = 0.0;
         for (int k = 0; k < rows_per_iter; ++k) a += (double)red[k * cols + threadIdx.x];
-        parts[(size_t)blockIdx.x * C + threadIdx.x] = a;
+        parts[(size_t)blockIdx.x * C + c0 + threadIdx.x] = a;
     }
 }
 
@@ -270,18 +272,22 @@ extern "C" int lisec_relu_mask(float* grad, const float* act, long long n, lisec
 
 extern "C" int lisec_colsum(const float* x, int stride, long long M, int C, float* out, void* workspace,
                             size_t workspace_bytes, lisec_stream_t stream_) {
-    LISEC_CHECK_ARG(x && out && workspace && M > 0 && C >= 1 && C <= 256 && kEwThreads % C == 0 && stride >= C,
-                    "colsum: C must divide 256");
+    LISEC_CHECK_ARG(x && out && workspace && M > 0 && C >= 1 && stride >= C &&
+                    ((C <= 256 && kEwThreads % C == 0) || (C % 256 == 0 && C <= 1024)),
+                    "colsum: C must divide 256 or be a multiple of 256 up to 1024");
     if (workspace_bytes < lisec_eltwise_workspace_bytes()) {
         set_error("eltwise workspace too small");
         return LISEC_ENOSPC;
     }
     hipStream_t st = static_cast<hipStream_t>(stream_);
     double* parts = static_cast<double*>(workspace);
-    const int rows_per_iter = kEwThreads / C;
+    const int rows_per_iter = C < kEwThreads ? kEwThreads / C : 1;
+    const int slabs = C < kEwThreads ? 1 : C / kEwThreads;
     int nb = (int)((M + rows_per_iter - 1) / rows_per_iter);
+    const int cap = kEwBlocks * 2 * 256 / C;                 // partial rows the workspace holds
+    if (nb > cap) nb = cap;
     if (nb > kEwBlocks) nb = kEwBlocks;
-    hipLaunchKernelGGL(k_colsum, dim3(nb), dim3(kEwThreads), 0, st, x, stride, M, C, parts);
+    hipLaunchKernelGGL(k_colsum, dim3(nb, slabs), dim3(kEwThreads), 0, st, x, stride, M, C, parts);
     LISEC_LAUNCH_CHECK();
     return launch_reduce_parts(parts, nb, C, 1.0, out, nullptr, st);
 }

@@ -244,6 +244,7 @@ class LisecNet:
         self.head_dgeom = ops.geom(0, (1, Ho, Wo), (1, Ho, Wo), (1, 1, 1), (1, 1, 1), (0, 0, 0), 16, 768)
         self.packed_t["head"] = (torch.empty(ops.packed_floats(1, 16, 768), dtype=f32, device=dev), None)
         self.head_dw = torch.empty(768, 16, dtype=f32, device=dev)
+        self.up_db = torch.empty(768, dtype=f32, device=dev)
         self.head_db = torch.empty(16, dtype=f32, device=dev)
         self.wgrad_ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         # weight gradients are leaves of the backward graph: they run on a second HIP stream next to the
@@ -301,6 +302,8 @@ class LisecNet:
         p.grad_view(G, "cls.bias").copy_(self.head_db[:2])
         p.grad_view(G, "reg.bias").copy_(self.head_db[2:])
         ops.conv_forward(self.head_dgeom, d["head"], self.packed_t["head"][0], d["concat"])
+        # the three deconv bias gradients are the column sums of the concat gradient: one pass over it
+        ops.colsum(d["concat"], 768, M, 768, self.up_db)
         # ---- RPN blocks, last to first -------------------------------------------------------------
         layers = self.layers
         first_write = set()                    # gradient buffers that already hold a contribution
@@ -334,7 +337,7 @@ class LisecNet:
                     on_side(lambda L=L, c=c, dy=dy: ops.conv_wgrad(
                         c.g, a[L["src"]], dy, p.grad_view(G, c.wname), self.wgrad_ws,
                         in_bn=self.bnstate[c.in_bn], flags=ops.IN_RELU, transpose_out=True))
-                ops.colsum(dy, 768, M, 256, p.grad_view(G, c.bias))
+                p.grad_view(G, c.bias).copy_(self.up_db[256 * b:256 * (b + 1)])
                 dgrad_into(c, dy, L["src"])
             elif L["kind"] == "conv":
                 dst = L["dst"]
