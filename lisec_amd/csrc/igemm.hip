@@ -297,22 +297,24 @@ k_igemm(ConvGeom g, const float* __restrict__ in, const float* __restrict__ wp,
 // gradients, Wo >= 126).  The three kw taps of one (kd, kh) pair read the SAME input line shifted by one position, so
 // the A tile is staged once per (kd, kh, channel slab) as the tile's line segment(s) plus one halo column on each
 // side, and tap kw only moves the fragment base by one LDS row: a third of the global loads, LDS writes and
-// BatchNormalization-on-load work of k_igemm per MFMA.  A 128-row tile touches at most two output lines (Wo >= 126):
+// BatchNormalization-on-load work of k_igemm per MFMA.  A 128-row tile touches at most NSEG output lines (NSEG = 2 for
+// Wo >= 126, 3 for Wo >= 64; narrower maps measured no gain and stay on k_igemm):
 //     halo row j <  a + 2 : line L0,     w_in = w0 - 1 + j              (a = rows of the tile on line L0)
-//     halo row j >= a + 2 : line L0 + 1, w_in = j - (a + 2) - 1
-// and output row r reads halo row  r + (r >= a ? 2 : 0) + f(kw),  f = kw (mode 0) or 2 - kw (mode 1).  Zero padding in w
-// is simply a zero halo row; the (kd, kh) validity is per line, i.e. wave-uniform.  Unsliced launches only.
-constexpr int HALO_MAX_ROWS = BM + 4;                          // two segments, two halo columns each
-constexpr int AH_FLOATS = HALO_MAX_ROWS * LDA;                 // 8976 floats: with the W slab 52 288 B, 3 per CU
+//     halo row j >= a + 2 : line L0 + k, w_in = (j - (a + 2)) % (Wo + 2) - 1,   k = 1 + (j - (a + 2)) / (Wo + 2)
+// and output row r (on segment k) reads halo row  r + 2k + f(kw),  f = kw (mode 0) or 2 - kw (mode 1).  Zero padding
+// in w is simply a zero halo row; the (kd, kh) validity is per line, i.e. wave-uniform.  K slices are whole A tiles.
+constexpr int halo_rows(int nseg) { return BM + 2 * nseg; }     // segments + two halo columns each
+constexpr size_t halo_lds_bytes(int nseg) { return (size_t)(halo_rows(nseg) * LDA + B_FLOATS) * sizeof(float); }   // <= 52 832 B: 3 per CU
 
-template <int MODE, bool XF, int TAG = 0>
+template <int MODE, bool XF, int TAG = 0, int NSEG = 2>
 __global__ void __launch_bounds__(kThreads)
 k_igemm_halo(ConvGeom g, const float* __restrict__ in, const float* __restrict__ wp,
              const float* __restrict__ bias, const float* __restrict__ in_bn, int flags,
              float* __restrict__ out, double* __restrict__ stats, int nsplit, float* __restrict__ partial, int tile0) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int HALO_MAX_ROWS = halo_rows(NSEG);
     float* sA = smem;
-    float* sB = smem + AH_FLOATS;
+    float* sB = smem + HALO_MAX_ROWS * LDA;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -321,27 +323,29 @@ k_igemm_halo(ConvGeom g, const float* __restrict__ in, const float* __restrict__
     const int n0 = blockIdx.y * BN;
     const int mlimit = g.M;
 
-    // ---- the (at most two) output lines of this tile -----------------------------------------------
+    // ---- the (at most NSEG) output lines of this tile ----------------------------------------------
     const int L0 = m0 / g.Wo, w0 = m0 - L0 * g.Wo;
     const int a = g.Wo - w0 < BM ? g.Wo - w0 : BM;               // rows on line L0
     const int nlines = g.Do * g.Ho;
-    const int nrows = a < BM ? BM + 4 : BM + 2;                  // staged halo rows
-    const int d0 = L0 / g.Ho, h0 = L0 - d0 * g.Ho;
-    const int L1 = L0 + 1, d1 = L1 / g.Ho, h1 = L1 - d1 * g.Ho;
-    const bool line1 = a < BM && L1 < nlines;
+    const int nseg = a < BM ? 1 + (BM - a + g.Wo - 1) / g.Wo : 1;
+    const int nrows = BM + 2 * nseg;                             // staged halo rows
 
     // ---- staging map of this thread: halo row j = p*16 + tid/16, 16-byte piece tid%16 ----------------
     const int piece = tid & 15;
     int woff[9];                                                 // w_in * in_stride + piece*4, < 0: never valid
-    unsigned segbits = 0;                                        // bit p: row p belongs to line L0 + 1
+    unsigned segbits = 0;                                        // 2 bits per p: the segment of row p
 #pragma unroll
     for (int p = 0; p < 9; ++p) {
         const int j = p * 16 + (tid >> 4);
-        const bool s1 = j >= a + 2;
-        const int w_in = s1 ? j - (a + 2) - 1 : w0 - 1 + j;
+        int sg = 0, w_in = w0 - 1 + j;
+        if (j >= a + 2) {
+            const int jj = j - (a + 2);
+            sg = 1 + jj / (g.Wo + 2);
+            w_in = jj - (sg - 1) * (g.Wo + 2) - 1;
+        }
         const bool ok = j < nrows && w_in >= 0 && w_in < g.Wi;
         woff[p] = ok ? w_in * g.in_stride + piece * 4 : -1;
-        segbits |= s1 ? (1u << p) : 0u;
+        segbits |= (unsigned)(sg & 3) << (2 * p);
     }
 
     const int ncc = (g.Cin + BK - 1) / BK;
@@ -363,10 +367,17 @@ k_igemm_halo(ConvGeom g, const float* __restrict__ in, const float* __restrict__
         const int gi = t / ncc;
         kh = gi % g.KH; kd = gi / g.KH;
     };
+    auto seg_base = [&](int k, int kd, int kh) -> int {          // source line of segment k, or -1
+        const int L = L0 + k, d = L / g.Ho, h = L - d * g.Ho;
+        return line_base(d, h, kd, kh, k < nseg && L < nlines);
+    };
     auto live = [&](int s) -> bool {
         int kd, kh, cc, kw;
         group_of(s, kd, kh, cc, kw);
-        return line_base(d0, h0, kd, kh, true) >= 0 || line_base(d1, h1, kd, kh, line1) >= 0;
+        bool any = false;
+#pragma unroll
+        for (int k = 0; k < NSEG; ++k) any = any || seg_base(k, kd, kh) >= 0;
+        return any;
     };
 
     float4 ra[9];
@@ -382,11 +393,12 @@ k_igemm_halo(ConvGeom g, const float* __restrict__ in, const float* __restrict__
         if (staged_a) {
             const int c = cc * BK + piece * 4;
             const bool cok = c < g.Cin;
-            const int b0 = line_base(d0, h0, kd, kh, true), b1 = line_base(d1, h1, kd, kh, line1);
+            const int sb0 = seg_base(0, kd, kh), sb1 = seg_base(1, kd, kh), sb2 = NSEG > 2 ? seg_base(2, kd, kh) : -1;
             valid_mask = 0;
 #pragma unroll
             for (int p = 0; p < 9; ++p) {
-                const int lb = (segbits >> p) & 1 ? b1 : b0;
+                const unsigned sg = (segbits >> (2 * p)) & 3u;
+                const int lb = sg == 0 ? sb0 : (sg == 1 || NSEG == 2 ? sb1 : sb2);
                 const bool ok = cok && woff[p] >= 0 && lb >= 0;
                 const int off = ok ? lb + woff[p] + cc * BK : 0;        // branch-free: invalid pieces read element 0
                 ra[p] = *reinterpret_cast<const float4*>(in + off);
@@ -434,7 +446,8 @@ k_igemm_halo(ConvGeom g, const float* __restrict__ in, const float* __restrict__
 
     f32x16 acc0 = {0}, acc1 = {0};
     const int r_lane = wave * 32 + (lane & 31);
-    const float* aLane = sA + (r_lane + (r_lane >= a ? 2 : 0)) * LDA + 4 * (lane >> 5);
+    const int seg_lane = r_lane < a ? 0 : 1 + (r_lane - a) / g.Wo;
+    const float* aLane = sA + (r_lane + 2 * seg_lane) * LDA + 4 * (lane >> 5);
     const float* bCol = sB + ((lane >> 5) * BN + (lane & 31)) * 4;
 
     // split-K: slice z of the (kd, kh, channel slab) list -- whole A tiles, three taps each
@@ -808,13 +821,14 @@ extern "C" int lisec_conv_forward_masked(const lisec_conv_geom* c, const float* 
     } while (0)
     // 3-tap stride-1 pad-1 contraction along w over full lines: the w-halo kernel (one A tile per (kd, kh) pair)
     const bool halo_geom = !g.row_coords && !g.ps && g.ls_w == 0 && g.KW == 3 && g.pw == 1 && g.Wi == g.Wo &&
-                           g.Wo >= BM - 2 && g.in_stride % 4 == 0;
-    const size_t lds_halo = (size_t)(AH_FLOATS + B_FLOATS) * sizeof(float);
+                           g.Wo >= 64 && g.in_stride % 4 == 0;       // <= 3 lines per 128-row tile
+    const bool halo3 = g.Wo < BM - 2;                                // more than two lines per tile possible
+    const size_t lds_halo = halo_lds_bytes(halo3 ? 3 : 2);
     if ((flags & LISEC_CONV_TAG_ROOFLINE) && c->mode == 0 && !xf) {
         dim3 grid(ntiles, nnb, 1);                   // one launch, every tile, under its own symbol
-        if (halo_geom)
-            hipLaunchKernelGGL((k_igemm_halo<0, false, 1>), grid, dim3(kThreads), lds_halo, st, g, in, packed_w, bias,
-                               in_bnstate, flags, out, stats_partials, 1, (float*)nullptr, 0);
+        if (halo_geom && !halo3)
+            hipLaunchKernelGGL((k_igemm_halo<0, false, 1, 2>), grid, dim3(kThreads), halo_lds_bytes(2), st, g, in, packed_w,
+                               bias, in_bnstate, flags, out, stats_partials, 1, (float*)nullptr, 0);
         else
             hipLaunchKernelGGL((k_igemm<0, false, 1>), grid, dim3(kThreads), lds, st, g, in, packed_w, bias, in_bnstate,
                                flags, out, stats_partials, 1, (float*)nullptr, 0);
@@ -824,8 +838,13 @@ extern "C" int lisec_conv_forward_masked(const lisec_conv_geom* c, const float* 
     // the halo kernel slices K by whole A tiles: (kd, kh, channel slab) entries
     const int nstage = g.KD * g.KH * cdiv(g.Cin, BK);
     const bool halo = halo_geom && plan.nsplit <= nstage;
-#define LISEC_IH(M_, X_, GRID_, NS_, PART_, T0_) hipLaunchKernelGGL((k_igemm_halo<M_, X_>), GRID_, dim3(kThreads), lds_halo, \
-        st, g, in, packed_w, bias, in_bnstate, flags, out, stats_partials, NS_, PART_, T0_)
+#define LISEC_IH(M_, X_, GRID_, NS_, PART_, T0_)                                                                 \
+    do {                                                                                                         \
+        if (halo3) hipLaunchKernelGGL((k_igemm_halo<M_, X_, 0, 3>), GRID_, dim3(kThreads), lds_halo, st, g, in, packed_w, \
+                                      bias, in_bnstate, flags, out, stats_partials, NS_, PART_, T0_);            \
+        else hipLaunchKernelGGL((k_igemm_halo<M_, X_, 0, 2>), GRID_, dim3(kThreads), lds_halo, st, g, in, packed_w, bias, \
+                                in_bnstate, flags, out, stats_partials, NS_, PART_, T0_);                        \
+    } while (0)
 #define LISEC_IG_ANY(GRID_, NS_, PART_, T0_)                                                                   \
     do {                                                                                                       \
         if (halo) {                                                                                            \

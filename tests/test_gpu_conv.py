@@ -166,6 +166,9 @@ def test_output_mask_gates_the_stored_gradient(shape):
     dict(D=1, H=3, W=127, Cin=64, Cout=64, k=(1, 3, 3), stride=(1, 1, 1), pad=(0, 1, 1), bias=False),
     dict(D=1, H=3, W=128, Cin=64, Cout=64, k=(1, 3, 3), stride=(1, 1, 1), pad=(0, 1, 1)),          # tiles == lines
     dict(D=3, H=2, W=129, Cin=64, Cout=64, k=(3, 3, 3), stride=(1, 1, 1), pad=(1, 1, 1)),
+    dict(D=1, H=50, W=100, Cin=128, Cout=128, k=(1, 3, 3), stride=(1, 1, 1), pad=(0, 1, 1), in_bn=True, in_relu=True),  # 3 lines / tile
+    dict(D=1, H=25, W=50, Cin=256, Cout=256, k=(1, 3, 3), stride=(1, 1, 1), pad=(0, 1, 1), in_bn=True, in_relu=True),   # narrower than 64: generic kernel
+    dict(D=2, H=7, W=43, Cin=64, Cout=64, k=(3, 3, 3), stride=(1, 1, 1), pad=(1, 1, 1)),                                # generic kernel
 ])
 @pytest.mark.parametrize("splitk", [False, True])
 def test_w_halo_kernel_forward(case, splitk):
@@ -177,12 +180,13 @@ def test_w_halo_kernel_forward(case, splitk):
 
 
 @pytest.mark.parametrize("splitk", [False, True])
+@pytest.mark.parametrize("W", [200, 100])
 @pytest.mark.parametrize("stride,pad,D", [((1, 1, 1), (0, 1, 1), 4), ((2, 1, 1), (1, 1, 1), 4), ((1, 1, 1), (1, 1, 1), 1)])
-def test_w_halo_kernel_data_gradient(stride, pad, D, splitk):
+def test_w_halo_kernel_data_gradient(stride, pad, D, splitk, W):
     """mode 1 through the halo kernel: fragment base moves by 2 - kw; the depth stride keeps its divisibility rule."""
     from lisec_amd import ops
     g = torch.Generator().manual_seed(3)
-    H, W, Cin, Cout = 3, 200, 64, 64
+    H, Cin, Cout = 3 if W == 200 else 11, 64, 64
     k = (3, 3, 3) if D > 1 else (1, 3, 3)
     pad = pad if D > 1 else (0, 1, 1)
     x = torch.randn(D, H, W, Cin, generator=g, requires_grad=True)
