@@ -22,6 +22,7 @@ struct ConvGeom {
     // class = (h & 1) * 2 + (w & 1), q = (h >> 1) * (Wo / 2) + (w >> 1) < pc_rows; pc_span = rows per class rounded
     // up to whole tiles, M = 4 * pc_span.  Every tile then has ONE parity, i.e. one set of taps that divide.
     int pc_span, pc_rows;
+    int pointwise;           // 1x1x1 taps, unit strides, no padding, dense rows: row m reads position m
 };
 
 int conv_geom_check(const lisec_conv_geom* c, ConvGeom* g);
@@ -94,6 +95,11 @@ __device__ __forceinline__ int axis_mask(int o, int K, int ls, int pad, int n_in
 __device__ __forceinline__ RowGather row_gather(const ConvGeom& g, int m, int mode, int lane_elem_off) {
     RowGather r;
     if (m >= g.M) { r.off = 0; r.mask = 0; return r; }
+    if (g.pointwise) {                        // 1x1x1, unit stride, no padding: source position == output position
+        r.off = m * g.in_stride + lane_elem_off;
+        r.mask = 1 | (1 << 4) | (1 << 8);
+        return r;
+    }
     int d, h, w;
     if (g.row_coords) {
         if (m >= *g.row_count) { r.off = 0; r.mask = 0; return r; }

@@ -652,6 +652,8 @@ int conv_geom_check(const lisec_conv_geom* c, ConvGeom* g) {
     g->ps = c->ps; g->ps_channels = c->ps_channels;
     g->row_coords = nullptr; g->row_count = nullptr; g->out_mask = nullptr;
     g->pc_span = 0; g->pc_rows = 0;
+    g->pointwise = c->KD * c->KH * c->KW == 1 && ld == 0 && lh == 0 && lw == 0 && c->pd == 0 && c->ph == 0 && c->pw == 0 &&
+                   c->Di == c->Do && c->Hi == c->Ho && c->Wi == c->Wo;
     return 0;
 }
 
@@ -801,7 +803,7 @@ extern "C" int lisec_conv_forward_masked(const lisec_conv_geom* c, const float* 
     if (row_coords) {
         LISEC_CHECK_ARG(row_count && row_capacity > 0 && !stats_partials && !c->ps,
                         "row list needs a device count, a capacity, and no stats / pixel-shuffle");
-        g.row_coords = row_coords; g.row_count = row_count; g.M = row_capacity;
+        g.row_coords = row_coords; g.row_count = row_count; g.M = row_capacity; g.pointwise = 0;
         // K slicing is planned for the capacity; workgroups past the device-side row count exit at once
     }
     LISEC_CHECK_ARG(in && packed_w && out, "NULL tensor pointer");

@@ -506,7 +506,7 @@ extern "C" int lisec_conv_wgrad(const lisec_conv_geom* c, const float* in, const
     if (int rc = conv_geom_check(c, &g)) return rc;
     if (row_coords) {
         LISEC_CHECK_ARG(row_count && row_capacity > 0, "row list needs a device count and a capacity");
-        g.row_coords = row_coords; g.row_count = row_count; g.M = row_capacity;
+        g.row_coords = row_coords; g.row_count = row_count; g.M = row_capacity; g.pointwise = 0;
     }
     LISEC_CHECK_ARG(in && dy && workspace && dW, "NULL pointer");
     LISEC_CHECK_ARG(g.out_stride % 4 == 0 && g.Cout % 4 == 0, "dY channels/stride must be multiples of 4");
