@@ -154,8 +154,23 @@ k_igemm(ConvGeom g, const float* __restrict__ in, const float* __restrict__ wp,
     // ---- rows this thread stages: r = p*16 + tid/16, 16-byte piece tid%16 ----------------------
     const int piece = tid & 15;
     RowGather rows[8];
+    {
+        // each gather descriptor is computed ONCE (thread r < 128 owns row r: two integer divisions + three axis masks) and
+        // handed to the 16 threads that stage that row through LDS, instead of 8 descriptors per thread
+        int2* shared_rows = reinterpret_cast<int2*>(smem);
+        if (tid < BM) {
+            const RowGather r = row_gather(g, m0 + tid, MODE, 0);
+            shared_rows[tid] = make_int2(r.off, r.mask);
+        }
+        __syncthreads();
 #pragma unroll
-    for (int p = 0; p < 8; ++p) rows[p] = row_gather(g, m0 + p * 16 + (tid >> 4), MODE, piece * 4);
+        for (int p = 0; p < 8; ++p) {
+            const int2 v = shared_rows[p * 16 + (tid >> 4)];
+            rows[p].off = v.x + piece * 4;
+            rows[p].mask = v.y;
+        }
+        __syncthreads();
+    }
     // tile-uniform depth range for whole-tap skipping
     const int mlast = (m0 + BM - 1 < g.M ? m0 + BM - 1 : g.M - 1);
     const int d_first = g.pc_span ? 0 : m0 / HW, d_last = g.pc_span ? 0 : mlast / HW;
