@@ -188,7 +188,7 @@ def main():
         tf = flops / (ms * 1e-3) / 1e12
         # traffic: HBM bytes per launch from rocprofv3 PMC passes of this kernel (profiles/r01_pmc_summary.txt):
         # FETCH_SIZE 124 820 KiB (x2, the gfx950 correction for wide coalesced reads) + WRITE_SIZE 82 500 KiB
-        roofline = dict(bound="mfma", kernel="k_igemm_halo<0,false,1> mid1 Conv3D 64->64 k3 s(2,1,1)", achieved=tf,
+        roofline = dict(bound="mfma", kernel="k_igemm_halo<0,false,1,2> mid1 Conv3D 64->64 k3 s(2,1,1)", achieved=tf,
                         peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s", frac=tf / PEAK_F32_MFMA_TFLOPS,
                         traffic=(2 * 124820.0 + 82500.0) * 1024, traffic_unit="bytes/launch (PMC, offline)",
                         us_per_launch=ms * 1e3, flops_per_launch=flops)
