@@ -205,23 +205,26 @@ k_wgrad(ConvGeom g, const float* __restrict__ in, const float* __restrict__ in_b
 // three kw taps read the same source line shifted by one position, so the source rows w0-pw .. w0-pw+len+1 are
 // staged ONCE (zero outside the map) and tap kw reads LDS rows j+kw: half the global->LDS traffic of the generic
 // kernel, no per-row address arithmetic, and 3x longer MFMA runs between barriers.  The contraction runs over the
-// rows, so a short tail tile (W' = 400 = 3*128 + 16) only shortens the loop.
-constexpr int HALO_ROWS = BMW + 2;
+// rows; the tiles of a line are made equal (W' = 400 -> 4 x 100 rows) so that no short tail tile pays a full staging round.
 
 template <bool XF>
 __global__ void __launch_bounds__(kThreads)
 k_wgrad_halo(ConvGeom g, const float* __restrict__ in, const float* __restrict__ in_bn, int flags,
-             const float* __restrict__ dy, int nsplit, int tiles_per_split, float* __restrict__ partial, int flip) {
+             const float* __restrict__ dy, int nsplit, int tiles_per_split, float* __restrict__ partial, int flip,
+             int LT) {
+    // LT <= 128: rows per tile, chosen by the host so that the tiles of one line are equal (W' = 400 -> 4 x 100) and,
+    // with DR = LT rounded up to 8, the workgroup's LDS is (2 DR + 2) x 256 B: 53 760 B at LT = 100, three per CU
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* sA = smem;                                  // [HALO_ROWS (+pad to 8)][64]
-    float* sD = smem + (HALO_ROWS + 6) * BC;           // [128][64]
+    const int DR = (LT + 7) & ~7;
+    float* sA = smem;                                  // [DR + 2][64]: halo rows, zero beyond len + 2
+    float* sD = smem + (DR + 2) * BC;                  // [DR][64]: dY rows, zero beyond len
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ngroups = g.KD * g.KH;
     const int split = blockIdx.x / ngroups, group = blockIdx.x - split * ngroups;
     const int kd = group / g.KH, kh = group - kd * g.KH;
     const int c0 = blockIdx.y * BC, n0 = blockIdx.z * BC;
-    const int tpl = (g.Wo + BMW - 1) / BMW;            // tiles per output line
+    const int tpl = (g.Wo + LT - 1) / LT;              // tiles per output line
     const int ntiles = g.Do * g.Ho * tpl;
     const int t_begin = split * tiles_per_split;
     const int t_end = t_begin + tiles_per_split < ntiles ? t_begin + tiles_per_split : ntiles;
@@ -244,8 +247,8 @@ k_wgrad_halo(ConvGeom g, const float* __restrict__ in, const float* __restrict__
     // tile -> (output line, w0, len, source line offset or -1)
     auto tile_info = [&](int tile, int& w0, int& len, long long& src_line, long long& dy_line) -> bool {
         const int line = tile / tpl;
-        w0 = (tile - line * tpl) * BMW;
-        len = g.Wo - w0 < BMW ? g.Wo - w0 : BMW;
+        w0 = (tile - line * tpl) * LT;
+        len = g.Wo - w0 < LT ? g.Wo - w0 : LT;
         const int d = line / g.Ho, h = line - d * g.Ho;
         const int sd = (d << g.ls_d) - g.pd + kd, sh = (h << g.ls_h) - g.ph + kh;
         dy_line = (long long)line * g.Wo;
@@ -284,7 +287,7 @@ k_wgrad_halo(ConvGeom g, const float* __restrict__ in, const float* __restrict__
 #pragma unroll
         for (int p = 0; p < 9; ++p) {
             const int s_ = p * 16 + rsub;
-            if (s_ < HALO_ROWS + 6) {
+            if (s_ < DR + 2) {
                 float4 v = ra[p];
                 const bool ok = (amask >> p) & 1;
                 if (XF) {
@@ -300,7 +303,7 @@ k_wgrad_halo(ConvGeom g, const float* __restrict__ in, const float* __restrict__
         }
 #pragma unroll
         for (int p = 0; p < 8; ++p)
-            *reinterpret_cast<float4*>(sD + (p * 16 + rsub) * BC + piece * 4) = rd[p];
+            if (p * 16 + rsub < DR) *reinterpret_cast<float4*>(sD + (p * 16 + rsub) * BC + piece * 4) = rd[p];
         cur_len = nxt_len;
     };
 
@@ -436,6 +439,7 @@ k_wgrad_reduce_lanes(const float* __restrict__ partial, int nsplit, int ntaps, i
 
 struct WgradPlan {
     int TG, ngroups, nsplit, tiles_per_split, ntiles;
+    int LT;              // halo kernel: rows per tile
     bool halo;
     size_t ws_bytes;
 };
@@ -451,7 +455,8 @@ WgradPlan make_plan(const ConvGeom& g, int mode = 0, bool dy_xf = false) {
     if (p.halo) {
         p.TG = 3;
         p.ngroups = g.KD * g.KH;
-        p.ntiles = g.Do * g.Ho * cdiv(g.Wo, BMW);
+        p.LT = cdiv(g.Wo, cdiv(g.Wo, BMW));         // equal tiles per line
+        p.ntiles = g.Do * g.Ho * cdiv(g.Wo, p.LT);
     }
     int cb = cdiv(g.Cin, BC), nb = cdiv(g.Cout, BC);
     int base = p.ngroups * cb * nb;
@@ -526,13 +531,14 @@ extern "C" int lisec_conv_wgrad(const lisec_conv_geom* c, const float* in, const
     int rc = 0;
     if (p.halo) {
         dim3 grid(p.nsplit * p.ngroups, cdiv(g.Cin, BC), cdiv(g.Cout, BC));
-        size_t lds = (size_t)((HALO_ROWS + 6) * BC + TILE_FLOATS) * sizeof(float);
+        const int DR = (p.LT + 7) & ~7;
+        size_t lds = (size_t)(2 * DR + 2) * BC * sizeof(float);
         if (in_bnstate || (flags & LISEC_CONV_IN_RELU))
             hipLaunchKernelGGL(k_wgrad_halo<true>, grid, dim3(kThreads), lds, st, g, in, in_bnstate, flags, dy, p.nsplit,
-                               p.tiles_per_split, partial, flip ? 1 : 0);
+                               p.tiles_per_split, partial, flip ? 1 : 0, p.LT);
         else
             hipLaunchKernelGGL(k_wgrad_halo<false>, grid, dim3(kThreads), lds, st, g, in, in_bnstate, flags, dy, p.nsplit,
-                               p.tiles_per_split, partial, flip ? 1 : 0);
+                               p.tiles_per_split, partial, flip ? 1 : 0, p.LT);
         LISEC_LAUNCH_CHECK();
     } else {
         rc = c->mode == 0 ? launch_wgrad<0>(g, p, in, in_bnstate, flags, dy, dy_bnstate, partial, st)
