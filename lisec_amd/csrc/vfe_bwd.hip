@@ -23,7 +23,7 @@
 namespace lisec {
 namespace {
 
-constexpr int kBwdBlocks = 256;
+constexpr int kBwdBlocks = 512;
 constexpr int kMaxRows = 64;            // rows of one voxel (<= T <= 64)
 
 struct Vox {
