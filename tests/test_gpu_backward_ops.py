@@ -155,3 +155,28 @@ def test_relu_mask_colsum_loss_sgd():
         ops.sgd_nesterov_step(wd, gr.to(DEV), vd, lr_t, 0.9)
     _close(wd, w, rtol=1e-6)
     _close(vd, v, rtol=1e-6)
+
+
+@pytest.mark.parametrize("M", [1250, 5000, 9001])
+@pytest.mark.parametrize("C,relu", [(128, True), (256, True), (64, False)])
+def test_bn_backward_in_place_without_bias(M, C, relu):
+    """The RPN layers' call: no conv-bias gradient, dy written over dA (the sizes of RPN blocks 3 and 2, and a ragged one)."""
+    from lisec_amd import ops
+    g = torch.Generator().manual_seed(C + M)
+    y = (torch.randn(M, C, generator=g) * 2 + 0.5).double().requires_grad_(True)
+    gamma = (torch.rand(C, generator=g) + 0.5).double().requires_grad_(True)
+    beta = torch.randn(C, generator=g).double().requires_grad_(True)
+    mean = y.mean(0)
+    var = ((y - mean) ** 2).mean(0)
+    inv = gamma * torch.rsqrt(var + 1e-3)
+    z = y * inv + (beta - mean * inv)
+    a = F.relu(z) if relu else z
+    dA = torch.randn(M, C, generator=g)
+    a.backward(dA.double())
+    st = torch.cat([inv, beta - mean * inv, mean, torch.rsqrt(var + 1e-3)]).float().detach().to(DEV)
+    dg, db = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    buf = dA.to(DEV).clone()
+    ops.bn_backward(buf, C, y.detach().float().to(DEV), st, M, C, relu, dg, db, buf)
+    _close(buf, y.grad, rtol=2e-4)
+    _close(dg, gamma.grad, rtol=2e-4)
+    _close(db, beta.grad, rtol=2e-4)
