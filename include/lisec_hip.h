@@ -220,6 +220,26 @@ int lisec_conv_num_mblocks(const lisec_conv_geom* g);
  */
 size_t lisec_conv_forward_workspace_bytes(const lisec_conv_geom* g);
 size_t lisec_conv_forward_rows_workspace_bytes(const lisec_conv_geom* g, int row_capacity);
+/* lisec_conv_forward with optional extras (NULL fields = off):
+ *   out_mask     the output gate of lisec_conv_forward_masked
+ *   bwd_y, bwd_bnstate, bwd_relu
+ *                the call computes a gradient dA that is about to cross a BatchNormalization(+ReLU) backwards:
+ *                bwd_y is that layer's raw output (positions x Cout, row stride Cout), bwd_bnstate its bnstate.
+ *                stats_partials (required; lisec_conv_num_mblocks_bwd(g) rows) then receives per tile
+ *                (sum dz, sum dz*yhat), dz = dA * (bwd_relu ? bn(y) > 0 : 1), yhat = (y - mean)*invstd -- pass 1 of
+ *                lisec_bn_backward, folded into the store; finish with lisec_bn_backward_apply. */
+typedef struct lisec_conv_extras {
+    const float* out_mask;
+    const float* bwd_y;
+    const float* bwd_bnstate;
+    int bwd_relu;
+} lisec_conv_extras;
+int lisec_conv_num_mblocks_bwd(const lisec_conv_geom* g);
+int lisec_conv_forward_ex(const lisec_conv_geom* g, const float* in, const float* packed_w, const float* bias,
+                          const float* in_bnstate, int flags, float* out, const lisec_conv_extras* extras,
+                          double* stats_partials, void* workspace, size_t workspace_bytes,
+                          const int32_t* row_coords, const int32_t* row_count, int row_capacity,
+                          lisec_stream_t stream);
 /* lisec_conv_forward with an output gate: stored value = out_mask[m][n] > 0 ? value : 0, out_mask laid out like
  * `out` (same stride).  The data gradient of a layer whose consumer-side activation was a ReLU is gated by that
  * activation while it is stored (what lisec_relu_mask does in a separate pass).  out_mask NULL = no gate. */
@@ -287,6 +307,12 @@ size_t lisec_eltwise_workspace_bytes(void);
 int lisec_bn_backward(const float* dA, int da_stride, const float* y, const float* bnstate, long long M, int C,
                       int relu, float* dgamma, float* dbeta, float* dbias, float* dy, void* workspace,
                       size_t workspace_bytes, lisec_stream_t stream);
+/* Passes 2-3 of lisec_bn_backward for a gradient whose pass-1 partials (sum dz, sum dz*yhat per tile) were produced by
+ * lisec_conv_forward_ex: sums `partials` (double[nparts][2][C], index order), writes dgamma / dbeta and
+ * dy = scale * (dz - mean(dz) - yhat * mean(dz*yhat)); dy may alias dA. */
+int lisec_bn_backward_apply(const float* dA, int da_stride, const float* y, const float* bnstate, long long M, int C,
+                            int relu, const double* partials, int nparts, float* dgamma, float* dbeta, float* dy,
+                            void* workspace, size_t workspace_bytes, lisec_stream_t stream);
 
 /* grad[i] = act[i] > 0 ? grad[i] : 0   (backward of Dense(..., 'relu'), :195) */
 int lisec_relu_mask(float* grad, const float* act, long long n, lisec_stream_t stream);

@@ -31,6 +31,11 @@ class RpnCfg(Structure):
                 ("anchors", (c_double * 4) * 2)]
 
 
+class ConvExtras(ctypes.Structure):           # lisec_conv_extras
+    _fields_ = [("out_mask", ctypes.c_void_p), ("bwd_y", ctypes.c_void_p), ("bwd_bnstate", ctypes.c_void_p),
+                ("bwd_relu", ctypes.c_int)]
+
+
 class PackDesc(Structure):
     _fields_ = [("src", c_void_p), ("dst", c_void_p), ("tap_stride", ctypes.c_longlong),
                 ("k_stride", ctypes.c_longlong), ("n_stride", ctypes.c_longlong), ("start", ctypes.c_longlong),
@@ -100,6 +105,13 @@ def _declare(lib):
     lib.lisec_conv_num_mblocks.argtypes = [POINTER(ConvGeom)]
     lib.lisec_conv_forward.restype = c_int
     lib.lisec_conv_forward.argtypes = [POINTER(ConvGeom), P, P, P, P, c_int, P, P, P, c_size_t, P, P, c_int, P]
+    lib.lisec_conv_forward_ex.restype = c_int
+    lib.lisec_conv_forward_ex.argtypes = [POINTER(ConvGeom), P, P, P, P, c_int, P, POINTER(ConvExtras), P, P, c_size_t, P, P,
+                                          c_int, P]
+    lib.lisec_conv_num_mblocks_bwd.restype = c_int
+    lib.lisec_conv_num_mblocks_bwd.argtypes = [POINTER(ConvGeom)]
+    lib.lisec_bn_backward_apply.restype = c_int
+    lib.lisec_bn_backward_apply.argtypes = [P, c_int, P, P, LL, c_int, c_int, P, c_int, P, P, P, P, c_size_t, P]
     lib.lisec_conv_forward_masked.restype = c_int
     lib.lisec_conv_forward_masked.argtypes = [POINTER(ConvGeom), P, P, P, P, c_int, P, P, P, P, c_size_t, P, P, c_int, P]
     lib.lisec_conv_forward_workspace_bytes.restype = c_size_t

@@ -23,6 +23,11 @@ struct ConvGeom {
     // up to whole tiles, M = 4 * pc_span.  Every tile then has ONE parity, i.e. one set of taps that divide.
     int pc_span, pc_rows;
     int pointwise;           // 1x1x1 taps, unit strides, no padding, dense rows: row m reads position m
+    // optional BatchNormalization-backward statistics of the stored gradient (see lisec_conv_extras): the per-tile
+    // partials become (sum dz, sum dz*yhat) with dz = stored value * (relu ? bn(y) > 0 : 1), yhat = (y - mean)*invstd
+    const float* bwd_y;      // (positions, Cout) raw conv output of the layer the gradient belongs to, row stride Cout
+    const float* bwd_bn;     // its bnstate float[4*Cout]
+    int bwd_relu;
 };
 
 int conv_geom_check(const lisec_conv_geom* c, ConvGeom* g);

@@ -261,6 +261,33 @@ extern "C" int lisec_bn_backward(const float* dA, int da_stride, const float* y,
     return LISEC_OK;
 }
 
+extern "C" int lisec_bn_backward_apply(const float* dA, int da_stride, const float* y, const float* bnstate,
+                                       long long M, int C, int relu, const double* partials, int nparts,
+                                       float* dgamma, float* dbeta, float* dy, void* workspace,
+                                       size_t workspace_bytes, lisec_stream_t stream_) {
+    LISEC_CHECK_ARG(dA && y && bnstate && partials && dgamma && dbeta && dy && workspace && nparts > 0, "NULL pointer");
+    LISEC_CHECK_ARG(M > 0 && C >= 4 && C <= 256 && C % 4 == 0 && (kEwThreads * 4) % C == 0 && da_stride % 4 == 0,
+                    "bn_backward: C must divide 1024 and be a multiple of 4");
+    if (workspace_bytes < lisec_eltwise_workspace_bytes()) {
+        set_error("eltwise workspace too small");
+        return LISEC_ENOSPC;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream_);
+    float* coef = reinterpret_cast<float*>(static_cast<char*>(workspace) + align_up(sizeof(double) * (size_t)kEwBlocks * 2 * 256, 256));
+    if (int rc = launch_bn_bwd_finalize(partials, nparts, C, (double)M, dgamma, dbeta, coef, st)) return rc;
+    const int rows_per_iter = kEwThreads / (C / 4);
+    int nb = (int)((M + rows_per_iter - 1) / rows_per_iter);
+    if (nb > kEwBlocks) nb = kEwBlocks;
+    if (relu)
+        hipLaunchKernelGGL(k_bn_bwd_apply<true>, dim3(nb), dim3(kEwThreads), 0, st, dA, da_stride, y, bnstate, coef, M, C, dy,
+                           (double*)nullptr);
+    else
+        hipLaunchKernelGGL(k_bn_bwd_apply<false>, dim3(nb), dim3(kEwThreads), 0, st, dA, da_stride, y, bnstate, coef, M, C, dy,
+                           (double*)nullptr);
+    LISEC_LAUNCH_CHECK();
+    return LISEC_OK;
+}
+
 extern "C" int lisec_relu_mask(float* grad, const float* act, long long n, lisec_stream_t stream_) {
     LISEC_CHECK_ARG(grad && act && n >= 0 && n % 4 == 0, "relu_mask: n must be a multiple of 4");
     if (n == 0) return LISEC_OK;

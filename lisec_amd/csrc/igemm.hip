@@ -68,6 +68,12 @@ __device__ __forceinline__ void store_tile(const ConvGeom& g, const f32x16& acc0
         pc_i = pc_q / (g.Wo >> 1);
         pc_j = pc_q - pc_i * (g.Wo >> 1);
     }
+    // BatchNormalization-backward statistics: per-column constants of the layer the gradient belongs to
+    float ysA = 1.f, yhA = 0.f, ymA = 0.f, yiA = 0.f, ysB = 1.f, yhB = 0.f, ymB = 0.f, yiB = 0.f;
+    if (g.bwd_y) {
+        if (nA < g.Cout) { ysA = g.bwd_bn[nA]; yhA = g.bwd_bn[g.Cout + nA]; ymA = g.bwd_bn[2 * g.Cout + nA]; yiA = g.bwd_bn[3 * g.Cout + nA]; }
+        if (nB < g.Cout) { ysB = g.bwd_bn[nB]; yhB = g.bwd_bn[g.Cout + nB]; ymB = g.bwd_bn[2 * g.Cout + nB]; yiB = g.bwd_bn[3 * g.Cout + nB]; }
+    }
     const float biasA = (bias && nA < g.Cout) ? bias[ncA] : 0.f;
     const float biasB = (bias && nB < g.Cout) ? bias[ncB] : 0.f;
     const bool orelu = (flags & LISEC_CONV_OUT_RELU) != 0, accum = (flags & LISEC_CONV_ACCUMULATE) != 0;
@@ -104,8 +110,18 @@ __device__ __forceinline__ void store_tile(const ConvGeom& g, const f32x16& acc0
             if (orelu) { va = fmaxf(va, 0.f); vb = fmaxf(vb, 0.f); }
             if (nA < g.Cout) o[ncA] = va;
             if (nB < g.Cout) o[ncB] = vb;
-            sumA += va; sqA = fmaf(va, va, sqA);
-            sumB += vb; sqB = fmaf(vb, vb, sqB);
+            if (g.bwd_y) {
+                // (sum dz, sum dz * yhat) of the gradient just stored, for the BatchNormalization it is about to cross
+                const float* yr = g.bwd_y + orow * g.Cout;
+                const float ya = nA < g.Cout ? yr[nA] : 0.f, yb = nB < g.Cout ? yr[nB] : 0.f;
+                const float da = (g.bwd_relu && !(fmaf(ya, ysA, yhA) > 0.f)) || nA >= g.Cout ? 0.f : va;
+                const float db = (g.bwd_relu && !(fmaf(yb, ysB, yhB) > 0.f)) || nB >= g.Cout ? 0.f : vb;
+                sumA += da; sqA = fmaf(da, (ya - ymA) * yiA, sqA);
+                sumB += db; sqB = fmaf(db, (yb - ymB) * yiB, sqB);
+            } else {
+                sumA += va; sqA = fmaf(va, va, sqA);
+                sumB += vb; sqB = fmaf(vb, vb, sqB);
+            }
         }
     }
     if (stats) {
@@ -551,7 +567,8 @@ __global__ void __launch_bounds__(kSkThreads)
 k_splitk_reduce(const float* __restrict__ partial, int nsplit, int M, int Cout, int CoutP,
                 const float* __restrict__ bias, int flags, float* __restrict__ out, int out_stride,
                 double* __restrict__ stats, int tile0, const int32_t* __restrict__ row_count,
-                const float* __restrict__ out_mask, int pc_span, int pc_rows, int Wo) {
+                const float* __restrict__ out_mask, int pc_span, int pc_rows, int Wo,
+                const float* __restrict__ bwd_y, const float* __restrict__ bwd_bn, int bwd_relu) {
     __shared__ float red[2][kSkThreads][4];
     if (row_count && *row_count < M) M = *row_count;          // row list shorter than its capacity
     constexpr int cq = BN / 4;                       // one 64-channel slab per blockIdx.y
@@ -560,6 +577,13 @@ k_splitk_reduce(const float* __restrict__ partial, int nsplit, int M, int Cout, 
     const bool cok = c < Cout;
     float4 b = make_float4(0, 0, 0, 0);
     if (bias && cok) b = *reinterpret_cast<const float4*>(bias + c);
+    float4 ysc = make_float4(1, 1, 1, 1), ysh = make_float4(0, 0, 0, 0), ymu = ysh, yis = ysh;
+    if (bwd_y && cok) {
+        ysc = *reinterpret_cast<const float4*>(bwd_bn + c);
+        ysh = *reinterpret_cast<const float4*>(bwd_bn + Cout + c);
+        ymu = *reinterpret_cast<const float4*>(bwd_bn + 2 * Cout + c);
+        yis = *reinterpret_cast<const float4*>(bwd_bn + 3 * Cout + c);
+    }
     const bool orelu = (flags & LISEC_CONV_OUT_RELU) != 0, accum = (flags & LISEC_CONV_ACCUMULATE) != 0;
     float4 s1 = make_float4(0, 0, 0, 0), s2 = make_float4(0, 0, 0, 0);
     const int tile = tile0 + blockIdx.x;
@@ -600,8 +624,20 @@ k_splitk_reduce(const float* __restrict__ partial, int nsplit, int M, int Cout, 
             }
             if (orelu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
             *reinterpret_cast<float4*>(o) = v;
-            s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
-            s2.x = fmaf(v.x, v.x, s2.x); s2.y = fmaf(v.y, v.y, s2.y); s2.z = fmaf(v.z, v.z, s2.z); s2.w = fmaf(v.w, v.w, s2.w);
+            if (bwd_y) {
+                const float4 yv = *reinterpret_cast<const float4*>(bwd_y + orow * Cout + c);
+#define LISEC_BWD(f)                                                                     \
+                {                                                                        \
+                    const float dz = (bwd_relu && !(fmaf(yv.f, ysc.f, ysh.f) > 0.f)) ? 0.f : v.f; \
+                    s1.f += dz;                                                          \
+                    s2.f = fmaf(dz, (yv.f - ymu.f) * yis.f, s2.f);                       \
+                }
+                LISEC_BWD(x) LISEC_BWD(y) LISEC_BWD(z) LISEC_BWD(w)
+#undef LISEC_BWD
+            } else {
+                s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
+                s2.x = fmaf(v.x, v.x, s2.x); s2.y = fmaf(v.y, v.y, s2.y); s2.z = fmaf(v.z, v.z, s2.z); s2.w = fmaf(v.w, v.w, s2.w);
+            }
         }
     }
     if (stats) {
@@ -667,6 +703,7 @@ int conv_geom_check(const lisec_conv_geom* c, ConvGeom* g) {
     g->ps = c->ps; g->ps_channels = c->ps_channels;
     g->row_coords = nullptr; g->row_count = nullptr; g->out_mask = nullptr;
     g->pc_span = 0; g->pc_rows = 0;
+    g->bwd_y = nullptr; g->bwd_bn = nullptr; g->bwd_relu = 0;
     g->pointwise = c->KD * c->KH * c->KW == 1 && ld == 0 && lh == 0 && lw == 0 && c->pd == 0 && c->ph == 0 && c->pw == 0 &&
                    c->Di == c->Do && c->Hi == c->Ho && c->Wi == c->Wo;
     return 0;
@@ -710,6 +747,15 @@ extern "C" int lisec_conv_pack_weights_batched(const lisec_pack_desc* device_tab
 extern "C" int lisec_conv_num_mblocks(const lisec_conv_geom* c) {
     ConvGeom g;
     if (conv_geom_check(c, &g)) return -1;
+    return cdiv(g.M, BM);
+}
+
+namespace { void parity_order(const lisec_conv_geom* c, ConvGeom* g); }
+
+extern "C" int lisec_conv_num_mblocks_bwd(const lisec_conv_geom* c) {
+    ConvGeom g;
+    if (conv_geom_check(c, &g)) return -1;
+    parity_order(c, &g);                              // the row order a backward-statistics call uses
     return cdiv(g.M, BM);
 }
 
@@ -807,14 +853,32 @@ extern "C" int lisec_conv_forward_masked(const lisec_conv_geom* c, const float* 
                                          const float* out_mask, double* stats_partials, void* workspace,
                                          size_t workspace_bytes, const int32_t* row_coords,
                                          const int32_t* row_count, int row_capacity, lisec_stream_t stream_) {
+    lisec_conv_extras ex = {out_mask, nullptr, nullptr, 0};
+    return lisec_conv_forward_ex(c, in, packed_w, bias, in_bnstate, flags, out, &ex, stats_partials, workspace,
+                                 workspace_bytes, row_coords, row_count, row_capacity, stream_);
+}
+
+extern "C" int lisec_conv_forward_ex(const lisec_conv_geom* c, const float* in, const float* packed_w,
+                                     const float* bias, const float* in_bnstate, int flags, float* out,
+                                     const lisec_conv_extras* extras, double* stats_partials, void* workspace,
+                                     size_t workspace_bytes, const int32_t* row_coords,
+                                     const int32_t* row_count, int row_capacity, lisec_stream_t stream_) {
     ConvGeom g;
     if (int rc = conv_geom_check(c, &g)) return rc;
+    const float* out_mask = extras ? extras->out_mask : nullptr;
     LISEC_CHECK_ARG(!out_mask || (!c->ps && ((uintptr_t)out_mask & 15) == 0),
                     "out_mask: 16-byte aligned, not with a pixel-shuffle store");
     g.out_mask = out_mask;
+    const bool bwd_stats = extras && extras->bwd_y;
+    if (bwd_stats) {
+        LISEC_CHECK_ARG(extras->bwd_bnstate && stats_partials && !c->ps && !row_coords && c->Cout % 4 == 0 &&
+                        ((uintptr_t)extras->bwd_y & 15) == 0 && ((uintptr_t)extras->bwd_bnstate & 15) == 0,
+                        "backward statistics need y, its bnstate, a partials buffer, dense rows and Cout % 4 == 0");
+        g.bwd_y = extras->bwd_y; g.bwd_bn = extras->bwd_bnstate; g.bwd_relu = extras->bwd_relu ? 1 : 0;
+    }
     // stride 2 along h and w, transposed gather (data gradient of a stride-2 Conv2D): rows are visited in parity
     // classes so that a tile only runs the taps that divide -- 9/4 of the 9 taps on average
-    if (!row_coords && !stats_partials) parity_order(c, &g);
+    if (!row_coords && (!stats_partials || bwd_stats)) parity_order(c, &g);
     if (row_coords) {
         LISEC_CHECK_ARG(row_count && row_capacity > 0 && !stats_partials && !c->ps,
                         "row list needs a device count, a capacity, and no stats / pixel-shuffle");
@@ -881,7 +945,7 @@ extern "C" int lisec_conv_forward_masked(const lisec_conv_geom* c, const float* 
         LISEC_IG_ANY(grid, plan.nsplit, partial, plan.tile0_tail);
         hipLaunchKernelGGL(k_splitk_reduce, dim3(tail, nnb), dim3(kSkThreads), 0, st, partial, plan.nsplit, g.M, g.Cout,
                            g.CoutP, bias, flags, out, g.out_stride, stats_partials, plan.tile0_tail, g.row_count, g.out_mask,
-                           g.pc_span, g.pc_rows, g.Wo);
+                           g.pc_span, g.pc_rows, g.Wo, g.bwd_y, g.bwd_bn, g.bwd_relu);
     }
 #undef LISEC_IG_ANY
 #undef LISEC_IH

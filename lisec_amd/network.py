@@ -245,6 +245,19 @@ class LisecNet:
         self.packed_t["head"] = (torch.empty(ops.packed_floats(1, 16, 768), dtype=f32, device=dev), None)
         self.head_dw = torch.empty(768, 16, dtype=f32, device=dev)
         self.up_db = torch.empty(768, dtype=f32, device=dev)
+        # conv outputs that sit under a BatchNormalization(+ReLU), and how many layers read each of them
+        self.bn_of, self.consumers = {}, {}
+        nparts = 1
+        for L in self.layers:
+            self.consumers[L["src"]] = self.consumers.get(L["src"], 0) + 1
+            if L["kind"] == "conv":
+                self.bn_of[L["dst"]] = (L["conv"].bn, L["conv"].g.Cout)
+        for L in self.layers:
+            if L["src"] in self.bn_of:
+                nparts = max(nparts, ops.num_mblocks_bwd(self.dgeom[L["conv"].name]) * 2 * self.bn_of[L["src"]][1])
+            if "dense" in L:
+                nparts = max(nparts, ops.num_mblocks_bwd(self.dgeom[L["dense"].name]) * 2 * 64)
+        self.bparts = torch.empty(nparts, dtype=torch.float64, device=dev)
         self.head_db = torch.empty(16, dtype=f32, device=dev)
         self.wgrad_ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         # weight gradients are leaves of the backward graph: they run on a second HIP stream next to the
@@ -316,12 +329,24 @@ class LisecNet:
             with torch.cuda.stream(self.side):
                 fn()
 
+        writes = {}                            # gradient buffer -> contributions stored so far
+        bwd_ready = {}                         # gradient buffer -> partial rows of its BN-backward statistics
+
         def dgrad_into(c, dy, dst_name):
             flags = ops.ACCUMULATE if dst_name in first_write else 0
             # the output of a middle block went through Dense(relu) (model_training.py:195): its gradient is gated
             # by that activation while the data gradient is stored (single consumer, so no ACCUMULATE there)
             mask = a[dst_name] if dst_name.endswith(".u") else None
-            ops.conv_forward(self.dgeom[c.name], dy, self.packed_t[c.name][0], d[dst_name], flags=flags, out_mask=mask)
+            # the LAST contribution to the gradient of a conv output also reduces the statistics its
+            # BatchNormalization backward needs (pass 1 of bn_backward folded into the store)
+            writes[dst_name] = writes.get(dst_name, 0) + 1
+            bwd = stats = None
+            if dst_name in self.bn_of and writes[dst_name] == self.consumers[dst_name]:
+                bn_name, C = self.bn_of[dst_name]
+                bwd, stats = (a[dst_name], self.bnstate[bn_name], True), self.bparts
+                bwd_ready[dst_name] = ops.num_mblocks_bwd(self.dgeom[c.name])
+            ops.conv_forward(self.dgeom[c.name], dy, self.packed_t[c.name][0], d[dst_name], flags=flags, out_mask=mask,
+                             bwd=bwd, stats=stats)
             first_write.add(dst_name)
 
         for L in reversed(layers):
@@ -343,8 +368,13 @@ class LisecNet:
                 dst = L["dst"]
                 C = c.g.Cout
                 is_first_rpn = L["name"] == "rpn1.conv0"
-                ops.bn_backward(d[dst], C, a[dst], self.bnstate[c.bn], c.M, C, True,
-                                p.grad_view(G, c.bn + ".gamma"), p.grad_view(G, c.bn + ".beta"), d[dst])
+                if dst in bwd_ready:
+                    ops.bn_backward_apply(d[dst], C, a[dst], self.bnstate[c.bn], c.M, C, True, self.bparts,
+                                          bwd_ready.pop(dst), p.grad_view(G, c.bn + ".gamma"),
+                                          p.grad_view(G, c.bn + ".beta"), d[dst])
+                else:
+                    ops.bn_backward(d[dst], C, a[dst], self.bnstate[c.bn], c.M, C, True,
+                                    p.grad_view(G, c.bn + ".gamma"), p.grad_view(G, c.bn + ".beta"), d[dst])
                 # the bias of a conv feeding a training-mode BN has gradient sum(dy) == 0 identically (BN removes
                 # the mean); Keras' autograd returns rounding noise there -- the exact 0 stays in self.grad
                 on_side(lambda L=L, c=c, dst=dst: ops.conv_wgrad(
@@ -358,9 +388,12 @@ class LisecNet:
                 n, dn = L["name"], L["dense"]
                 on_side(lambda n=n, dn=dn: ops.conv_wgrad(dn.g, a[n + ".y"], d[n + ".u"], p.grad_view(G, dn.wname),
                                                           self.wgrad_ws, in_bn=self.bnstate[dn.in_bn]))
-                ops.conv_forward(self.dgeom[dn.name], d[n + ".u"], self.packed_t[dn.name][0], d[n + ".z"])
-                ops.bn_backward(d[n + ".z"], 64, a[n + ".y"], self.bnstate[c.bn], c.M, 64, False,
-                                p.grad_view(G, c.bn + ".gamma"), p.grad_view(G, c.bn + ".beta"), d[n + ".z"])
+                # Dense data gradient; its store also reduces the statistics of the BatchNormalization under it
+                ops.conv_forward(self.dgeom[dn.name], d[n + ".u"], self.packed_t[dn.name][0], d[n + ".z"],
+                                 bwd=(a[n + ".y"], self.bnstate[c.bn], False), stats=self.bparts)
+                ops.bn_backward_apply(d[n + ".z"], 64, a[n + ".y"], self.bnstate[c.bn], c.M, 64, False, self.bparts,
+                                      ops.num_mblocks_bwd(self.dgeom[dn.name]), p.grad_view(G, c.bn + ".gamma"),
+                                      p.grad_view(G, c.bn + ".beta"), d[n + ".z"])
                 if L["src"] == "grid":
                     # the grid is a constant on the empty cells + V voxel rows: both gradients reduce to V-row
                     # contractions plus sums of dy over boundary-trimmed boxes (exact; csrc/sparse_grid.hip)

@@ -89,17 +89,39 @@ def conv_workspace(g, device, row_capacity=0):
     return _SPLITK_WS[key]
 
 
-def conv_forward(g, x, wp, out, bias=None, in_bn=None, flags=0, stats=None, splitk=True, rows=None, out_mask=None):
+def conv_forward(g, x, wp, out, bias=None, in_bn=None, flags=0, stats=None, splitk=True, rows=None, out_mask=None,
+                 bwd=None):
     """rows: optional (row_coords int32 (cap,3), row_count int32 device scalar, capacity) row list.
-    out_mask: optional tensor laid out like `out`; values are stored as 0 where out_mask <= 0."""
+    out_mask: optional tensor laid out like `out`; values are stored as 0 where out_mask <= 0.
+    bwd: optional (y, bnstate, relu): `out` is a gradient about to cross that BatchNormalization(+ReLU) backwards and
+    `stats` (num_mblocks_bwd(g) rows) receives the per-tile (sum dz, sum dz*yhat) -- see bn_backward_apply."""
     rc, rn, cap = rows if rows is not None else (None, None, 0)
     ws = conv_workspace(g, out.device, cap) if splitk else None
-    _lib.check(_lib.load().lisec_conv_forward_masked(ctypes.byref(g), _lib.ptr(x), _lib.ptr(wp), _lib.ptr(bias),
-                                                     _lib.ptr(in_bn), flags, _lib.ptr(out), _lib.ptr(out_mask),
-                                                     _lib.ptr(stats), _lib.ptr(ws),
-                                                     ws.numel() if ws is not None else 0,
-                                                     _lib.ptr(rc), _lib.ptr(rn), cap, _lib.current_stream()))
+    ex = _lib.ConvExtras(_lib.ptr(out_mask).value if out_mask is not None else None,
+                         _lib.ptr(bwd[0]).value if bwd is not None else None,
+                         _lib.ptr(bwd[1]).value if bwd is not None else None, 1 if (bwd is not None and bwd[2]) else 0)
+    _lib.check(_lib.load().lisec_conv_forward_ex(ctypes.byref(g), _lib.ptr(x), _lib.ptr(wp), _lib.ptr(bias),
+                                                 _lib.ptr(in_bn), flags, _lib.ptr(out), ctypes.byref(ex),
+                                                 _lib.ptr(stats), _lib.ptr(ws),
+                                                 ws.numel() if ws is not None else 0,
+                                                 _lib.ptr(rc), _lib.ptr(rn), cap, _lib.current_stream()))
     return out
+
+
+def num_mblocks_bwd(g):
+    n = _lib.load().lisec_conv_num_mblocks_bwd(ctypes.byref(g))
+    if n < 0:
+        raise _lib.LisecError(_lib.load().lisec_last_error().decode())
+    return n
+
+
+def bn_backward_apply(dA, da_stride, y, bnstate, M, C, relu, parts, nparts, dgamma, dbeta, dy):
+    """Passes 2-3 of bn_backward on partials written by conv_forward(..., bwd=...)."""
+    ws = _ew_workspace(y.device)
+    _lib.check(_lib.load().lisec_bn_backward_apply(_lib.ptr(dA), da_stride, _lib.ptr(y), _lib.ptr(bnstate), M, C,
+                                                   1 if relu else 0, _lib.ptr(parts), nparts, _lib.ptr(dgamma),
+                                                   _lib.ptr(dbeta), _lib.ptr(dy), _lib.ptr(ws), ws.numel(),
+                                                   _lib.current_stream()))
 
 
 def bn_finalize(partials, nparts, C, n_rows, gamma, beta, moving_mean, moving_var, unbiased, bnstate):

@@ -230,3 +230,55 @@ def test_stride2_data_gradient_parity_classes(H, W, Cin, Cout, splitk):
     dxm = torch.full((1, H, W, Cin), float("nan"), device=DEV)
     ops.conv_forward(geo, dy.to(DEV), wp, dxm, splitk=splitk, out_mask=mask.to(DEV))
     _close(dxm, torch.where(mask > 0, x.grad.detach(), torch.zeros_like(mask)))
+
+
+@pytest.mark.parametrize("splitk", [False, True])
+@pytest.mark.parametrize("mode,stride,W", [(1, (1, 1, 1), 130), (1, (1, 2, 2), 64), (0, (1, 2, 2), 40)])
+def test_backward_statistics_folded_into_the_store(mode, stride, W, splitk):
+    """lisec_conv_forward_ex with bwd_y: the per-tile partials are (sum dz, sum dz*yhat) of the gradient that was just
+    stored (pass 1 of lisec_bn_backward), also in the parity-class row order and through the K-sliced combine; then
+    lisec_bn_backward_apply must equal the three-pass lisec_bn_backward on the same gradient."""
+    from lisec_amd import ops
+    g = torch.Generator().manual_seed(17)
+    H, Cg, Cs = 6, 64, 128                      # Cg: channels of the gradient that is produced, Cs: of its source
+    k, pad = (1, 3, 3), (0, 1, 1)
+    if mode == 1:                               # data gradient of a conv: source positions = that conv's output map
+        Hs, Ws = (H + 2 - 3) // stride[1] + 1, (W + 2 - 3) // stride[2] + 1
+        geo = ops.geom(1, (1, Hs, Ws), (1, H, W), k, stride, pad, Cs, Cg)
+    else:                                       # data gradient of a stride-s deconv: a strided conv over its output
+        Hs, Ws = H * stride[1], W * stride[2]
+        k, pad = (1, stride[1], stride[2]), (0, 0, 0)
+        geo = ops.geom(0, (1, Hs, Ws), (1, H, W), k, stride, pad, Cs, Cg)
+    ntaps = k[1] * k[2]
+    src = torch.randn(1, Hs, Ws, Cs, generator=g).to(DEV)
+    w = (torch.randn(ntaps, Cs, Cg, generator=g) * 0.1).to(DEV)
+    wp = ops.pack_weights(w, ntaps, Cs, Cg, Cs * Cg, Cg, 1)
+    y = (torch.randn(H * W, Cg, generator=g) * 2 + 0.3).to(DEV)
+    mean, var = y.mean(0), y.var(0, unbiased=False)
+    inv = torch.rsqrt(var + 1e-3)
+    gamma, beta = torch.rand(Cg, generator=g).to(DEV) + 0.5, torch.randn(Cg, generator=g).to(DEV)
+    st = torch.cat([gamma * inv, beta - mean * gamma * inv, mean, inv]).contiguous()
+    M = H * W
+    for relu in (True, False):
+        plain = torch.empty(1, H, W, Cg, device=DEV)
+        ops.conv_forward(geo, src, wp, plain, splitk=splitk)
+        dg0, db0 = torch.empty(Cg, device=DEV), torch.empty(Cg, device=DEV)
+        want = torch.empty(M, Cg, device=DEV)
+        ops.bn_backward(plain, Cg, y, st, M, Cg, relu, dg0, db0, want)
+        nparts = ops.num_mblocks_bwd(geo)
+        parts = torch.full((nparts, 2, Cg), float("nan"), dtype=torch.float64, device=DEV)
+        got = torch.empty(1, H, W, Cg, device=DEV)
+        ops.conv_forward(geo, src, wp, got, splitk=splitk, bwd=(y, st, relu), stats=parts)
+        assert torch.equal(got, plain)
+        dz = plain.reshape(M, Cg).double()
+        if relu:
+            dz = dz * ((y.double() * st[:Cg].double() + st[Cg:2 * Cg].double()) > 0)
+        yhat = (y.double() - mean.double()) * inv.double()
+        tot = parts.sum(0)
+        _close(tot[0], dz.sum(0), rtol=1e-5)
+        _close(tot[1], (dz * yhat).sum(0), rtol=1e-5)
+        dg1, db1 = torch.empty(Cg, device=DEV), torch.empty(Cg, device=DEV)
+        ops.bn_backward_apply(got, Cg, y, st, M, Cg, relu, parts, nparts, dg1, db1, got)
+        _close(got.reshape(M, Cg), want, rtol=1e-5)
+        _close(dg1, dg0, rtol=1e-5)
+        _close(db1, db0, rtol=1e-5)
