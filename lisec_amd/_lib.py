@@ -165,15 +165,30 @@ def check(rc):
 
 
 def ptr(t):
-    """Device pointer of a torch tensor (or None)."""
+    """Device address of a torch tensor as a plain int (ctypes converts it for `void*` parameters), or None."""
     if t is None:
         return None
-    return c_void_p(t.data_ptr())
+    return t.data_ptr()
+
+
+# A caller that issues many launches on a stream it already knows (LisecNet.forward / backward) pins the handle here
+# instead of asking torch for the current stream on every launch; None = ask torch.
+_pinned_stream = None
+
+
+def pin_stream(handle):
+    """Pins the stream handle returned by current_stream(); returns the previous pin (restore it when done)."""
+    global _pinned_stream
+    prev = _pinned_stream
+    _pinned_stream = handle
+    return prev
 
 
 def current_stream():
+    if _pinned_stream is not None:
+        return _pinned_stream
     import torch
-    return c_void_p(torch.cuda.current_stream().cuda_stream)
+    return torch.cuda.current_stream().cuda_stream
 
 
 def require_gpu():

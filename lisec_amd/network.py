@@ -172,6 +172,13 @@ class LisecNet:
         """sample: VoxelSample of one lidar sweep.  Returns (cls (1,Ho,Wo,2), reg (1,Ho,Wo,14)) device views."""
         if sample.grid_shape != (self.D, self.H, self.W) or sample.cfg.sampleSize != self.T:
             raise ValueError("voxel sample does not match the model's grid")
+        prev_pin = _lib.pin_stream(torch.cuda.current_stream().cuda_stream)   # one stream query for the whole schedule
+        try:
+            return self._forward(sample, training)
+        finally:
+            _lib.pin_stream(prev_pin)
+
+    def _forward(self, sample, training):
         self._pack_all()
         a = self.act
         self.vfe.forward(sample, training, out=a["grid"])
@@ -245,6 +252,7 @@ class LisecNet:
         self.packed_t["head"] = (torch.empty(ops.packed_floats(1, 16, 768), dtype=f32, device=dev), None)
         self.head_dw = torch.empty(768, 16, dtype=f32, device=dev)
         self.up_db = torch.empty(768, dtype=f32, device=dev)
+        self._fork_events, self._join_event = [], torch.cuda.Event()
         # conv outputs that sit under a BatchNormalization(+ReLU), and how many layers read each of them
         self.bn_of, self.consumers = {}, {}
         nparts = 1
@@ -292,6 +300,13 @@ class LisecNet:
         rpn_grads_ready(lo, hi): optional hook, called (inside the second stream's context) as soon as the
         gradients of every RPN/head variable -- theta[lo:hi], 94 % of the parameters -- are final, while the
         middle layers and the VFE are still being differentiated: data parallelism starts its all-reduce there."""
+        prev_pin = _lib.pin_stream(torch.cuda.current_stream().cuda_stream)
+        try:
+            return self._backward(y_cls, y_reg, loss, grad_scale, rpn_grads_ready)
+        finally:
+            _lib.pin_stream(prev_pin)
+
+    def _backward(self, y_cls, y_reg, loss, grad_scale, rpn_grads_ready):
         self._prepare_training()
         self._pack_all_t()
         p, a, d, G = self.params, self.act, self.dact, self.grad
@@ -322,12 +337,23 @@ class LisecNet:
         first_write = set()                    # gradient buffers that already hold a contribution
         main = torch.cuda.current_stream()
 
+        side_handle = self.side.cuda_stream
+        events = self._fork_events
+        nfork = [0]
+
         def on_side(fn):
-            ev = torch.cuda.Event()
+            if nfork[0] == len(events):
+                events.append(torch.cuda.Event())
+            ev = events[nfork[0]]                       # events are reused step after step
+            nfork[0] += 1
             ev.record(main)
             self.side.wait_event(ev)
             with torch.cuda.stream(self.side):
-                fn()
+                pin = _lib.pin_stream(side_handle)
+                try:
+                    fn()
+                finally:
+                    _lib.pin_stream(pin)
 
         writes = {}                            # gradient buffer -> contributions stored so far
         bwd_ready = {}                         # gradient buffer -> partial rows of its BN-backward statistics
@@ -416,7 +442,7 @@ class LisecNet:
                     dgrad_into(c, d[n + ".z"], L["src"])
         # ---- VFE -----------------------------------------------------------------------------------
         self.vfe.backward(None, G, dout_rows=self.dout_rows, g_all=self.g_all)
-        done = torch.cuda.Event()
+        done = self._join_event
         done.record(self.side)
         main.wait_event(done)                  # every weight gradient has landed before the optimizer reads G
         return self.loss_out

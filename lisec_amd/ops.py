@@ -97,9 +97,8 @@ def conv_forward(g, x, wp, out, bias=None, in_bn=None, flags=0, stats=None, spli
     `stats` (num_mblocks_bwd(g) rows) receives the per-tile (sum dz, sum dz*yhat) -- see bn_backward_apply."""
     rc, rn, cap = rows if rows is not None else (None, None, 0)
     ws = conv_workspace(g, out.device, cap) if splitk else None
-    ex = _lib.ConvExtras(_lib.ptr(out_mask).value if out_mask is not None else None,
-                         _lib.ptr(bwd[0]).value if bwd is not None else None,
-                         _lib.ptr(bwd[1]).value if bwd is not None else None, 1 if (bwd is not None and bwd[2]) else 0)
+    ex = _lib.ConvExtras(_lib.ptr(out_mask), _lib.ptr(bwd[0]) if bwd is not None else None,
+                         _lib.ptr(bwd[1]) if bwd is not None else None, 1 if (bwd is not None and bwd[2]) else 0)
     _lib.check(_lib.load().lisec_conv_forward_ex(ctypes.byref(g), _lib.ptr(x), _lib.ptr(wp), _lib.ptr(bias),
                                                  _lib.ptr(in_bn), flags, _lib.ptr(out), ctypes.byref(ex),
                                                  _lib.ptr(stats), _lib.ptr(ws),

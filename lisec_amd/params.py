@@ -88,19 +88,25 @@ class ParamStore:
                 self.offsets[name] = ("state", ns, shape)
                 ns += (n + 3) // 4 * 4
         self.n_theta, self.n_state = nt, ns
+        self._views = {}
         self.theta = torch.zeros(nt, dtype=torch.float32, device=device)
         self.state = torch.zeros(ns, dtype=torch.float32, device=device)
         self.load_dict(init if init is not None else glorot_numpy())
 
     def view(self, name, buf=None):
+        """Named view into theta / state (or into `buf`, a buffer laid out like theta).  Views are cached per buffer:
+        the schedule asks for the same few hundred views every step."""
         which, off, shape = self.offsets[name]
         base = buf if buf is not None else (self.theta if which == "theta" else self.state)
-        return base[off:off + int(np.prod(shape))].view(*shape)
+        key = (name, base.data_ptr())
+        v = self._views.get(key)
+        if v is None:
+            v = self._views[key] = base[off:off + int(np.prod(shape))].view(*shape)
+        return v
 
     def grad_view(self, grad, name):
-        which, off, shape = self.offsets[name]
-        assert which == "theta"
-        return grad[off:off + int(np.prod(shape))].view(*shape)
+        assert self.offsets[name][0] == "theta"
+        return self.view(name, buf=grad)
 
     def ptr(self, name, buf=None):
         import ctypes
