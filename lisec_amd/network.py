@@ -341,19 +341,25 @@ class LisecNet:
         events = self._fork_events
         nfork = [0]
 
-        def on_side(fn):
+        def on_side(fn, torch_ops=False):
+            """Runs fn's launches on the second stream after everything issued so far on the main one.  C-ABI launches
+            take the pinned handle; only a fn that also issues torch / torch.distributed work needs torch's (slow)
+            stream context."""
             if nfork[0] == len(events):
                 events.append(torch.cuda.Event())
             ev = events[nfork[0]]                       # events are reused step after step
             nfork[0] += 1
             ev.record(main)
             self.side.wait_event(ev)
-            with torch.cuda.stream(self.side):
-                pin = _lib.pin_stream(side_handle)
-                try:
+            pin = _lib.pin_stream(side_handle)
+            try:
+                if torch_ops:
+                    with torch.cuda.stream(self.side):
+                        fn()
+                else:
                     fn()
-                finally:
-                    _lib.pin_stream(pin)
+            finally:
+                _lib.pin_stream(pin)
 
         writes = {}                            # gradient buffer -> contributions stored so far
         bwd_ready = {}                         # gradient buffer -> partial rows of its BN-backward statistics
@@ -408,7 +414,7 @@ class LisecNet:
                     in_bn=self.bnstate[c.in_bn] if c.in_bn else None, flags=ops.IN_RELU if c.in_relu else 0))
                 if is_first_rpn and rpn_grads_ready is not None:
                     lo = p.offsets["rpn1.conv0.kernel"][1]
-                    on_side(lambda lo=lo: rpn_grads_ready(lo, p.n_theta))
+                    on_side(lambda lo=lo: rpn_grads_ready(lo, p.n_theta), torch_ops=True)
                 dgrad_into(c, d[dst], L["src"])
             else:   # mid layer: conv3d -> BN -> Dense(relu)
                 n, dn = L["name"], L["dense"]
