@@ -170,13 +170,20 @@ k_igemm(ConvGeom g, const float* __restrict__ in, const float* __restrict__ wp,
     // ---- rows this thread stages: r = p*16 + tid/16, 16-byte piece tid%16 ----------------------
     const int piece = tid & 15;
     RowGather rows[8];
+    int tile_mask = 0;
     {
         // each gather descriptor is computed ONCE (thread r < 128 owns row r: two integer divisions + three axis masks) and
         // handed to the 16 threads that stage that row through LDS, instead of 8 descriptors per thread
         int2* shared_rows = reinterpret_cast<int2*>(smem);
+        int* tile_or = reinterpret_cast<int*>(shared_rows + BM);     // OR of the rows' validity bits
+        if (g.row_coords) {                                          // (wave-uniform branch)
+            if (tid == 0) *tile_or = 0;
+            __syncthreads();
+        }
         if (tid < BM) {
             const RowGather r = row_gather(g, m0 + tid, MODE, 0);
             shared_rows[tid] = make_int2(r.off, r.mask);
+            if (g.row_coords && r.mask) atomicOr(tile_or, r.mask);
         }
         __syncthreads();
 #pragma unroll
@@ -185,6 +192,7 @@ k_igemm(ConvGeom g, const float* __restrict__ in, const float* __restrict__ wp,
             rows[p].off = v.x + piece * 4;
             rows[p].mask = v.y;
         }
+        if (g.row_coords) tile_mask = *tile_or;
         __syncthreads();
     }
     // tile-uniform depth range for whole-tap skipping
@@ -207,7 +215,14 @@ k_igemm(ConvGeom g, const float* __restrict__ in, const float* __restrict__ wp,
             const int tap = s / ncc, kw = tap % g.KW, kh = (tap / g.KW) % g.KH;
             return (((pclass >> 1) + g.ph - kh) & 1) == 0 && (((pclass & 1) + g.pw - kw) & 1) == 0;
         }
-        if (g.row_coords || d_first != d_last) return true;
+        if (g.row_coords) {
+            // row list (voxels sorted by cell, so a tile mostly shares z and its parity): a tap none of whose axis bits
+            // is set in ANY row of the tile reads nothing -- conservative (per-axis OR), never skips a live tap
+            const int tap = s / ncc, kw = tap % g.KW, kh = (tap / g.KW) % g.KH, kd = tap / (g.KW * g.KH);
+            const int tb = tap_bits(kd, kh, kw);
+            return (tile_mask & tb) == tb;
+        }
+        if (d_first != d_last) return true;
         const int kd = (s / ncc) / (g.KH * g.KW);
         return (dmask_first >> kd) & 1;
     };
