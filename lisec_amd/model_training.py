@@ -293,7 +293,10 @@ class Model:
         o = self.optimizer
         for _ in range(epochs):
             order = list(np.random.permutation(idx)) if shuffle else list(idx)
-            tot = np.zeros(3)
+            # the running loss stays on the device: reading it back every step would stall the host behind the GPU and
+            # expose the ~2 ms it needs to enqueue the next step; the progress line is refreshed ~20 times per epoch
+            tot_dev = torch.zeros(3, dtype=torch.float64, device=dev)
+            every = max(1, steps // 20)
             t0 = time.time()
             for st in range(steps):
                 i = int(order[st % len(order)])
@@ -308,9 +311,10 @@ class Model:
                 else:
                     self.net.backward(yc, yr, loss=self.loss)
                 self.net.apply_gradients(lr=o.lr, decay=o.decay, momentum=o.momentum)
-                tot += self.net.loss_out.cpu().numpy()
-                if verbose:
-                    print(f"\r{st + 1}/{steps} - loss: {tot[0] / (st + 1):.4f}", end="", flush=True)
+                tot_dev += self.net.loss_out
+                if verbose and ((st + 1) % every == 0 or st + 1 == steps):
+                    print(f"\r{st + 1}/{steps} - loss: {float(tot_dev[0].item()) / (st + 1):.4f}", end="", flush=True)
+            tot = tot_dev.cpu().numpy()
             if verbose:
                 print(f" - {time.time() - t0:.1f}s")
             for key, v in zip(("loss", "ClassificationLayer_loss", "RegressionLayer_loss"), tot / max(steps, 1)):
