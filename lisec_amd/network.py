@@ -122,6 +122,8 @@ class LisecNet:
         self.parts = torch.empty(max_parts, dtype=torch.float64, device=dev)
         self._packed_version = -1
         self.params_version = 0
+        self.state_version = 0
+        self._folded = {}
         self._train_ready = False
         self.iterations = 0
         self.loss_out = torch.zeros(3, dtype=f32, device=dev)
@@ -155,9 +157,12 @@ class LisecNet:
             ops.bn_finalize(self.parts, c.nmb, C, c.M, p.view(c.bn + ".gamma"), p.view(c.bn + ".beta"),
                             p.view(c.bn + ".moving_mean"), p.view(c.bn + ".moving_variance"), True,
                             self.bnstate[c.bn])
-        else:
+            self.state_version += 1               # moving statistics moved, bnstate holds batch statistics
+        elif self._folded.get(c.bn) != (self.params_version, self.state_version):
+            # inference: scale/shift from the moving statistics, folded once per weight version (not per sweep)
             ops.bn_fold(p.view(c.bn + ".gamma"), p.view(c.bn + ".beta"), p.view(c.bn + ".moving_mean"),
                         p.view(c.bn + ".moving_variance"), C, self.bnstate[c.bn])
+            self._folded[c.bn] = (self.params_version, self.state_version)
 
     def _run_conv(self, c, x, out, training):
         p = self.params
