@@ -314,6 +314,16 @@ int lisec_bn_backward_apply(const float* dA, int da_stride, const float* y, cons
                             int relu, const double* partials, int nparts, float* dgamma, float* dbeta, float* dy,
                             void* workspace, size_t workspace_bytes, lisec_stream_t stream);
 
+/* n strided 2-D float copies in one launch: dst[r*dst_stride + c] = src[r*src_stride + c], r < rows, c < cols.
+ * `device_table` lives in device memory (the pointers are fixed for the life of a model). */
+typedef struct lisec_copy_desc {
+    const float* src;
+    float* dst;
+    int rows, cols;
+    long long src_stride, dst_stride;
+} lisec_copy_desc;
+int lisec_copy2d_batched(const lisec_copy_desc* device_table, int n, lisec_stream_t stream);
+
 /* grad[i] = act[i] > 0 ? grad[i] : 0   (backward of Dense(..., 'relu'), :195) */
 int lisec_relu_mask(float* grad, const float* act, long long n, lisec_stream_t stream);
 

@@ -36,6 +36,11 @@ class ConvExtras(ctypes.Structure):           # lisec_conv_extras
                 ("bwd_relu", ctypes.c_int)]
 
 
+class CopyDesc(Structure):                     # lisec_copy_desc
+    _fields_ = [("src", c_void_p), ("dst", c_void_p), ("rows", c_int), ("cols", c_int),
+                ("src_stride", ctypes.c_longlong), ("dst_stride", ctypes.c_longlong)]
+
+
 class PackDesc(Structure):
     _fields_ = [("src", c_void_p), ("dst", c_void_p), ("tap_stride", ctypes.c_longlong),
                 ("k_stride", ctypes.c_longlong), ("n_stride", ctypes.c_longlong), ("start", ctypes.c_longlong),
@@ -105,6 +110,8 @@ def _declare(lib):
     lib.lisec_conv_num_mblocks.argtypes = [POINTER(ConvGeom)]
     lib.lisec_conv_forward.restype = c_int
     lib.lisec_conv_forward.argtypes = [POINTER(ConvGeom), P, P, P, P, c_int, P, P, P, c_size_t, P, P, c_int, P]
+    lib.lisec_copy2d_batched.restype = c_int
+    lib.lisec_copy2d_batched.argtypes = [P, c_int, P]
     lib.lisec_conv_forward_ex.restype = c_int
     lib.lisec_conv_forward_ex.argtypes = [POINTER(ConvGeom), P, P, P, P, c_int, P, POINTER(ConvExtras), P, P, c_size_t, P, P,
                                           c_int, P]

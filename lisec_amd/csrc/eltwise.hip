@@ -288,6 +288,24 @@ extern "C" int lisec_bn_backward_apply(const float* dA, int da_stride, const flo
     return LISEC_OK;
 }
 
+// n small strided 2-D copies in one launch (a workgroup per descriptor): the head kernels / biases and their gradients
+// move between the Keras-shaped variables and the merged (768,16) head layout without one tiny launch per slice
+__global__ void k_copy2d_batched(const lisec_copy_desc* __restrict__ tab) {
+    const lisec_copy_desc d = tab[blockIdx.x];
+    const long long total = (long long)d.rows * d.cols;
+    for (long long i = threadIdx.x; i < total; i += blockDim.x) {
+        const long long r = i / d.cols, c = i - r * d.cols;
+        d.dst[r * d.dst_stride + c] = d.src[r * d.src_stride + c];
+    }
+}
+
+extern "C" int lisec_copy2d_batched(const lisec_copy_desc* device_table, int n, lisec_stream_t stream_) {
+    LISEC_CHECK_ARG(device_table && n > 0, "bad batched copy arguments");
+    hipLaunchKernelGGL(k_copy2d_batched, dim3(n), dim3(256), 0, static_cast<hipStream_t>(stream_), device_table);
+    LISEC_LAUNCH_CHECK();
+    return LISEC_OK;
+}
+
 extern "C" int lisec_relu_mask(float* grad, const float* act, long long n, lisec_stream_t stream_) {
     LISEC_CHECK_ARG(grad && act && n >= 0 && n % 4 == 0, "relu_mask: n must be a multiple of 4");
     if (n == 0) return LISEC_OK;

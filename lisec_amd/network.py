@@ -143,10 +143,12 @@ class LisecNet:
                         entries.append((p.view(c.wname), self.packed[c.name]) + tuple(c.pack))
             self._pack_table = ops.PackTable(entries, self.device)
         self._pack_table.run()
-        self.head_w[:, :2] = p.view("cls.kernel")[0, 0]
-        self.head_w[:, 2:] = p.view("reg.kernel")[0, 0]
-        self.head_b[:2] = p.view("cls.bias")
-        self.head_b[2:] = p.view("reg.bias")
+        if getattr(self, "_head_merge", None) is None:     # Keras-shaped head variables -> the merged (768,16) layout
+            self._head_merge = ops.CopyTable([(p.view("cls.kernel")[0, 0], self.head_w[:, :2]),
+                                              (p.view("reg.kernel")[0, 0], self.head_w[:, 2:]),
+                                              (p.view("cls.bias"), self.head_b[:2]),
+                                              (p.view("reg.bias"), self.head_b[2:])], self.device)
+        self._head_merge.run()
         ops.pack_weights(self.head_w, 1, 768, 16, 0, 16, 1, out=self.packed["head"])
         self._packed_version = self.params_version
 
@@ -330,13 +332,20 @@ class LisecNet:
         # ---- heads (model_training.py:254-255) ---------------------------------------------------
         ops.conv_wgrad(self.head_geom, a["concat"], d["head"], self.head_dw, self.wgrad_ws)
         ops.colsum(d["head"], 16, M, 16, self.head_db)
-        p.grad_view(G, "cls.kernel")[0, 0].copy_(self.head_dw[:, :2])
-        p.grad_view(G, "reg.kernel")[0, 0].copy_(self.head_dw[:, 2:])
-        p.grad_view(G, "cls.bias").copy_(self.head_db[:2])
-        p.grad_view(G, "reg.bias").copy_(self.head_db[2:])
+        if getattr(self, "_head_split", None) is None:     # merged head gradients -> the Keras-shaped slots of G
+            self._head_split = ops.CopyTable([(self.head_dw[:, :2], p.grad_view(G, "cls.kernel")[0, 0]),
+                                              (self.head_dw[:, 2:], p.grad_view(G, "reg.kernel")[0, 0]),
+                                              (self.head_db[:2], p.grad_view(G, "cls.bias")),
+                                              (self.head_db[2:], p.grad_view(G, "reg.bias"))], self.device)
+        self._head_split.run()
         ops.conv_forward(self.head_dgeom, d["head"], self.packed_t["head"][0], d["concat"])
         # the three deconv bias gradients are the column sums of the concat gradient: one pass over it
         ops.colsum(d["concat"], 768, M, 768, self.up_db)
+        if getattr(self, "_up_bias_split", None) is None:
+            self._up_bias_split = ops.CopyTable(
+                [(self.up_db[256 * L["slot"]:256 * (L["slot"] + 1)], p.grad_view(G, L["conv"].bias))
+                 for L in self.layers if L["kind"] == "deconv"], self.device)
+        self._up_bias_split.run()
         # ---- RPN blocks, last to first -------------------------------------------------------------
         layers = self.layers
         first_write = set()                    # gradient buffers that already hold a contribution
@@ -399,7 +408,6 @@ class LisecNet:
                     on_side(lambda L=L, c=c, dy=dy: ops.conv_wgrad(
                         c.g, a[L["src"]], dy, p.grad_view(G, c.wname), self.wgrad_ws,
                         in_bn=self.bnstate[c.in_bn], flags=ops.IN_RELU, transpose_out=True))
-                p.grad_view(G, c.bias).copy_(self.up_db[256 * b:256 * (b + 1)])
                 dgrad_into(c, dy, L["src"])
             elif L["kind"] == "conv":
                 dst = L["dst"]

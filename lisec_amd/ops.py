@@ -66,6 +66,25 @@ class PackTable:
                                                                _lib.current_stream()))
 
 
+class CopyTable:
+    """Device-resident table for lisec_copy2d_batched: entries (src, dst) of equal 1-D / 2-D shapes (views allowed)."""
+
+    def __init__(self, pairs, device):
+        arr = (_lib.CopyDesc * len(pairs))()
+        for d, (src, dst) in zip(arr, pairs):
+            assert src.shape == dst.shape and src.dim() in (1, 2) and src.dtype == dst.dtype == torch.float32
+            rows, cols = (1, src.shape[0]) if src.dim() == 1 else src.shape
+            assert src.stride(-1) == 1 and dst.stride(-1) == 1
+            d.src, d.dst, d.rows, d.cols = src.data_ptr(), dst.data_ptr(), rows, cols
+            d.src_stride = src.stride(0) if src.dim() == 2 else cols
+            d.dst_stride = dst.stride(0) if dst.dim() == 2 else cols
+        self.n, self.keep = len(pairs), pairs
+        self.table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
+
+    def run(self):
+        _lib.check(_lib.load().lisec_copy2d_batched(_lib.ptr(self.table), self.n, _lib.current_stream()))
+
+
 def num_mblocks(g):
     n = _lib.load().lisec_conv_num_mblocks(ctypes.byref(g))
     if n < 0:
