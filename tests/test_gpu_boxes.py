@@ -55,3 +55,59 @@ def test_rpn_to_region_vs_oracle():
     head = torch.from_numpy(np.concatenate([prob.reshape(-1, 2), regress.reshape(-1, 14)], 1)).cuda()
     b2, p2 = boxes.rpnToRegion(head[:, :2].reshape(100, 200, 2), head[:, 2:].reshape(100, 200, 14))
     assert np.array_equal(b2, got_boxes) and np.array_equal(p2, got_probs)
+
+
+class _FakeLyft:
+    """Duck-typed LyftDataset: the tables imageToRPN reads (serialize_data.py:341-381)."""
+
+    def __init__(self, anns, ego_t, ego_q):
+        self.t = {"sample_data": {"sd": {"ego_pose_token": "ego"}}, "ego_pose": {"ego": {"translation": ego_t, "rotation": ego_q}},
+                  "sample_annotation": {f"a{i}": a for i, a in enumerate(anns)},
+                  "instance": {f"i{i}": {"category_token": a["_cat"]} for i, a in enumerate(anns)},
+                  "category": {"car": {"name": "car"}, "bus": {"name": "bus"}}}
+
+    def get(self, table, token):
+        return self.t[table][token]
+
+
+def test_save_labels_for_sample(tmp_path):
+    """saveLabelsForSample under the reference's name: global -> ego transform (inverse ego rotation), car filter,
+    +-50 m filter, the four .npy files train() reads back."""
+    from lisec_amd import boxes, serialize_data
+    from lisec_amd.model_training import rotate_points
+    rng = np.random.default_rng(5)
+    ego_t = [100.0, -40.0, 2.0]
+    yaw = 0.3
+    ego_q = [np.cos(yaw / 2), 0.0, 0.0, np.sin(yaw / 2)]
+    local = _scene(rng, 6)
+    local[5, :2] = [70.0, 0.0]                                    # outside +-50 m: dropped
+    anns = []
+    for i, b in enumerate(local):
+        g = rotate_points(b[None, :3], np.array(ego_q), False)[0] + np.array(ego_t)       # ego -> global
+        anns.append({"translation": list(g), "size": list(b[3:6]), "rotation": [np.cos(b[6] / 2), 0, 0, np.sin(b[6] / 2)],
+                     "instance_token": f"i{i}", "_cat": "bus" if i == 4 else "car"})
+    ds = _FakeLyft(anns, ego_t, ego_q)
+    sample = {"anns": [f"a{i}" for i in range(6)], "data": {"LIDAR_TOP": "sd"}}
+    cls, reg = serialize_data.saveLabelsForSample([sample, sample], str(tmp_path / "labels3"), ds)
+    assert cls.shape == (2, 100, 200, 2) and reg.shape == (2, 100, 200, 14)
+    for name, shape in (("labelsClass.npy", cls.shape), ("regressClass.npy", reg.shape)):
+        assert np.load(tmp_path / "labels3" / name).shape == shape
+    assert list(np.load(tmp_path / "labels3" / "labelsShape.npy")) == [2, 100, 200, 2]
+    # same targets as preprocessLabels on the four kept boxes (yaw from the quaternion, ego-frame positions)
+    want_cls, want_reg = boxes.preprocessLabels(local[:4], seed=0)
+    assert np.array_equal(cls[0], want_cls)
+    assert np.allclose(reg[0], want_reg, atol=1e-9)
+    serialize_data.level5Data = ds                               # the reference's module-global form
+    c2, _ = serialize_data.imageToRPN(sample)
+    assert np.array_equal(c2, want_cls)
+    serialize_data.level5Data = None
+
+
+def test_rpn_to_region_module_name():
+    from lisec_amd import boxes, rpnToRegion
+    rng = np.random.default_rng(3)
+    cls = rng.uniform(0, 1, (1, 100, 200, 2)).astype(np.float32)
+    reg = rng.normal(0, 0.1, (1, 100, 200, 14)).astype(np.float32)
+    b, p = rpnToRegion.rpnToRegion(cls, reg)
+    b2, p2 = boxes.rpnToRegion(cls[0], reg[0], maxBoxes=20, overlapThresh=0.)
+    assert np.array_equal(b, b2) and np.array_equal(p, p2) and b.shape[1] == 7
