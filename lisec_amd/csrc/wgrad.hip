@@ -22,7 +22,8 @@ constexpr int BMW = 128, BC = 64;                // rows per M tile, channel blo
 constexpr int kThreads = 256;
 constexpr int TILE_FLOATS = BMW * BC;            // 8192 (32 KB)
 
-template <int MODE, int TG>
+// RL: row-list instantiation (tiles are tested for work by their decoded row masks, see first_live)
+template <int MODE, int TG, bool RL = false>
 __global__ void __launch_bounds__(kThreads)
 k_wgrad(ConvGeom g, const float* __restrict__ in, const float* __restrict__ in_bn, int flags,
         const float* __restrict__ dy, const float* __restrict__ dy_bn, int nsplit, int tiles_per_split,
@@ -135,11 +136,27 @@ k_wgrad(ConvGeom g, const float* __restrict__ in, const float* __restrict__ in_b
     const float* dCol = sD + (4 * (lane >> 5)) * BC + (wave & 1) * 32 + (lane & 31);
 
     // step list: (tile, t) with t in [0, TG); dY is staged with t == 0
-    int tile = t_begin;
-    while (tile < t_end && !tile_live(tile)) ++tile;
+    // first tile >= `tile` with work for this tap group; its row descriptors are decoded on return.  Row lists: the
+    // voxels are sorted by cell, so most tiles share one depth (parity) and whole (kd, kh) groups fall away
+    const int gbits = (1 << kd) | (16 << kh);
+    auto first_live = [&](int tile) -> int {
+        if (!RL) {
+            while (tile < t_end && !tile_live(tile)) ++tile;
+            if (tile < t_end) decode_rows(tile);
+            return tile;
+        }
+        for (; tile < t_end; ++tile) {
+            decode_rows(tile);
+            int pred = 0;
+#pragma unroll
+            for (int p = 0; p < 8; ++p) pred |= (rows[p].mask & gbits) == gbits;
+            if (__syncthreads_or(pred)) break;
+        }
+        return tile;
+    };
+    int tile = first_live(t_begin);
     int t = 0;
     if (tile < t_end) {
-        decode_rows(tile);
         load_a(kw0);
         load_d(tile);
         store_a();
@@ -151,12 +168,11 @@ k_wgrad(ConvGeom g, const float* __restrict__ in, const float* __restrict__ in_b
         int ntile = tile, nt = t + 1;
         if (nt == TG) {
             nt = 0;
-            ++ntile;
-            while (ntile < t_end && !tile_live(ntile)) ++ntile;
+            ntile = first_live(ntile + 1);
         }
         const bool more = ntile < t_end;
         if (more) {
-            if (nt == 0) { decode_rows(ntile); load_d(ntile); }
+            if (nt == 0) load_d(ntile);
             load_a(kw0 + nt);
         }
 #pragma unroll
@@ -475,7 +491,12 @@ int launch_wgrad(const ConvGeom& g, const WgradPlan& p, const float* in, const f
                  const float* dy, const float* dy_bn, float* partial, hipStream_t st) {
     dim3 grid(p.nsplit * p.ngroups, cdiv(g.Cin, BC), cdiv(g.Cout, BC));
     size_t lds = 2 * TILE_FLOATS * sizeof(float);
-#define LISEC_WG(T) hipLaunchKernelGGL((k_wgrad<MODE, T>), grid, dim3(kThreads), lds, st, g, in, in_bn, flags, dy, \
+#define LISEC_WG(T)                                                                                               \
+    if (g.row_coords)                                                                                             \
+        hipLaunchKernelGGL((k_wgrad<MODE, T, true>), grid, dim3(kThreads), lds, st, g, in, in_bn, flags, dy, dy_bn, \
+                           p.nsplit, p.tiles_per_split, partial);                                                 \
+    else                                                                                                          \
+        hipLaunchKernelGGL((k_wgrad<MODE, T, false>), grid, dim3(kThreads), lds, st, g, in, in_bn, flags, dy, \
                                        dy_bn, p.nsplit, p.tiles_per_split, partial)
     switch (p.TG) {
         case 1: LISEC_WG(1); break;
