@@ -71,7 +71,7 @@ def event_time_ms(fn, iters):
     return e0.elapsed_time(e1) / iters
 
 
-def cpu_baseline(seconds_budget=25.0):
+def cpu_baseline(seconds_budget=12.0):
     """Dense torch-CPU oracle (fwd + bwd + update) on a shrunken grid, extrapolated to the Lyft grid."""
     from oracle import model_ref as M
     from oracle import voxel_ref
@@ -82,11 +82,12 @@ def cpu_baseline(seconds_budget=25.0):
         avail = os.cpu_count() or 1
     cores = max(1, min(avail, 16))
     torch.set_num_threads(cores)
-    cfg = dict(xSize=0.5, ySize=0.25, zSize=0.25, sampleSize=35, maxVoxelX=12, maxVoxelY=24, maxVoxelZ=8)
-    D, H, W = 8, 24, 48
+    D, H, W = 8, 48, 96                 # 1/17.4 of the Lyft grid's dense rows: ~2 s per step on 16 cores, ~5 GB of RAM
+    cfg = dict(xSize=0.5, ySize=0.25, zSize=0.25, sampleSize=35, maxVoxelX=H // 2, maxVoxelY=W // 2, maxVoxelZ=8)
     rng = np.random.default_rng(0)
     n = 20000 * (H * W) // (200 * 400)
-    pts = np.stack([rng.uniform(-6.5, 6.5, n), rng.uniform(-6.5, 6.5, n), rng.uniform(-0.5, 2.5, n)], 1)
+    ext = 0.5 * (H // 2) * 1.1          # the same 10 % of points beyond the grid as the U20k cloud
+    pts = np.stack([rng.uniform(-ext, ext, n), rng.uniform(-ext, ext, n), rng.uniform(-0.5, 2.5, n)], 1)
     vox = voxel_ref.voxelize_ref(pts.astype(np.float32).astype(np.float64), **cfg)
     dense = torch.from_numpy(voxel_ref.to_dense(vox, (D, H, W, 35, 6)))[None]
     p = M.glorot_params()
@@ -98,7 +99,7 @@ def cpu_baseline(seconds_budget=25.0):
     while True:
         _, _, p, vel, _ = M.train_step(p, vel, dense, yc, yr, steps)
         steps += 1
-        if time.time() - t0 > seconds_budget or steps >= 3:
+        if steps >= 2 and (time.time() - t0 > seconds_budget or steps >= 6):
             break
     per_step = (time.time() - t0) / steps
     scale = (200 * 400) / float(H * W)
