@@ -2,6 +2,7 @@
 """Headline benchmark: Lyft-grid samples/s, forward + backward + SGD step (BASELINE.json metric).
 
     python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus N --steps K --warmup W         (starts the N ranks itself, one fresh process per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -108,6 +109,74 @@ def cpu_baseline(seconds_budget=12.0):
                        f"{per_step:.2f} s/step), extrapolated x{scale:.1f} by dense row count to 8x200x400")
 
 
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N fresh child interpreters of this same command, one rank
+    per GPU (RANK = LOCAL_RANK = 0..N-1, rendezvous on 127.0.0.1), BEFORE anything in this process touches the GPU.
+    Rank 0 inherits stdout (it prints the one JSON line); the other ranks' stdout goes to stderr.  Returns the exit code:
+    0 when every rank returned 0.  A rank that fails takes the others down (they would wait in the rendezvous forever)."""
+    import subprocess
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL needs on this pool
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    alive = list(procs)
+    while alive:
+        time.sleep(0.2)
+        for p in list(alive):
+            code = p.poll()
+            if code is None:
+                continue
+            alive.remove(p)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                for q in alive:                               # exact PIDs we started, never a pattern
+                    q.terminate()
+    for p in procs:
+        try:
+            p.wait(timeout=30)
+        except subprocess.TimeoutExpired:
+            p.kill()
+    return rc
+
+
+def dry_run(rank, world, args):
+    """LISEC_BENCH_DRYRUN=1: the launcher / rendezvous / timing-reduction / JSON path of this file with the GPU work
+    replaced by a sleep (CPU test of `python bench.py --gpus N`; gloo)."""
+    from lisec_amd.parallel import DataParallel
+    if os.environ.get("LISEC_BENCH_FAIL_RANK") == str(rank):      # test hook: this rank dies before the rendezvous
+        raise SystemExit(3)
+    dp = DataParallel("cpu") if world > 1 else None
+    if dp is not None:
+        dp.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.01 * args.steps * (1 + rank))
+    dt = time.perf_counter() - t0
+    per_rank = dp.gather_floats(dt) if dp is not None else [dt]
+    if dp is not None:
+        dt = dp.max_float(dt)
+    if rank == 0:
+        print(json.dumps({"metric": "lyft_samples_per_sec_fwd_bwd", "value": world * args.steps / dt, "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+                          "ms_per_step_per_rank": [1e3 * t / args.steps for t in per_rank], "dry_run": True,
+                          "dist_backend": dp.backend_name() if dp is not None else None,
+                          "rccl_ranks": dp.rccl_ranks() if dp is not None else 0}), flush=True)
+    if dp is not None:
+        dp.barrier()
+        dp.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -121,17 +190,20 @@ def main():
                     help="u20k: the headline workload (BASELINE configs 2-4); r200k: a Lyft-size sweep")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: this process becomes the launcher (it never touches the GPU)
+        raise SystemExit(launch_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU")
+    if os.environ.get("LISEC_BENCH_DRYRUN") == "1":
+        return dry_run(rank, world, args)
     # LISEC_BENCH_DEVICE pins every rank to one device index (rehearsing the N > 1 code path on a one-GPU box
     # together with LISEC_DIST_BACKEND=gloo); the driver's multi-GPU run uses cuda:LOCAL_RANK and RCCL
-    dev_index = int(os.environ.get("LISEC_BENCH_DEVICE", local_rank))
-    torch.cuda.set_device(dev_index)
-    dev = torch.device("cuda", dev_index)
+    from lisec_amd.parallel import select_device
+    dev = select_device(local_rank=local_rank, world=world)
 
     from lisec_amd import Constants, ops
     from lisec_amd.network import LisecNet
@@ -150,6 +222,7 @@ def main():
     if dp is not None:
         dp.broadcast_(net.params.theta)
         dp.broadcast_(net.params.state)
+        net.params.touch()
     allreduce = dp.bucketed() if dp is not None else None
     def step():
         sample = vox(pts)
@@ -168,6 +241,7 @@ def main():
         dp.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    per_rank = dp.gather_floats(dt) if dp is not None else [dt]
     if dp is not None:
         dt = dp.max_float(dt)
     loss_val = float(loss[0].item())
@@ -215,6 +289,9 @@ def main():
         result = {
             "metric": "lyft_samples_per_sec_fwd_bwd", "value": world * args.steps / dt, "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            "ms_per_step_per_rank": [1e3 * t / args.steps for t in per_rank],
+            "dist_backend": dp.backend_name() if dp is not None else None,
+            "rccl_ranks": dp.rccl_ranks() if dp is not None else 0,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"Lyft grid 8x200x400x35, {args.cloud.upper()} synthetic cloud, 1 sample/GPU/step, "

@@ -199,8 +199,14 @@ def current_stream():
 
 
 def require_gpu():
+    """The device this process computes on.  Under a multi-process launch (WORLD_SIZE > 1) that is cuda:LOCAL_RANK,
+    bound here before anything is allocated (one process per GPU; lisec_amd.parallel.select_device)."""
+    import os
     import torch
     if not torch.cuda.is_available():
         raise LisecError("lisec_amd needs an MI355X (torch.cuda.is_available() is False); "
                          "there is no CPU fallback for the hot path")
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("LISEC_DEVICE"):
+        from .parallel import select_device
+        return select_device()
     return torch.device("cuda", torch.cuda.current_device())

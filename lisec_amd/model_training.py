@@ -233,6 +233,7 @@ class Model:
             self.dp = DataParallel(self.net.device)
             self.dp.broadcast_(self.net.params.theta)
             self.dp.broadcast_(self.net.params.state)
+            self.net.params.touch()
 
     # -- compile / fit / predict / save ------------------------------------------------------------
     def compile(self, optimizer, loss):
@@ -336,7 +337,27 @@ class Model:
         <layer>/<weight>:0 with Keras' automatic layer names, training_config and the SGD iteration count + momentum
         accumulators under optimizer_weights), written by lisec_amd.hdf5_lite -- see lisec_amd/keras_h5.py.  A path
         ending in .npz gets a plain numpy archive with the names of lisec_amd.params.param_specs() instead."""
-        d = self.net.params.to_dict()
+        p = self.net.params
+        if self.dp is not None:
+            # data parallel: theta is identical on every rank, the BatchNormalization moving statistics are per
+            # replica (each rank saw its own samples).  The checkpoint carries their MEAN over the ranks and is
+            # written by rank 0 alone; the replicas' own statistics are left as they are.
+            own = p.state.clone()
+            self.dp.average_(p.state)
+            d = p.to_dict() if self.dp.rank == 0 else None
+            p.state.copy_(own)
+            if self.dp.rank != 0:
+                self.dp.barrier()
+                return
+        else:
+            d = p.to_dict()
+        try:
+            self._write(path, d)
+        finally:
+            if self.dp is not None:
+                self.dp.barrier()          # nobody reads the file before rank 0 has closed it
+
+    def _write(self, path, d):
         os.makedirs(os.path.dirname(os.path.abspath(path)) or ".", exist_ok=True)
         if str(path).endswith(".npz"):
             meta = dict(format="lisec_amd-npz-1", nx=self.nx, ny=self.ny, nz=self.nz, maxPoints=self.maxPoints,
@@ -425,7 +446,8 @@ def train(samples, level5Data, save_path):
     model.compile(optimizer=sgd, loss=['mse', 'mse'])
     history = model.fit(x=trainPoints, y=[outClass, outRegress], batch_size=1, verbose=1, epochs=1,
                         steps_per_epoch=180)
-    print(history.history)
+    if model.dp is None or model.dp.rank == 0:
+        print(history.history)
     model.save(save_path)
     return model
 
@@ -440,6 +462,7 @@ def train_with_model(samples, level5Data, model_path, save_path):
     model.compile(optimizer=sgd, loss=['mse', 'mse'])
     history = model.fit(x=trainPoints, y=[outClass, outRegress], batch_size=1, verbose=1, epochs=1,
                         steps_per_epoch=180)
-    print(history.history)
+    if model.dp is None or model.dp.rank == 0:
+        print(history.history)
     model.save(save_path)
     return model

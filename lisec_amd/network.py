@@ -131,7 +131,7 @@ class LisecNet:
     # ------------------------------------------------------------------------------------------------
     def _pack_all(self):
         """Repack theta into the kernels' [tap][K/4][N][4] layout (after every optimizer step)."""
-        if self._packed_version == self.params_version:
+        if self._packed_version == (self.params_version, self.params.version):
             return
         p = self.params
         if getattr(self, "_pack_table", None) is None:
@@ -150,7 +150,7 @@ class LisecNet:
                                               (p.view("reg.bias"), self.head_b[2:])], self.device)
         self._head_merge.run()
         ops.pack_weights(self.head_w, 1, 768, 16, 0, 16, 1, out=self.packed["head"])
-        self._packed_version = self.params_version
+        self._packed_version = (self.params_version, self.params.version)
 
     def _bn_after(self, c, training):
         p = self.params
@@ -160,11 +160,11 @@ class LisecNet:
                             p.view(c.bn + ".moving_mean"), p.view(c.bn + ".moving_variance"), True,
                             self.bnstate[c.bn])
             self.state_version += 1               # moving statistics moved, bnstate holds batch statistics
-        elif self._folded.get(c.bn) != (self.params_version, self.state_version):
+        elif self._folded.get(c.bn) != (self.params_version, self.state_version, p.version):
             # inference: scale/shift from the moving statistics, folded once per weight version (not per sweep)
             ops.bn_fold(p.view(c.bn + ".gamma"), p.view(c.bn + ".beta"), p.view(c.bn + ".moving_mean"),
                         p.view(c.bn + ".moving_variance"), C, self.bnstate[c.bn])
-            self._folded[c.bn] = (self.params_version, self.state_version)
+            self._folded[c.bn] = (self.params_version, self.state_version, p.version)
 
     def _run_conv(self, c, x, out, training):
         p = self.params
@@ -285,7 +285,7 @@ class LisecNet:
         self._train_ready = True
 
     def _pack_all_t(self):
-        if self._packed_t_version == self.params_version:
+        if self._packed_t_version == (self.params_version, self.params.version):
             return
         p = self.params
         if getattr(self, "_pack_table_t", None) is None:
@@ -299,7 +299,7 @@ class LisecNet:
             entries.append((self.head_w, self.packed_t["head"][0], 1, 16, 768, 0, 1, 16))
             self._pack_table_t = ops.PackTable(entries, self.device)
         self._pack_table_t.run()
-        self._packed_t_version = self.params_version
+        self._packed_t_version = (self.params_version, self.params.version)
 
     def backward(self, y_cls, y_reg, loss="mse", grad_scale=1.0, rpn_grads_ready=None):
         """y_cls (Ho,Wo,2), y_reg (Ho,Wo,14): float32 device tensors.  Fills self.grad (layout of theta)

@@ -12,6 +12,42 @@ import torch
 import torch.distributed as dist
 
 
+def resolve_device_index(env, device_count=None):
+    """Which GPU a rank uses: cuda:LOCAL_RANK, one process per GPU.  LISEC_BENCH_DEVICE overrides it for every rank
+    (several ranks on ONE card: only legal with the gloo backend, which tests use on a one-GPU box).  Pure function
+    of `env` (a mapping) so that it can be tested without a GPU."""
+    world = int(env.get("WORLD_SIZE", "1"))
+    local_rank = int(env.get("LOCAL_RANK", env.get("RANK", "0") if world > 1 else "0"))
+    override = env.get("LISEC_BENCH_DEVICE")
+    backend = env.get("LISEC_DIST_BACKEND") or "nccl"
+    if override is not None and override != "":
+        if world > 1 and backend == "nccl":
+            raise RuntimeError("LISEC_BENCH_DEVICE puts every rank on one GPU; RCCL (backend nccl) needs one GPU per "
+                               "rank -- set LISEC_DIST_BACKEND=gloo for a shared-card rehearsal")
+        idx = int(override)
+    else:
+        idx = local_rank if world > 1 else int(env.get("LISEC_DEVICE", "-1"))
+    if device_count is not None and idx >= device_count:
+        raise RuntimeError(f"rank with LOCAL_RANK={local_rank} wants cuda:{idx} but only {device_count} GPU(s) are "
+                           "visible: launch at most one rank per GPU")
+    return idx
+
+
+def select_device(local_rank=None, world=None):
+    """Binds this process to its GPU (torch.cuda.set_device) BEFORE any buffer is allocated and returns the
+    torch.device.  Single-process runs keep torch's current device unless LISEC_DEVICE names one."""
+    env = dict(os.environ)
+    if local_rank is not None:
+        env["LOCAL_RANK"] = str(local_rank)
+    if world is not None:
+        env["WORLD_SIZE"] = str(world)
+    idx = resolve_device_index(env, torch.cuda.device_count())
+    if idx < 0:
+        idx = torch.cuda.current_device()
+    torch.cuda.set_device(idx)
+    return torch.device("cuda", idx)
+
+
 class DataParallel:
     def __init__(self, device, backend=None):
         self.device = torch.device(device)
@@ -31,6 +67,27 @@ class DataParallel:
                                     world_size=int(os.environ.get("WORLD_SIZE", "1")), **kwargs)
             self._own_group = True
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        if self.on_gpu and self.world > 1 and dist.get_backend() == "nccl":
+            # one GPU per rank: two ranks of one host on the same card make RCCL fail late and obscurely
+            mine = (os.uname().nodename, self.device.index)
+            everyone = [None] * self.world
+            dist.all_gather_object(everyone, mine)
+            if len(set(everyone)) != self.world:
+                raise RuntimeError(f"data-parallel ranks share a GPU: {everyone}; each rank must own cuda:LOCAL_RANK")
+
+    def backend_name(self):
+        return dist.get_backend()
+
+    def rccl_ranks(self):
+        """Ranks taking part in RCCL collectives (0 when the backend is gloo)."""
+        return self.world if dist.get_backend() == "nccl" else 0
+
+    def gather_floats(self, x):
+        """[x of rank 0, x of rank 1, ...] on every rank."""
+        t = torch.tensor([x], dtype=torch.float64, device=self.device if self.on_gpu else "cpu")
+        out = [torch.zeros_like(t) for _ in range(self.world)]
+        dist.all_gather(out, t)
+        return [float(o.item()) for o in out]
 
     def shard(self, items):
         """Whole samples are dealt round-robin: rank r takes items r, r+world, ... (equal counts; the tail

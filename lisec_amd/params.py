@@ -89,6 +89,7 @@ class ParamStore:
                 ns += (n + 3) // 4 * 4
         self.n_theta, self.n_state = nt, ns
         self._views = {}
+        self.version = 0          # bumped by every external write (load_dict / touch): consumers repack on change
         self.theta = torch.zeros(nt, dtype=torch.float32, device=device)
         self.state = torch.zeros(ns, dtype=torch.float32, device=device)
         self.load_dict(init if init is not None else glorot_numpy())
@@ -123,6 +124,11 @@ class ParamStore:
             if tuple(a.shape) != tuple(shape):
                 raise ValueError(f"{name}: shape {a.shape} != {shape}")
             self.view(name).copy_(torch.from_numpy(np.ascontiguousarray(a)))
+        self.version += 1
+
+    def touch(self):
+        """Call after writing theta / state directly (e.g. a broadcast into them): invalidates every packed copy."""
+        self.version += 1
 
     def to_dict(self):
         return {name: self.view(name).detach().cpu().numpy().copy() for name, _, _ in self.specs}

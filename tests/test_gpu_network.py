@@ -99,7 +99,6 @@ def test_train_steps_small_grid_vs_oracle_autograd(loss):
         p64 = {k: v.float().double() for k, v in p64.items()}
         vel = {k: v.float().double() for k, v in vel.items()}
         net.params.load_dict({k: v.float() for k, v in p64.items()})
-        net.params_version += 1
         for n_, v_ in vel.items():
             net.params.grad_view(net.velocity, n_).copy_(v_.float())
         net.iterations = it

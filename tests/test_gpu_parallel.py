@@ -38,6 +38,12 @@ def _worker(rank, world, port, out_dir):
               epochs=1, steps_per_epoch=4, shuffle=False)
     torch.cuda.synchronize()
     np.save(os.path.join(out_dir, f"theta{rank}.npy"), model.net.params.theta.cpu().numpy())
+    np.save(os.path.join(out_dir, f"state{rank}.npy"), model.net.params.state.cpu().numpy())
+    # every rank calls save() on the SAME path (as train() does): rank 0 alone writes, the file carries the
+    # rank-mean of the per-replica BatchNormalization moving statistics, the replicas keep their own
+    model.save(os.path.join(out_dir, "ckpt.npz"))
+    assert os.path.exists(os.path.join(out_dir, "ckpt.npz"))       # closed before anyone passes the barrier
+    assert np.array_equal(model.net.params.state.cpu().numpy(), np.load(os.path.join(out_dir, f"state{rank}.npy")))
     model.dp.barrier()
     model.dp.close()
 
@@ -50,6 +56,12 @@ def test_two_ranks_train_identically_and_match_manual_averaging(tmp_path):
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     t0, t1 = np.load(tmp_path / "theta0.npy"), np.load(tmp_path / "theta1.npy")
     assert np.array_equal(t0, t1)                            # replicas stay bit-identical
+    s0, s1 = np.load(tmp_path / "state0.npy"), np.load(tmp_path / "state1.npy")
+    assert not np.array_equal(s0, s1)                        # per-replica moving statistics (different samples)
+    from lisec_amd import model_training as mt
+    ck = mt.load_model(str(tmp_path / "ckpt.npz"))
+    assert np.array_equal(ck.net.params.theta.cpu().numpy(), t0)
+    assert np.allclose(ck.net.params.state.cpu().numpy(), 0.5 * (s0.astype(np.float64) + s1), rtol=1e-6, atol=1e-7)
 
     # single process: same two steps with the per-rank gradients averaged by hand
     from lisec_amd import model_training as mt
@@ -72,3 +84,25 @@ def test_two_ranks_train_identically_and_match_manual_averaging(tmp_path):
     torch.cuda.synchronize()
     ref = net.params.theta.cpu().numpy()
     assert np.allclose(t0, ref, rtol=1e-5, atol=1e-6)
+
+
+def test_bench_self_launch_two_ranks_on_one_gpu():
+    """The exact path the driver's scaling run takes -- plain `python bench.py --gpus 2` -- rehearsed on the one-GPU
+    box: the launcher starts two fresh ranks, both pinned to cuda:0 (LISEC_BENCH_DEVICE), gradients averaged over
+    gloo instead of RCCL (which needs one GPU per rank).  Same step code, same timing reduction, same JSON."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(LISEC_DIST_BACKEND="gloo", LISEC_BENCH_DEVICE="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    j = lines[0]
+    assert j["n_gpus"] == 2 and j["config"]["global_batch"] == 2 and j["scaling"] == "weak"
+    assert j["dist_backend"] == "gloo" and j["rccl_ranks"] == 0 and len(j["ms_per_step_per_rank"]) == 2
+    assert j["value"] > 0 and np.isfinite(j["config"]["final_loss"])
+    assert abs(j["value"] - 2 * 3 / (j["ms_per_step"] * 3e-3)) < 1e-6 * j["value"]

@@ -29,7 +29,6 @@ for it in range(3):
                                                     torch.from_numpy(y_reg)[None].double(), it)
     # re-synchronise with the oracle's state so that rounding differences do not compound
     net.params.load_dict({k: v.float() for k, v in p64.items()})
-    net.params_version += 1
     net._prepare_training()
     for n_, v_ in vel.items():
         net.params.grad_view(net.velocity, n_).copy_(v_.float())
