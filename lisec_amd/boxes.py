@@ -25,7 +25,11 @@ def rpnToRegion(labelsClass, labelsRegress, maxBoxes=20, overlapThresh=0.):
     """rpnToRegion(labelsClass (100,200,2), labelsRegress (100,200,14)) -> (boxes (k,7), probs (k,))
     (rpnToRegion.py:113-164; the reference hard-codes maxBoxes=20, overlapThresh=0.).  Inputs may be numpy
     arrays or device tensors (e.g. views of LisecNet's head buffer).  Probability ties pick the larger flat
-    index (the reference's np.argsort order among equal keys is unspecified)."""
+    index (the reference's np.argsort order among equal keys is unspecified).
+    Deviation from the reference, on purpose: nonMaxSuppressionFast deletes the suppressed candidates with
+    np.delete(idxs, toDelete) where toDelete holds box INDICES (rpnToRegion.py:66-67) -- a positional delete that
+    removes unrelated entries and raises IndexError on numpy >= 1.19 for any realistic map.  Here the boxes found to
+    overlap (IoU > overlapThresh) or to lie out of range are the ones suppressed (by value)."""
     dev = _lib.require_gpu()
     lib = _lib.load()
     cfg = _cfg()

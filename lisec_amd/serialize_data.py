@@ -34,12 +34,17 @@ def combine_lidar_data(sample, dataDir, dataset=None):
 
 
 def fixBoxScaling(dataSize, newX, newY, origX, origY):
-    """fixBoxScaling (serialize_data.py:184-191): x, l scaled by newX/origX and y, w by newY/origY (in a copy)."""
-    out = np.array(dataSize, dtype=np.float64, copy=True)
-    out[:, 0] *= newX / origX
-    out[:, 3] *= newX / origX
-    out[:, 1] *= newY / origY
-    out[:, 4] *= newY / origY
+    """fixBoxScaling(data.shape, newX, newY, origX, origY) (serialize_data.py:184-191): takes the SHAPE (rows, 7) of
+    the label table and returns the multiplier matrix of that shape -- columns 0 and 3 (x, length) newX/origX, columns
+    1 and 4 (y, width) newY/origY, everything else 1 -- which the caller applies as `data * fixBoxScaling(data.shape,
+    ...)` (:217).  preprocessLabels applies the same scaling itself."""
+    out = np.ones(tuple(dataSize), dtype=np.float64)
+    if out.ndim != 2 or out.shape[1] < 5:
+        raise ValueError("fixBoxScaling expects the shape (rows, >= 5) of a label table")
+    out[:, 0] = newX / origX
+    out[:, 1] = newY / origY
+    out[:, 3] = newX / origX
+    out[:, 4] = newY / origY
     return out
 
 

@@ -201,7 +201,14 @@ def decode_boxes(labelsRegress, nx=200, ny=400, voxelx=0.5, voxely=0.25, anchors
 
 def nms(boxInfo, probInfo, overlapThresh=0.0, maxBoxes=20, anchor=(1.6, 3.9)):
     """nonMaxSuppressionFast (rpnToRegion.py:18-72).  Ties in probability: the larger flat index is taken first
-    (the reference's np.argsort order among equal keys is unspecified).  Returns picked indices."""
+    (the reference's np.argsort order among equal keys is unspecified).  Returns picked indices.
+
+    INTENDED semantics, one deliberate deviation: the reference collects the suppressed BOX indices in `toDelete`
+    and then calls np.delete(idxs, toDelete) (:66-67), which removes by POSITION in the shrinking `idxs` list, not by
+    value -- it drops unrelated candidates and raises IndexError (numpy >= 1.19) as soon as a box index exceeds the
+    list length, i.e. on every real 40 000-candidate map.  This restatement (and boxes.hip, which is checked against
+    it) suppresses the boxes that were actually found to overlap / lie out of range: by value, via an alive[] mask.
+    The positional delete is NOT reproduced."""
     alive = np.ones(len(probInfo), dtype=bool)
     pick = []
     while alive.any():

@@ -122,15 +122,54 @@ def test_sparse_tensor_surface_and_dense_input():
     assert mt.get_voxel((-0.1, 0.3, 0.6), 0.5, 0.25, 0.25) == (-1, 1, 2)
 
 
-def test_gpu_lidar_ingest_matches_numpy(tmp_path):
-    """combine_lidar_data_gpu == the numpy combine_lidar_data (float64, 1e-12) and feeds the voxeliser."""
+def test_gpu_lidar_transform_known_answers_and_oracle():
+    """lisec_lidar_transform (the C ABI entry) against oracle/ingest_ref.py: the hand-computed known answers
+    (identity, +-90 degrees about each axis, 180 degrees, a NON-UNIT quaternion) and random sensors, float64."""
+    import ctypes
+    import torch
+    from lisec_amd import _lib
+    from lisec_amd import model_training as mt
+    from oracle import ingest_ref
+    lib, dev = _lib.load(), _lib.require_gpu()
+
+    def transform(raw5, q, t):
+        d_raw = torch.from_numpy(np.ascontiguousarray(raw5, dtype=np.float32)).to(dev)
+        out = torch.empty((len(raw5), 3), dtype=torch.float64, device=dev)
+        R = np.ascontiguousarray(mt._quaternion_matrix(q), dtype=np.float64)
+        tt = np.ascontiguousarray(t, dtype=np.float64)
+        _lib.check(lib.lisec_lidar_transform(_lib.ptr(d_raw), len(raw5), 5,
+                                             R.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                                             tt.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), _lib.ptr(out),
+                                             _lib.current_stream()))
+        return out.cpu().numpy()
+
+    for q, inverse, p, want in ingest_ref.KNOWN_ANSWERS:
+        if inverse:
+            continue                                              # the ingest path only rotates forwards (:93)
+        raw = np.zeros((1, 5), np.float32)
+        raw[0, :3] = p
+        raw[0, 3:] = 7.0                                          # intensity / ring columns are ignored (:90)
+        got = transform(raw, q, (0.25, -1.5, 2.0))
+        assert np.allclose(got[0], np.array(want) + (0.25, -1.5, 2.0), rtol=0, atol=1e-14)
+    rng = np.random.default_rng(9)
+    for _ in range(5):
+        raw = rng.normal(0, 30, (4097, 5)).astype(np.float32)
+        q, t = rng.normal(0, 1, 4) * rng.uniform(0.2, 5), rng.normal(0, 3, 3)
+        want = ingest_ref.rotate_points(raw[:, :3], q) + t
+        assert np.allclose(transform(raw, q, t), want, rtol=1e-13, atol=1e-12)
+
+
+def test_gpu_lidar_ingest_matches_oracle(tmp_path):
+    """combine_lidar_data_gpu == oracle/ingest_ref.combine_lidar_data (float64, 1e-12) and feeds the voxeliser."""
     import torch
     from lisec_amd import model_training as mt
+    from oracle import ingest_ref
     rng = np.random.default_rng(4)
     root = tmp_path / "lyft"
     l5 = FakeLevel5(str(root), 2, rng)
     for smp in l5.samples:
-        ref = mt.combine_lidar_data(smp, str(root), l5)
+        ref = ingest_ref.combine_lidar_data(smp, str(root), l5)
+        assert np.allclose(mt.combine_lidar_data(smp, str(root), l5), ref, rtol=1e-13, atol=1e-12)
         got = mt.combine_lidar_data_gpu(smp, str(root), l5)
         assert got.dtype == torch.float64 and tuple(got.shape) == ref.shape
         assert np.allclose(got.cpu().numpy(), ref, rtol=1e-12, atol=1e-12)

@@ -150,7 +150,67 @@ def test_train_steps_small_grid_vs_oracle_autograd(loss):
         p64, vel = p64_new, vel_new
 
 
-def _hybrid_oracle_lyft(op, pts, training, y_cls=None, y_reg=None, dtype=torch.float64):
+def test_train_step_fully_occupied_grid_vs_oracle():
+    """Every cell of the grid occupied (a dense (D,H,W,T,6) array handed to the model, as Model.fit accepts): there is
+    no "empty cell" class, the constant row V of the per-voxel outputs is defined as 0 and must not be read from
+    uninitialised memory (the saved buffer is poisoned with NaN first).  One training step vs the dense
+    autograd oracle in fp64."""
+    from lisec_amd import _lib
+    from lisec_amd import model_training as mt
+    from lisec_amd.network import LisecNet
+    from lisec_amd.params import ParamStore
+    from oracle import model_ref as M
+
+    rng = np.random.default_rng(12)
+    D, H, W, T = 8, 16, 32, 35
+    dense = rng.normal(0, 1, (D, H, W, T, 6)).astype(np.float32)
+    dense[:, :, :, 20:, :] *= (rng.uniform(0, 1, (D, H, W, 1, 1)) < 0.5)       # some voxels with zero (pad-like) rows
+    assert (np.abs(dense).reshape(D * H * W, -1).max(1) > 0).all()
+    op = M.glorot_params(seed=34, randomize_bn=True)
+    dev = torch.device("cuda")
+    net = LisecNet(H, W, D, T, params=ParamStore(dev, init=op))
+    sample = mt.dense_to_sample(dense, dev)
+    assert sample.host_info()["V"] == D * H * W
+    net.vfe._saved = torch.full((_lib.load().lisec_vfe_saved_floats(sample.cap),), float("nan"), device=dev)
+    y_cls = rng.integers(0, 3, (H // 2, W // 2, 2)).astype(np.float32)
+    y_reg = rng.normal(0, 1, (H // 2, W // 2, 14)).astype(np.float32)
+    p64 = {k: v.double() for k, v in op.items()}
+    vel = {n: torch.zeros_like(p64[n]) for n, _, k in M.param_specs() if M.is_trainable(k)}
+    x = torch.from_numpy(dense)[None].double()
+    taps = {}
+    cls_r, reg_r = M.forward(p64, x, training=True, stats={}, taps=taps)
+    kink = min(float(v.abs().min()) for k, v in taps.items() if ".z" in k) < 5e-6
+    loss_r, grads_r, _, _, _ = M.train_step(p64, vel, x, torch.from_numpy(y_cls)[None].double(),
+                                            torch.from_numpy(y_reg)[None].double(), 0)
+    lo = net.train_step(sample, torch.from_numpy(y_cls).to(dev), torch.from_numpy(y_reg).to(dev))
+    torch.cuda.synchronize()
+    close(net.act["grid"].cpu().numpy(), taps["vfe_grid"][0].numpy(), what="vfe grid (all cells occupied)")
+    assert torch.isfinite(net.grad).all() and torch.isfinite(net.params.theta).all()
+    vout = net.vfe.saved_field("vout").cpu().numpy()
+    assert (vout[D * H * W] == 0).all() and (net.vfe.saved_field("delta").cpu().numpy()[D * H * W] == 0).all()
+    assert abs(lo[0].item() - loss_r.item()) <= 1e-5 * abs(loss_r.item())
+    gtol = 1e-1 if kink else 3e-3
+    for name, g in grads_r.items():
+        got = net.params.grad_view(net.grad, name).cpu().numpy()
+        ref = g.numpy()
+        if ".conv" in name and name.endswith(".bias") and np.abs(ref).max() < 1e-12:
+            assert np.abs(got).max() < 1e-5, name
+            continue
+        err, tol = np.abs(got - ref).max(), gtol * np.abs(ref).max() + 1e-7
+        assert err <= tol, f"grad {name}: err {err:.3e} tol {tol:.3e}"
+
+
+def _oracle_loss(cls, reg, yc, yr, loss):
+    """'mse': compile(loss=['mse','mse']) (model_training.py:296); 'smoothl1_ce': the sigmoid cross-entropy +
+    SmoothL1 pair BASELINE.json's config 4 names (lisec_rpn_loss kind 1)."""
+    from oracle import model_ref as M
+    import torch.nn.functional as F
+    if loss == "mse":
+        return M.mse_loss(cls, reg, yc, yr)
+    return F.binary_cross_entropy_with_logits(cls, yc.clamp(0, 1)) + F.smooth_l1_loss(reg, yr)
+
+
+def _hybrid_oracle_lyft(op, pts, training, y_cls=None, y_reg=None, dtype=torch.float64, loss="mse"):
     """Full Lyft grid on the CPU: VFE by the fp64 row-class oracle (proven equal to the dense VFE in
     tests/test_oracle_model.py), everything from the first Conv3D on by the dense torch oracle in fp64
     (autograd for the gradients), VFE gradients by the row-class backward."""
@@ -181,7 +241,7 @@ def _hybrid_oracle_lyft(op, pts, training, y_cls=None, y_reg=None, dtype=torch.f
         work[n] = p64[n].clone().requires_grad_(True)
     g.requires_grad_(True)
     cls, reg = M.forward_from_grid(work, g, training=True, stats={})
-    loss = M.mse_loss(cls, reg, torch.from_numpy(y_cls)[None].to(dtype), torch.from_numpy(y_reg)[None].to(dtype))
+    loss = _oracle_loss(cls, reg, torch.from_numpy(y_cls)[None].to(dtype), torch.from_numpy(y_reg)[None].to(dtype), loss)
     loss.backward()
     grads = {n: work[n].grad.double().numpy() for n in names}
     dg = g.grad.double().numpy().reshape(ncells, 64)
@@ -192,59 +252,102 @@ def _hybrid_oracle_lyft(op, pts, training, y_cls=None, y_reg=None, dtype=torch.f
     return cls.detach(), reg.detach(), loss.item(), grads
 
 
-def test_full_lyft_grid_forward_and_training_step_vs_oracle():
-    """BASELINE configs 3 and 4 at the real grid (8,200,400,35): RPN class/regression maps in inference and
-    training mode, the loss and EVERY gradient of one training step, vs the CPU oracle in fp64.
+def u20k(seed, n=20000):
+    rng = np.random.default_rng(seed)
+    return np.stack([rng.uniform(-55, 55, n), rng.uniform(-55, 55, n), rng.uniform(-0.5, 2.5, n)], 1).astype(np.float32)
 
-    Gradient tolerance: at this size the gradients below the RPN are ill-conditioned in fp32 (BatchNormalization
-    backward subtracts the mean and the yhat-projection of a gradient that is almost entirely along them): the
-    ORACLE ITSELF evaluated in fp32 differs from its fp64 self by 0.3-5 % on those tensors.  So each gradient
-    must be within 3e-3 + 3x (the fp32 oracle's own worst relative distance from fp64 in that block of layers)."""
+
+def full_grid_gradient_report(pts, loss, seed=5, wseed=77):
+    """One training step at the Lyft grid on the GPU and in the CPU oracle (fp64 = truth, fp32 = what the SAME math
+    gives in the product's arithmetic).  Returns (maps/loss dict, rows) with rows = (name, max|ref|, gpu relative
+    error, fp32-oracle relative error), both relative to max|ref| of that tensor."""
     from conftest import LYFT
     from lisec_amd.network import LisecNet
     from lisec_amd.params import ParamStore
     from lisec_amd.voxelizer import Voxelizer
     from oracle import model_ref as M
-
-    rng = np.random.default_rng(5)
-    n = 20000
-    pts = np.stack([rng.uniform(-55, 55, n), rng.uniform(-55, 55, n), rng.uniform(-0.5, 2.5, n)], 1).astype(np.float32)
-    op = M.glorot_params(seed=77, randomize_bn=True)
+    rng = np.random.default_rng(seed)
+    op = M.glorot_params(seed=wseed, randomize_bn=True)
     dev = torch.device("cuda")
     net = LisecNet(200, 400, 8, 35, params=ParamStore(dev, init=op))
     sample = Voxelizer(**LYFT)(pts)
-    cls, reg = net.forward(sample, training=False)
+    y_cls = rng.integers(0, 3, (100, 200, 2)).astype(np.float32)
+    y_reg = rng.normal(0, 1, (100, 200, 14)).astype(np.float32)
+    net.forward(sample, training=True)
+    lo = net.backward(torch.from_numpy(y_cls).to(dev), torch.from_numpy(y_reg).to(dev), loss=loss)
+    torch.cuda.synchronize()
+    cls_t, reg_t, loss_r, grads_r = _hybrid_oracle_lyft(op, pts, True, y_cls, y_reg, loss=loss)
+    _, _, _, grads_32 = _hybrid_oracle_lyft(op, pts, True, y_cls, y_reg, dtype=torch.float32, loss=loss)
+    rows = []
+    for name, ref in grads_r.items():
+        got = net.params.grad_view(net.grad, name).cpu().numpy()
+        scale = np.abs(ref).max()
+        if ".conv" in name and name.endswith(".bias") and scale < 1e-10:
+            # bias of a conv feeding a training-mode BatchNormalization: the exact gradient is 0
+            assert np.abs(got).max() < 1e-5, name
+            continue
+        rows.append((name, scale, np.abs(got - ref).max() / scale, np.abs(grads_32[name] - ref).max() / scale))
+    out = dict(head=net.act["head"].cpu().numpy(), cls=cls_t[0].numpy(), reg=reg_t[0].numpy(), loss=float(lo[0].item()),
+               loss_ref=loss_r)
+    return out, rows
+
+
+def test_full_lyft_grid_inference_vs_oracle():
+    """BASELINE config 3 at the real grid (8,200,400,35): RPN class/regression maps in inference mode vs the CPU
+    oracle in fp64, rtol 1e-3."""
+    from conftest import LYFT
+    from lisec_amd.network import LisecNet
+    from lisec_amd.params import ParamStore
+    from lisec_amd.voxelizer import Voxelizer
+    from oracle import model_ref as M
+    pts = u20k(5)
+    op = M.glorot_params(seed=77, randomize_bn=True)
+    net = LisecNet(200, 400, 8, 35, params=ParamStore(torch.device("cuda"), init=op))
+    cls, reg = net.forward(Voxelizer(**LYFT)(pts), training=False)
     cls_r, reg_r, _, _ = _hybrid_oracle_lyft(op, pts, training=False)
     close(cls.cpu().numpy(), cls_r.numpy(), what="class map (inference)")
     close(reg.cpu().numpy(), reg_r.numpy(), what="regression map (inference)")
 
-    y_cls = rng.integers(0, 3, (100, 200, 2)).astype(np.float32)
-    y_reg = rng.normal(0, 1, (100, 200, 14)).astype(np.float32)
-    net.forward(sample, training=True)
-    lo = net.backward(torch.from_numpy(y_cls).to(dev), torch.from_numpy(y_reg).to(dev))
-    torch.cuda.synchronize()
-    cls_t, reg_t, loss_r, grads_r = _hybrid_oracle_lyft(op, pts, True, y_cls, y_reg)
-    _, _, _, grads_32 = _hybrid_oracle_lyft(op, pts, True, y_cls, y_reg, dtype=torch.float32)
-    close(net.act["head"][:, :, :2].cpu().numpy(), cls_t[0].numpy(), what="class map (training)")
-    close(net.act["head"][:, :, 2:].cpu().numpy(), reg_t[0].numpy(), what="regression map (training)")
-    assert abs(lo[0].item() - loss_r) <= 1e-5 * abs(loss_r)
-    worst = 0.0
-    # conditioning per block of layers: the largest relative fp32-vs-fp64 distance of the oracle's own tensors
-    cond = {}
-    for name, ref in grads_r.items():
-        if np.abs(ref).max() > 1e-10:
-            blk = name.split(".")[0]
-            cond[blk] = max(cond.get(blk, 0.0), np.abs(grads_32[name] - ref).max() / np.abs(ref).max())
-    for name, ref in grads_r.items():
-        got = net.params.grad_view(net.grad, name).cpu().numpy()
-        if ".conv" in name and name.endswith(".bias") and np.abs(ref).max() < 1e-10:
-            assert np.abs(got).max() < 1e-5, name
-            continue
-        tol = (3e-3 + 3.0 * cond[name.split(".")[0]]) * np.abs(ref).max() + 1e-9
-        err = np.abs(got - ref).max()
-        assert err <= tol, f"grad {name}: err {err:.3e} tol {tol:.3e} (max ref {np.abs(ref).max():.3e})"
-        worst = max(worst, err / np.abs(ref).max())
-    assert worst < 0.1
+
+# Per-tensor gradient bound at the full grid.  Below the RPN the gradients are ill-conditioned in fp32 on a sparse
+# sweep (98 % of the cells hold one constant, BatchNormalization backward subtracts the mean and the yhat-projection
+# of a gradient that lies almost entirely along them): the ORACLE ITSELF evaluated in fp32 differs from its fp64
+# self by 0.3-5 % on those tensors.  Every tensor must be within FLAT of the fp64 oracle, or within OWN x the fp32
+# oracle's distance ON THAT SAME TENSOR (per tensor, not per block of layers).
+FLAT, OWN = 3e-3, 1.5
+
+
+@pytest.mark.parametrize("loss", ["mse", "smoothl1_ce"])
+def test_full_lyft_grid_training_step_vs_oracle(loss):
+    """BASELINE config 4 at the real grid, U20k sweep: training-mode maps, the loss and EVERY gradient of one step,
+    for the reference's MSE+MSE pair (model_training.py:296) and for SmoothL1 + cross-entropy (config 4 as worded)."""
+    out, rows = full_grid_gradient_report(u20k(5), loss)
+    close(out["head"][:, :, :2], out["cls"], what="class map (training)")
+    close(out["head"][:, :, 2:], out["reg"], what="regression map (training)")
+    assert abs(out["loss"] - out["loss_ref"]) <= 1e-5 * abs(out["loss_ref"])
+    bad = [f"{n}: gpu {e:.2e} vs fp32-oracle {o:.2e} (max|ref| {sc:.2e})" for n, sc, e, o in rows
+           if e > max(FLAT, OWN * o)]
+    assert not bad, "gradients beyond max(3e-3, 1.5 x the fp32 oracle's own error):\n" + "\n".join(bad)
+    assert max(e for _, _, e, _ in rows) < 0.1
+
+
+def dense_sweep(seed, n=700000):
+    """A sweep that fills most of the grid (about two thirds of the 640 000 cells occupied): the maps vary from
+    position to position, the BatchNormalization backward no longer cancels to a small remainder, and fp32 holds
+    3e-3 outright on every tensor."""
+    rng = np.random.default_rng(seed)
+    return np.stack([rng.uniform(-49.4, 49.9, n), rng.uniform(-49.7, 49.9, n), rng.uniform(0.26, 1.99, n)],
+                    1).astype(np.float32)
+
+
+def test_full_lyft_grid_training_step_well_conditioned():
+    """The same step on a well-conditioned full-grid case: every gradient within 3e-3 of the fp64 oracle, flat."""
+    out, rows = full_grid_gradient_report(dense_sweep(6), "mse", seed=6)
+    close(out["head"][:, :, :2], out["cls"], what="class map (training, dense sweep)")
+    close(out["head"][:, :, 2:], out["reg"], what="regression map (training, dense sweep)")
+    assert abs(out["loss"] - out["loss_ref"]) <= 1e-5 * abs(out["loss_ref"])
+    bad = [f"{n}: gpu {e:.2e} (fp32-oracle {o:.2e})" for n, sc, e, o in rows if e > FLAT]
+    assert not bad, "gradients beyond 3e-3:\n" + "\n".join(bad)
 
 
 def test_lyft_grid_r200k_cloud_and_empty_cloud():

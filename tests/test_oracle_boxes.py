@@ -76,3 +76,52 @@ def test_labels_small_scene_and_decode_nms_roundtrip():
     pick = B.nms(boxes, probs, overlapThresh=0.0, maxBoxes=20)
     assert len(pick) == 21 and pick[0] == 40 * 200 + 100 and pick[1] == 20000 + 70 * 200 + 30
     assert (41 * 200 + 100) not in pick
+
+
+def test_fix_box_scaling_matches_reference_golden(golden_dir):
+    """fixBoxScaling keeps the reference's contract -- SHAPE in, multiplier matrix out, applied as
+    `data * fixBoxScaling(data.shape, ...)` (serialize_data.py:184-191, :217).  Golden = the reference function
+    itself, run by tests/golden/make_box_goldens.py."""
+    import os
+    from lisec_amd import serialize_data as sd
+    g = np.load(os.path.join(golden_dir, "box_fixscaling.npz"))
+    for i in range(4):
+        a = g[f"args{i}"]
+        got = sd.fixBoxScaling((int(a[0]), int(a[1])), int(a[2]), int(a[3]), int(a[4]), int(a[5]))
+        assert got.shape == g[f"mult{i}"].shape and np.array_equal(got, g[f"mult{i}"])
+    data = g["data"]
+    assert np.array_equal(data * sd.fixBoxScaling(data.shape, 100, 200, 200, 400), g["fixed"])
+    # the scaling preprocessLabels / the oracle apply internally is the same table
+    fixed = data.copy()
+    fixed[:, [0, 3]] *= 100 / 200
+    fixed[:, [1, 4]] *= 200 / 400
+    assert np.array_equal(fixed, g["fixed"])
+
+
+def test_nms_by_value_known_answer():
+    """Hand-computed NMS case (the by-value suppression this build intends; the reference's positional np.delete,
+    rpnToRegion.py:66-67, is deliberately not reproduced -- see oracle/boxes_ref.nms).
+    Five boxes l=2, w=4, h=1.5, yaw 0 -- boxToShapely (serialize_data.py:151-163) puts the WIDTH along x and the
+    length along y at yaw 0, so each covers x +-2, y +-1 -- probabilities descending with index:
+      0 at (20,20)            picked first
+      1 at (20.5,20)          overlaps 0 (intersection 3.5 x 2 > 0)      -> suppressed by 0
+      2 at (60,60)            far from 0                                  -> picked second
+      3 at (1.0,50)           x - 1.6 < 0: out of range (:56-60)          -> dropped in the first sweep, never picked
+      4 at (60,61)            overlaps 2 (intersection 4 x 1), not 0      -> survives sweep 1, suppressed by 2
+      5 at (60,64)            2 m clear of 4, touches nothing picked      -> picked third
+    overlapThresh = 0 as rpnToRegion calls it (:158)."""
+    boxes = np.array([[20.0, 20.0, 1.0, 2.0, 4.0, 1.5, 0.0],
+                      [20.5, 20.0, 1.0, 2.0, 4.0, 1.5, 0.0],
+                      [60.0, 60.0, 1.0, 2.0, 4.0, 1.5, 0.0],
+                      [1.0, 50.0, 1.0, 2.0, 4.0, 1.5, 0.0],
+                      [60.0, 61.0, 1.0, 2.0, 4.0, 1.5, 0.0],
+                      [60.0, 64.0, 1.0, 2.0, 4.0, 1.5, 0.0]])
+    probs = np.array([0.9, 0.8, 0.7, 0.6, 0.5, 0.4])
+    assert B.nms(boxes, probs, overlapThresh=0.0, maxBoxes=20) == [0, 2, 5]
+    # the reference's positional delete: after the first pick idxs = [5, 4, 3, 2, 1] (ascending probability) and
+    # toDelete = [3, 1] (box indices) removes POSITIONS 3 and 1, i.e. boxes 2 and 4 -- not the boxes found; and an
+    # index beyond the list raises on numpy >= 1.19.  The by-value rule is the only total, meaningful one.
+    import pytest
+    assert list(np.delete(np.array([5, 4, 3, 2, 1]), [3, 1])) == [5, 3, 1]
+    with pytest.raises(IndexError):
+        np.delete(np.array([5, 4]), [4])
