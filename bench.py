@@ -292,6 +292,7 @@ def main():
             "ms_per_step_per_rank": [1e3 * t / args.steps for t in per_rank],
             "dist_backend": dp.backend_name() if dp is not None else None,
             "rccl_ranks": dp.rccl_ranks() if dp is not None else 0,
+            "gradient_exchange": dp.exchange_name() if dp is not None else None,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"Lyft grid 8x200x400x35, {args.cloud.upper()} synthetic cloud, 1 sample/GPU/step, "

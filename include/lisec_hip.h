@@ -348,6 +348,27 @@ int lisec_sgd_nesterov_step(float* theta, const float* grad, float* velocity, lo
 int lisec_scale(float* x, long long n, float s, lisec_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * 4b. Data-parallel gradient exchange.  The reference trains in ONE process
+ *     (model.fit, model_training.py:299); here whole samples are sharded over one process per GPU and the
+ *     only exchange of a step is the all-reduce of the flat gradient buffer, followed by identical
+ *     lisec_sgd_nesterov_step calls on every rank.
+ *     lisec_comm_t is an RCCL communicator (ncclComm_t): make one with lisec_comm_unique_id (one rank;
+ *     ship the LISEC_COMM_ID_BYTES to the others by any means) + lisec_comm_init (every rank, after
+ *     hipSetDevice), or pass a communicator the caller already owns.  RCCL is resolved at run time from the
+ *     copy the process has loaded (librccl.so.1).
+ *     lisec_allreduce_grads: grad[0..n) <- sum over ranks / world, in place, enqueued on `stream` (RCCL
+ *     all-reduce + the scale kernel).  `world` is the divisor (the communicator's size for a mean).  Call it
+ *     on sub-ranges of the buffer to overlap the exchange with the rest of the backward pass: the RPN + head
+ *     gradients -- the tail of the buffer, 94 % of it -- are final long before the middle/VFE ones.
+ * ------------------------------------------------------------------------------------------ */
+#define LISEC_COMM_ID_BYTES 128
+typedef void* lisec_comm_t; /* ncclComm_t */
+int lisec_comm_unique_id(void* id /* LISEC_COMM_ID_BYTES, host */);
+int lisec_comm_init(int rank, int world, const void* id, lisec_comm_t* comm);
+int lisec_comm_destroy(lisec_comm_t comm);
+int lisec_allreduce_grads(lisec_comm_t comm, float* grad, long long n, int world, lisec_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * 5. Box geometry either side of the network; float64 like the reference.
  *    Anchor grid of rpnToRegion.py:75-150 / serialize_data.py:201-232: outX x outY cells of vx x vy metres
  *    (nx/2, ny/2, 2*voxelx, 2*voxely), two anchors (l, w, h, yaw) per cell.

@@ -143,6 +143,14 @@ def _declare(lib):
     lib.lisec_sgd_nesterov_step.argtypes = [P, P, P, LL, c_float, c_float, P]
     lib.lisec_scale.restype = c_int
     lib.lisec_scale.argtypes = [P, LL, c_float, P]
+    lib.lisec_comm_unique_id.restype = c_int
+    lib.lisec_comm_unique_id.argtypes = [ctypes.c_char_p]
+    lib.lisec_comm_init.restype = c_int
+    lib.lisec_comm_init.argtypes = [c_int, c_int, ctypes.c_char_p, POINTER(c_void_p)]
+    lib.lisec_comm_destroy.restype = c_int
+    lib.lisec_comm_destroy.argtypes = [P]
+    lib.lisec_allreduce_grads.restype = c_int
+    lib.lisec_allreduce_grads.argtypes = [P, P, LL, c_int, P]
     lib.lisec_bn_finalize.restype = c_int
     lib.lisec_bn_finalize.argtypes = [P, c_int, c_int, c_double, P, P, P, P, c_int, P, P]
     lib.lisec_bn_fold.restype = c_int

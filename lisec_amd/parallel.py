@@ -3,9 +3,16 @@
 The reference has no distributed code (single process, CPU).  Its fit(batch_size=1) semantics are kept
 per replica (BatchNormalization statistics are per-sample, never synchronised); the only exchange per
 step is ONE all-reduce of the contiguous 6.49 M-float gradient buffer (26 MB) over xGMI, followed by
-identical SGD-Nesterov updates on every rank.  backend "nccl" is RCCL on ROCm; "gloo" is used by the
-CPU tests of this host logic.
+identical SGD-Nesterov updates on every rank.
+
+Two planes.  Control (rendezvous, parameter broadcast, barriers, timing reductions): torch.distributed,
+backend "nccl" (= RCCL on ROCm) on GPUs, "gloo" in the CPU tests of this host logic.  Data (the gradient
+exchange of every step): the C ABI's lisec_allreduce_grads on an RCCL communicator of its own
+(lisec_comm_unique_id / lisec_comm_init; the 128-byte id travels over the control plane), enqueued on a
+dedicated HIP stream -- exactly what a C caller of include/lisec_hip.h would do.  LISEC_ALLREDUCE=torch
+routes the exchange through torch.distributed.all_reduce instead (gloo runs always do).
 """
+import ctypes
 import os
 
 import torch
@@ -74,6 +81,30 @@ class DataParallel:
             dist.all_gather_object(everyone, mine)
             if len(set(everyone)) != self.world:
                 raise RuntimeError(f"data-parallel ranks share a GPU: {everyone}; each rank must own cuda:LOCAL_RANK")
+        self.comm = None                 # lisec_comm_t (RCCL communicator) of the data plane
+        self.comm_stream = None
+        if self.on_gpu and dist.get_backend() == "nccl" and os.environ.get("LISEC_ALLREDUCE", "rccl") != "torch":
+            self._init_comm()
+
+    def _init_comm(self):
+        from . import _lib
+        lib = _lib.load()
+        ident = ctypes.create_string_buffer(128)                 # LISEC_COMM_ID_BYTES
+        if self.rank == 0:
+            _lib.check(lib.lisec_comm_unique_id(ident))
+        box = [bytes(ident.raw)]
+        if self.world > 1:
+            dist.broadcast_object_list(box, src=0)
+        comm = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(lib.lisec_comm_init(self.rank, self.world, box[0], ctypes.byref(comm)))
+        self.comm = comm
+        self.comm_stream = torch.cuda.Stream(device=self.device)
+        self._comm_event = torch.cuda.Event()
+
+    def exchange_name(self):
+        """What carries the gradient exchange: 'lisec_allreduce_grads (RCCL)' or 'torch.distributed.<backend>'."""
+        return "lisec_allreduce_grads (RCCL)" if self.comm is not None else "torch.distributed." + dist.get_backend()
 
     def backend_name(self):
         return dist.get_backend()
@@ -103,6 +134,11 @@ class DataParallel:
         """In-place mean over ranks (sum all-reduce, then * 1/world)."""
         if self.world == 1:
             return tensor
+        if self.comm is not None and tensor.is_cuda and tensor.dtype == torch.float32 and tensor.numel() % 4 == 0:
+            from . import _lib
+            _lib.check(_lib.load().lisec_allreduce_grads(self.comm, _lib.ptr(tensor), tensor.numel(), self.world,
+                                                         _lib.current_stream()))
+            return tensor
         dist.all_reduce(tensor, op=dist.ReduceOp.SUM)
         if self.on_gpu:
             from . import ops
@@ -129,6 +165,11 @@ class DataParallel:
             dist.barrier()
 
     def close(self):
+        if self.comm is not None:
+            from . import _lib
+            torch.cuda.synchronize(self.device)
+            _lib.load().lisec_comm_destroy(self.comm)
+            self.comm = None
         if self._own_group and dist.is_initialized():
             dist.destroy_process_group()
 
@@ -142,14 +183,40 @@ class _BucketedAverage:
     def __call__(self, grad):                      # plain single-bucket fallback
         return self.dp.average_(grad)
 
+    def _enqueue(self, grad, lo, hi, after):
+        """lisec_allreduce_grads of grad[lo:hi] on the communicator's own stream, after everything enqueued so far on
+        the stream handle `after` (one stream per communicator keeps RCCL's issue order trivially identical on
+        every rank; the later kernels of the producing stream do not queue behind the collective)."""
+        from . import _lib
+        dp = self.dp
+        ev = dp._comm_event
+        ev.record(torch.cuda.ExternalStream(after, device=dp.device))
+        dp.comm_stream.wait_event(ev)
+        _lib.check(_lib.load().lisec_allreduce_grads(dp.comm, grad.data_ptr() + 4 * lo, hi - lo, dp.world,
+                                                     dp.comm_stream.cuda_stream))
+
     def start_tail(self, grad, lo, hi):
         if not self.active:
             return
         self.lo = lo
+        if self.dp.comm is not None:
+            from . import _lib
+            self._enqueue(grad, lo, hi, _lib.current_stream())
+            self.work = "rccl"
+            return
         self.work = dist.all_reduce(grad[lo:hi], op=dist.ReduceOp.SUM, async_op=True)
 
     def finish(self, grad):
         if not self.active:
+            return grad
+        if self.dp.comm is not None:
+            from . import _lib
+            lo = self.lo if self.work is not None else grad.numel()
+            self._enqueue(grad, 0, lo, _lib.current_stream())       # the head (or everything, if no tail went out)
+            self.work = None
+            done = self.dp._comm_event
+            done.record(self.dp.comm_stream)
+            torch.cuda.current_stream().wait_event(done)            # the optimizer reads the averaged gradient
             return grad
         if self.work is None:
             return self.dp.average_(grad)

@@ -106,3 +106,55 @@ def test_bench_self_launch_two_ranks_on_one_gpu():
     assert j["dist_backend"] == "gloo" and j["rccl_ranks"] == 0 and len(j["ms_per_step_per_rank"]) == 2
     assert j["value"] > 0 and np.isfinite(j["config"]["final_loss"])
     assert abs(j["value"] - 2 * 3 / (j["ms_per_step"] * 3e-3)) < 1e-6 * j["value"]
+
+
+def test_rccl_allreduce_entry_one_rank():
+    """lisec_comm_unique_id / lisec_comm_init / lisec_allreduce_grads / lisec_comm_destroy (include/lisec_hip.h 4b)
+    straight through ctypes, as a C caller would use them: a one-rank RCCL communicator on this GPU, sum over the
+    (single) rank divided by `world`, in place, on an explicit stream."""
+    import ctypes
+    from lisec_amd import _lib
+    lib = _lib.load()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    ident = ctypes.create_string_buffer(128)
+    _lib.check(lib.lisec_comm_unique_id(ident))
+    assert any(ident.raw)
+    comm = ctypes.c_void_p()
+    _lib.check(lib.lisec_comm_init(0, 1, bytes(ident.raw), ctypes.byref(comm)))
+    assert comm.value
+    rng = np.random.default_rng(0)
+    host = rng.normal(0, 1, 6_491_072).astype(np.float32)         # the size of the flat gradient buffer
+    x = torch.from_numpy(host).to(dev)
+    st = torch.cuda.Stream(device=dev)
+    st.wait_stream(torch.cuda.current_stream())
+    _lib.check(lib.lisec_allreduce_grads(comm, x.data_ptr(), x.numel(), 4, st.cuda_stream))          # divisor 4
+    lo = 1_000_000                                                                                    # a sub-range
+    _lib.check(lib.lisec_allreduce_grads(comm, x.data_ptr() + 4 * lo, x.numel() - lo, 1, st.cuda_stream))
+    st.synchronize()
+    assert np.array_equal(x.cpu().numpy(), host * np.float32(0.25))
+    assert lib.lisec_allreduce_grads(comm, x.data_ptr(), 6, 1, st.cuda_stream) != 0                   # n % 4 != 0: refused
+    assert b"multiple of 4" in lib.lisec_last_error()
+    _lib.check(lib.lisec_comm_destroy(comm))
+
+
+def test_bench_one_rank_through_rccl_data_plane():
+    """bench.py with LISEC_FORCE_DP=1: one rank, backend nccl, and the gradient exchange of every step going through
+    lisec_allreduce_grads on the C ABI's own RCCL communicator (both buckets) -- the code the N-GPU run executes."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env.update(LISEC_FORCE_DP="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.pop("LISEC_DIST_BACKEND", None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")][0]
+    assert j["dist_backend"] == "nccl" and j["rccl_ranks"] == 1
+    assert j["gradient_exchange"] == "lisec_allreduce_grads (RCCL)"
+    assert np.isfinite(j["config"]["final_loss"]) and j["value"] > 0
