@@ -55,6 +55,17 @@ typedef struct {
 enum { LISEC_VI_NVOX = 0, LISEC_VI_NROWS = 1, LISEC_VI_NVALID = 2, LISEC_VI_MAXCOUNT = 3,
        LISEC_VI_OVERFLOW = 4 };
 
+/* Optional per-sweep side output of lisec_voxelize, input of lisec_vfe_forward: int64[LISEC_ROW_STATS_WORDS].
+ *   words [0, LISEC_ROW_STATS_MOMENT_WORDS): the first and second moments of the feature rows -- sum of x_k (6) and
+ *     of x_j*x_k (21, j <= k) over all kept rows, as order-independent two-limb fixed-point sums in
+ *     LISEC_ROW_STATS_REPLICAS replicas ([replica][27][2]).  The first Dense of the VFE stack has no bias and no
+ *     activation in front of its BatchNormalization (model_training.py:171-173,184), so the batch statistics of that
+ *     layer are a closed form of these moments and of the kernel: the VFE needs no pass over the rows for them.
+ *   the remaining words: scratch of lisec_vfe_forward, zeroed by lisec_voxelize and left zeroed by every forward. */
+#define LISEC_ROW_STATS_REPLICAS 16
+#define LISEC_ROW_STATS_MOMENT_WORDS (LISEC_ROW_STATS_REPLICAS * 27 * 2)
+#define LISEC_ROW_STATS_WORDS (LISEC_ROW_STATS_MOMENT_WORDS + 4 * 64 * 2)
+
 size_t lisec_voxelize_workspace_bytes(const lisec_voxel_cfg* cfg, int n_points);
 
 /*
@@ -72,12 +83,13 @@ size_t lisec_voxelize_workspace_bytes(const lisec_voxel_cfg* cfg, int n_points);
  *                  (model_training.py:135-140), voxel v owns rows row_start[v]..+npts[v];
  *                  ascending original point index, first sampleSize kept
  * row_point   dev  int32[n_points] or NULL: original point index of every row
+ * row_stats   dev  int64[LISEC_ROW_STATS_WORDS] or NULL: see above
  */
 int lisec_voxelize(const lisec_voxel_cfg* cfg, const void* points, int dtype, int n_points,
                    int point_stride, void* workspace, size_t workspace_bytes, int cap_voxels,
                    int32_t* info, int32_t* cell_voxel, int32_t* coords, int32_t* counts,
                    int32_t* npts, int32_t* row_start, float* rows, int32_t* row_point,
-                   lisec_stream_t stream);
+                   int64_t* row_stats, lisec_stream_t stream);
 
 /* Expands compact rows into the zero padded (V, T, 6) block layout the reference's
  * SparseTensor / dense tensor uses (model_training.py:141-152).  padded: float32[V*T*6]. */
@@ -119,12 +131,13 @@ size_t lisec_vfe_workspace_bytes(void);
  * info/cell_voxel/npts/row_start/rows: outputs of lisec_voxelize (device).
  * ncells = NZ*NX*NY, T = sampleSize.  training != 0: batch statistics (Keras fit), moving stats
  * updated; training == 0: moving statistics (Keras predict, Predict.py:38).
+ * row_stats: the voxeliser's side output (NULL: the moments are summed here, one more launch).
  * grid  dev float32[ncells*64]: (D,H,W,64), every cell written (empty cells hold relu(BN3(.)) != 0).
  */
 int lisec_vfe_forward(const lisec_vfe_params* p, const int32_t* info, const int32_t* cell_voxel,
-                      const int32_t* npts, const int32_t* row_start, const float* rows, int ncells, int T,
-                      int cap_voxels, int training, float* saved, void* workspace, size_t workspace_bytes,
-                      float* grid, lisec_stream_t stream);
+                      const int32_t* npts, const int32_t* row_start, const float* rows, int64_t* row_stats,
+                      int ncells, int T, int cap_voxels, int training, float* saved, void* workspace,
+                      size_t workspace_bytes, float* grid, lisec_stream_t stream);
 
 /* Re-materialises the dense grid from the `saved` buffer of the last lisec_vfe_forward (the HBM-bound
  * writer on its own: lets a caller recycle the 164 MB grid buffer, and lets bench.py time the writer). */
@@ -343,6 +356,14 @@ int lisec_rpn_loss(const float* head, const float* y_cls, const float* y_reg, lo
  * v <- m*v - lr_t*g;  w <- w + m*v - lr_t*g;  lr_t = lr/(1 + decay*iterations) is computed by the caller. */
 int lisec_sgd_nesterov_step(float* theta, const float* grad, float* velocity, long long n, float lr_t,
                             float momentum, lisec_stream_t stream);
+
+/* The same update with the iteration count kept on the DEVICE, so that a HIP graph captured over a whole training
+ * step can be replayed (kernel arguments are frozen in a graph): state = long long[2] {iterations, 0} (the second
+ * word is scratch and must be 0 between calls); the kernel computes lr_t = (float)(lr / (1 + decay*iterations)) in
+ * double, exactly what the host computes for lisec_sgd_nesterov_step, and increments iterations once every
+ * workgroup has read it. */
+int lisec_sgd_nesterov_step_dev(float* theta, const float* grad, float* velocity, long long n, double lr,
+                                double decay, float momentum, long long* state, lisec_stream_t stream);
 
 /* x *= s  (gradient averaging after the data-parallel all-reduce) */
 int lisec_scale(float* x, long long n, float s, lisec_stream_t stream);

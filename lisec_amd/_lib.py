@@ -53,6 +53,10 @@ class ConvGeom(Structure):
                                      "out_stride", "ps", "ps_channels")]
 
 
+ROW_STATS_REPLICAS = 16                       # LISEC_ROW_STATS_* of include/lisec_hip.h
+ROW_STATS_MOMENT_WORDS = ROW_STATS_REPLICAS * 27 * 2
+ROW_STATS_WORDS = ROW_STATS_MOMENT_WORDS + 4 * 64 * 2
+
 _lib = None
 
 
@@ -67,7 +71,7 @@ def _declare(lib):
     lib.lisec_voxelize_workspace_bytes.argtypes = [POINTER(VoxelCfg), c_int]
     lib.lisec_voxelize.restype = c_int
     lib.lisec_voxelize.argtypes = [POINTER(VoxelCfg), P, c_int, c_int, c_int, P, c_size_t, c_int,
-                                   P, P, P, P, P, P, P, P, P]
+                                   P, P, P, P, P, P, P, P, P, P]
     lib.lisec_voxel_rows_to_padded.restype = c_int
     lib.lisec_voxel_rows_to_padded.argtypes = [P, P, P, P, c_int, c_int, P, P]
     lib.lisec_vfe_saved_floats.restype = c_size_t
@@ -141,6 +145,8 @@ def _declare(lib):
     lib.lisec_rpn_loss.argtypes = [P, P, P, LL, c_int, c_float, P, P, P, c_size_t, P]
     lib.lisec_sgd_nesterov_step.restype = c_int
     lib.lisec_sgd_nesterov_step.argtypes = [P, P, P, LL, c_float, c_float, P]
+    lib.lisec_sgd_nesterov_step_dev.restype = c_int
+    lib.lisec_sgd_nesterov_step_dev.argtypes = [P, P, P, LL, c_double, c_double, c_float, P, P]
     lib.lisec_scale.restype = c_int
     lib.lisec_scale.argtypes = [P, LL, c_float, P]
     lib.lisec_comm_unique_id.restype = c_int
@@ -156,7 +162,7 @@ def _declare(lib):
     lib.lisec_bn_fold.restype = c_int
     lib.lisec_bn_fold.argtypes = [P, P, P, P, c_int, P, P]
     lib.lisec_vfe_forward.restype = c_int
-    lib.lisec_vfe_forward.argtypes = [POINTER(VfeParams), P, P, P, P, P, c_int, c_int, c_int, c_int, P, P,
+    lib.lisec_vfe_forward.argtypes = [POINTER(VfeParams), P, P, P, P, P, P, c_int, c_int, c_int, c_int, P, P,
                                       c_size_t, P, P]
 
 

@@ -60,6 +60,25 @@ struct Carver {
 #ifdef __HIPCC__
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
+// Order-independent (hence deterministic) cross-workgroup sums of doubles: a value is split into two integer limbs
+// (units of 2^-8 and 2^-40) that are added with 64-bit integer atomics; integer addition commutes, so the total does not
+// depend on the arrival order.  Resolution 2^-40 per addend; exact range |total| < 2^45, graceful beyond.
+__device__ __forceinline__ void fx_split(double s, long long& hi, long long& lo) {
+    double h = floor(s * 256.0);
+    h = fmin(fmax(h, -9.0e18), 9.0e18);
+    hi = (long long)h;
+    lo = (long long)rint((s - h * (1.0 / 256.0)) * 1099511627776.0);
+}
+__device__ __forceinline__ double fx_join(long long hi, long long lo) {
+    return (double)hi * (1.0 / 256.0) + (double)lo * (1.0 / 1099511627776.0);
+}
+__device__ __forceinline__ void fx_atomic_add(long long* acc, double s) {      // acc[0] = hi limb, acc[1] = lo limb
+    long long hi, lo;
+    fx_split(s, hi, lo);
+    atomicAdd(reinterpret_cast<unsigned long long*>(acc), (unsigned long long)hi);
+    atomicAdd(reinterpret_cast<unsigned long long*>(acc + 1), (unsigned long long)lo);
+}
+
 template <typename T>
 __device__ __forceinline__ T wave_sum(T v) {
 #pragma unroll

@@ -206,6 +206,32 @@ __global__ void k_sgd_nesterov(float* __restrict__ w, const float* __restrict__ 
     }
 }
 
+// The same update with the iteration count on the device (a captured HIP graph of the step bakes kernel arguments in):
+// state[0] = iterations, state[1] = ticket (0 between launches).  Every workgroup reads state[0] before it takes its
+// ticket; the workgroup that takes the last one increments the count, i.e. after all of them have read it.
+__global__ void k_sgd_nesterov_dev(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ v,
+                                   long long n4, double lr, double decay, float mom, long long* __restrict__ state) {
+    const long long it = __hip_atomic_load(&state[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const float lr_t = (float)(lr / (1.0 + decay * (double)it));       // what the host computes in double, then rounds
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        float4 W = reinterpret_cast<float4*>(w)[i], V = reinterpret_cast<float4*>(v)[i];
+        const float4 G = reinterpret_cast<const float4*>(g)[i];
+#define LISEC_UPD(f) { float nv = mom * V.f - lr_t * G.f; V.f = nv; W.f = W.f + mom * nv - lr_t * G.f; }
+        LISEC_UPD(x) LISEC_UPD(y) LISEC_UPD(z) LISEC_UPD(w)
+#undef LISEC_UPD
+        reinterpret_cast<float4*>(w)[i] = W;
+        reinterpret_cast<float4*>(v)[i] = V;
+    }
+    __syncthreads();                                                   // every wave of this workgroup has read `it`
+    if (threadIdx.x == 0) {
+        const unsigned long long t = atomicAdd(reinterpret_cast<unsigned long long*>(&state[1]), 1ULL);
+        if (t == (unsigned long long)gridDim.x - 1) {
+            __hip_atomic_store(&state[1], 0LL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&state[0], it + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 __global__ void k_scale(float* __restrict__ x, long long n4, float s) {
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
         float4 a = reinterpret_cast<float4*>(x)[i];
@@ -361,6 +387,16 @@ extern "C" int lisec_sgd_nesterov_step(float* theta, const float* grad, float* v
     if (n == 0) return LISEC_OK;
     hipLaunchKernelGGL(k_sgd_nesterov, dim3(ew_blocks(n / 4)), dim3(kEwThreads), 0, static_cast<hipStream_t>(stream_),
                        theta, grad, velocity, n / 4, lr_t, momentum);
+    LISEC_LAUNCH_CHECK();
+    return LISEC_OK;
+}
+
+extern "C" int lisec_sgd_nesterov_step_dev(float* theta, const float* grad, float* velocity, long long n, double lr,
+                                           double decay, float momentum, long long* state, lisec_stream_t stream_) {
+    LISEC_CHECK_ARG(theta && grad && velocity && state && n >= 0 && n % 4 == 0, "sgd: n must be a multiple of 4");
+    if (n == 0) return LISEC_OK;
+    hipLaunchKernelGGL(k_sgd_nesterov_dev, dim3(ew_blocks(n / 4)), dim3(kEwThreads), 0, static_cast<hipStream_t>(stream_),
+                       theta, grad, velocity, n / 4, lr, decay, momentum, state);
     LISEC_LAUNCH_CHECK();
     return LISEC_OK;
 }

@@ -16,12 +16,13 @@
 // so max_t relu(BN(y_t)) == relu(BN(max_t y_t or min_t y_t)): only per-voxel max/min of the pre-BN
 // value are kept ("ymm"), nothing per row is stored and each stage recomputes the cheap lower layers.
 //
-// Training needs a grid-wide BN reduction per layer => 3 stage kernels; the statistics of layer L are
-// finalised in the PROLOGUE of stage L+1 (every workgroup sums the 256 per-workgroup partials in the
-// same fixed order while its weight loads are in flight; workgroup 0 also stores bnstate and updates
-// the moving statistics), so only layer 3 needs a finaliser launch of its own (one workgroup per
-// channel) in front of the grid writer: 5 launches.  Inference (moving statistics) runs the three
-// passes inside one kernel: 2 launches.  Voxel metadata and input rows are prefetched one and two
+// Training needs the batch statistics of a layer before the next layer can run => a launch boundary
+// per BatchNormalization -- except the first one, whose statistics are a closed form of the row moments
+// the voxeliser leaves in row_stats (Dense(6,16) has no bias and only the input in front of it).  The
+// statistics of layers 2 and 3 are summed across workgroups in two-limb fixed-point integer accumulators
+// (order-independent, hence deterministic) and finalised in the PROLOGUE of the consuming kernel by every
+// workgroup (workgroup 0 also stores bnstate and updates the moving statistics): 3 launches -- layers
+// 1+2, layer 3, grid writer.  Inference (moving statistics) runs the three passes in one kernel: 2 launches.  Voxel metadata and input rows are prefetched one and two
 // voxels ahead (the stage kernels are latency-, not throughput-bound on a 20 k-point sweep).  The
 // last kernel streams the dense (D,H,W,64) grid: 164 MB for the Lyft grid, the HBM-bound part of this
 // file (empty cells hold the non-zero constant relu(BN3(.)), so the write is compulsory), and writes
@@ -31,54 +32,49 @@
 namespace lisec {
 namespace {
 
-constexpr int kFwdBlocks = 256;      // one workgroup per CU; also the number of statistic partials per layer
+constexpr int kFwdBlocks = 256;      // one workgroup per CU
 constexpr int kFwdThreads = 512;     // 8 waves
 constexpr int kFwdWaves = kFwdThreads / 64;
+constexpr int kAccReplicas = 4;      // replicas of the cross-workgroup statistic accumulators (atomic contention)
 
-// Sums parts[nparts][2][C] (double) over the workgroups in a FIXED order (thread (grp, col) takes parts grp,
-// grp + ngrp, ... in index order, then the groups are combined in index order): every workgroup of the
-// consuming kernel computes bit-identical scale / shift.  Result in LDS: sbn[0..C) = scale, sbn[C..2C) = shift.
-// Workgroup 0 also stores the bnstate the backward reads and updates the moving statistics (biased batch
-// variance: the rank-6 VFE path of Keras is not the fused one).
+// Cross-workgroup statistic accumulators: long long[kAccReplicas][2*C][2] two-limb fixed-point sums (common.h):
+// integer atomics commute, so the totals -- and everything derived from them -- are deterministic.
 template <int C>
-__device__ __forceinline__ void block_finalize(const double* __restrict__ parts, int nparts, double N,
-                                               const float* __restrict__ gamma, const float* __restrict__ beta,
-                                               float* __restrict__ mmean, float* __restrict__ mvar,
-                                               float* __restrict__ bnsaved, float* sbn, double* red) {
-    constexpr int cols = 2 * C, ngrp = kFwdThreads / cols;
-    const int col = threadIdx.x % cols, grp = threadIdx.x / cols;
-    double a = 0.0;
-    int b = grp;
-    for (; b + 3 * ngrp < nparts; b += 4 * ngrp) {
-        const double v0 = parts[(size_t)b * cols + col];
-        const double v1 = parts[(size_t)(b + ngrp) * cols + col];
-        const double v2 = parts[(size_t)(b + 2 * ngrp) * cols + col];
-        const double v3 = parts[(size_t)(b + 3 * ngrp) * cols + col];
-        a += v0; a += v1; a += v2; a += v3;
-    }
-    for (; b < nparts; b += ngrp) a += parts[(size_t)b * cols + col];
-    red[grp * cols + col] = a;
-    __syncthreads();
-    if (threadIdx.x < C) {
-        const int c = threadIdx.x;
-        double s1 = 0.0, s2 = 0.0;
+__device__ __forceinline__ void acc_add(long long* acc, int q, int c, double v) {
+    fx_atomic_add(acc + ((size_t)(blockIdx.x % kAccReplicas) * 2 * C + q * C + c) * 2, v);
+}
+template <int C>
+__device__ __forceinline__ double acc_read(const long long* acc, int q, int c) {
+    long long hi = 0, lo = 0;
 #pragma unroll
-        for (int g = 0; g < ngrp; ++g) { s1 += red[g * cols + c]; s2 += red[g * cols + C + c]; }
-        const double mean = s1 / N;
-        double var = s2 / N - mean * mean;             // biased; fp64 so the cancellation is harmless
-        if (var < 0.0) var = 0.0;
-        const double inv = 1.0 / sqrt(var + (double)kBnEps);
-        const double scale = (double)gamma[c] * inv;
-        const float fsc = (float)scale, fsh = (float)((double)beta[c] - mean * scale);
-        sbn[c] = fsc;
-        sbn[C + c] = fsh;
-        if (blockIdx.x == 0) {
-            bnsaved[c] = fsc; bnsaved[C + c] = fsh; bnsaved[2 * C + c] = (float)mean; bnsaved[3 * C + c] = (float)inv;
-            mmean[c] = (float)((double)mmean[c] * (double)kBnMomentum + mean * (1.0 - (double)kBnMomentum));
-            mvar[c] = (float)((double)mvar[c] * (double)kBnMomentum + var * (1.0 - (double)kBnMomentum));
-        }
+    for (int r = 0; r < kAccReplicas; ++r) {
+        const long long* p = acc + ((size_t)r * 2 * C + q * C + c) * 2;
+        hi += __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        lo += __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    __syncthreads();
+    return fx_join(hi, lo);
+}
+
+// BatchNormalization state of one channel from (sum y, sum y^2) over N dense rows: scale / shift into LDS; workgroup 0
+// also stores the bnstate the backward reads and updates the moving statistics (biased batch variance: the rank-6 VFE
+// path of Keras is not the fused one).
+template <int C>
+__device__ __forceinline__ void bn_from_sums(int c, double s1, double s2, double N, const float* __restrict__ gamma,
+                                             const float* __restrict__ beta, float* __restrict__ mmean,
+                                             float* __restrict__ mvar, float* __restrict__ bnsaved, float* sbn) {
+    const double mean = s1 / N;
+    double var = s2 / N - mean * mean;             // biased; fp64 so the cancellation is harmless
+    if (var < 0.0) var = 0.0;
+    const double inv = 1.0 / sqrt(var + (double)kBnEps);
+    const double scale = (double)gamma[c] * inv;
+    const float fsc = (float)scale, fsh = (float)((double)beta[c] - mean * scale);
+    sbn[c] = fsc;
+    sbn[C + c] = fsh;
+    if (blockIdx.x == 0) {
+        bnsaved[c] = fsc; bnsaved[C + c] = fsh; bnsaved[2 * C + c] = (float)mean; bnsaved[3 * C + c] = (float)inv;
+        mmean[c] = (float)((double)mmean[c] * (double)kBnMomentum + mean * (1.0 - (double)kBnMomentum));
+        mvar[c] = (float)((double)mvar[c] * (double)kBnMomentum + var * (1.0 - (double)kBnMomentum));
+    }
 }
 
 // inference: scale / shift from the moving statistics (what lisec_bn_fold computes), into LDS (+ bnsaved by workgroup 0)
@@ -107,43 +103,110 @@ struct StageBn {            // BatchNormalization variables of the three layers 
     float* saved[3];        // sv.bn1, sv.bn2, sv.bn3
 };
 
-// STAGE 1/2/3: training stage kernels (batch statistics of layer STAGE are reduced into parts_out; the
-// statistics of layer STAGE-1 are finalised from parts_in in the prologue);
-// STAGE 0: inference, all three passes, statistics from the moving averages.
+// Moments of the feature rows for callers that did not get them from the voxeliser (row_stats == NULL):
+// zero, then accumulate (same layout and arithmetic as voxelize.hip's k_features).
+__global__ void k_vfe_stats_zero(long long* __restrict__ stats) {
+    for (int i = threadIdx.x; i < LISEC_ROW_STATS_WORDS; i += blockDim.x) stats[i] = 0;
+}
+__global__ void __launch_bounds__(256)
+k_vfe_stats(VfeIn in, long long* __restrict__ stats) {
+    __shared__ double smom[4][27];
+    const int lane = lane_id(), w = threadIdx.x >> 6;
+    const int R = in.info[LISEC_VI_NROWS];
+    double mom[27];
+#pragma unroll
+    for (int k = 0; k < 27; ++k) mom[k] = 0.0;
+    for (int r = blockIdx.x * 256 + threadIdx.x; r < R; r += gridDim.x * 256) {
+        double f[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) f[k] = (double)in.rows[(size_t)r * 6 + k];
+        int q = 6;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            mom[j] += f[j];
+#pragma unroll
+            for (int k = j; k < 6; ++k) mom[q++] += f[j] * f[k];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 27; ++k) {
+        const double t = wave_sum(mom[k]);
+        if (lane == 0) smom[w][k] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < 27) {
+        const double t = ((smom[0][threadIdx.x] + smom[1][threadIdx.x]) + smom[2][threadIdx.x]) + smom[3][threadIdx.x];
+        if (t != 0.0) fx_atomic_add(stats + ((size_t)(blockIdx.x % LISEC_ROW_STATS_REPLICAS) * 27 + threadIdx.x) * 2, t);
+    }
+}
+
+// STAGE 2: training, layers 1 + 2.  BatchNormalization 1 needs no pass over the rows: Dense(6,16) has no bias and
+//          nothing but the input in front of it, so (sum y, sum y^2) of channel c are w_c . m and w_c^T S w_c with the
+//          row moments m, S the voxeliser left in row_stats (pad rows and empty voxels add 0).  The batch statistics
+//          of layer 2 go to the accumulators acc_out.
+// STAGE 3: training, layer 3: statistics of layer 2 read from acc_in, those of layer 3 added to acc_out.
+// STAGE 0: inference, all three layers, statistics from the moving averages.
 template <int STAGE>
 __global__ void __launch_bounds__(kFwdThreads)
 k_vfe_stage(VfeIn in, const float* __restrict__ W1, const float* __restrict__ W2,
             const float* __restrict__ W3, StageBn bn, double N,
             float* __restrict__ ymm1, float* __restrict__ ymm2, float* __restrict__ ymm3,
-            const double* __restrict__ parts_in, double* __restrict__ parts_out) {
+            const long long* __restrict__ row_stats, const long long* __restrict__ acc_in,
+            long long* __restrict__ acc_out, long long* __restrict__ acc_zero) {
     __shared__ float sbn1[32], sbn2[64];
-    __shared__ double red[kFwdThreads > 2 * kFwdWaves * 64 ? kFwdThreads : 2 * kFwdWaves * 64];
+    __shared__ double red[2 * kFwdWaves * 64];
     const int lane = lane_id(), w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c1 = lane & 15, c2 = lane & 31;
     VfeWeights W;
-    W.load(W1, W2, W3, STAGE);                        // issued first: in flight while the statistics are summed
+    W.load(W1, W2, W3, STAGE);       // issued first: in flight while the statistics are finalised
     if (STAGE == 0) {
         block_fold<16>(bn.gamma[0], bn.beta[0], bn.mmean[0], bn.mvar[0], bn.saved[0], sbn1);
         block_fold<32>(bn.gamma[1], bn.beta[1], bn.mmean[1], bn.mvar[1], bn.saved[1], sbn2);
-        __syncthreads();
     } else if (STAGE == 2) {
-        block_finalize<16>(parts_in, kFwdBlocks, N, bn.gamma[0], bn.beta[0], bn.mmean[0], bn.mvar[0], bn.saved[0],
-                           sbn1, red);
+        // row moments -> LDS (27 doubles), then the closed form per channel
+        if (threadIdx.x < 27) {
+            long long hi = 0, lo = 0;
+#pragma unroll
+            for (int r = 0; r < LISEC_ROW_STATS_REPLICAS; ++r) {
+                const long long* p = row_stats + ((size_t)r * 27 + threadIdx.x) * 2;
+                hi += p[0]; lo += p[1];
+            }
+            red[threadIdx.x] = fx_join(hi, lo);
+        }
+        if (blockIdx.x == 0 && acc_zero)                 // the accumulators of the NEXT stage start at zero
+            for (int i = threadIdx.x; i < kAccReplicas * 2 * 64 * 2; i += kFwdThreads) acc_zero[i] = 0;
+        __syncthreads();
+        if (threadIdx.x < 16) {
+            const int c = threadIdx.x;
+            double wv[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) wv[k] = (double)W1[k * 16 + c];
+            double s1 = 0.0, s2 = 0.0;
+            int q = 6;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                s1 += wv[j] * red[j];
+#pragma unroll
+                for (int k = j; k < 6; ++k) { s2 += (j == k ? 1.0 : 2.0) * wv[j] * wv[k] * red[q]; ++q; }
+            }
+            bn_from_sums<16>(c, s1, s2, N, bn.gamma[0], bn.beta[0], bn.mmean[0], bn.mvar[0], bn.saved[0], sbn1);
+        }
     } else if (STAGE == 3) {
         if (threadIdx.x < 32) sbn1[threadIdx.x] = bn.saved[0][threadIdx.x];      // written by stage 2's workgroup 0
-        block_finalize<32>(parts_in, kFwdBlocks, N, bn.gamma[1], bn.beta[1], bn.mmean[1], bn.mvar[1], bn.saved[1],
-                           sbn2, red);
+        if (threadIdx.x < 32) {
+            const int c = threadIdx.x;
+            bn_from_sums<32>(c, acc_read<32>(acc_in, 0, c), acc_read<32>(acc_in, 1, c), N, bn.gamma[1], bn.beta[1],
+                             bn.mmean[1], bn.mvar[1], bn.saved[1], sbn2);
+        }
     }
-    float sc1 = 0, sh1 = 0, sc2 = 0, sh2 = 0;
-    if (STAGE != 1) { sc1 = sbn1[c1]; sh1 = sbn1[16 + c1]; }
+    __syncthreads();
+    float sc1 = sbn1[c1], sh1 = sbn1[16 + c1], sc2 = 0, sh2 = 0;
     if (STAGE == 0 || STAGE == 3) { sc2 = sbn2[c2]; sh2 = sbn2[32 + c2]; }
     // the pad row after layer 1 is the same everywhere: relu(BN1(0)) = relu(shift1)
     const float a1pad = fmaxf(sh1, 0.0f);
     float A2pad = 0.0f;                                     // a1pad @ W2[16:, :]
-    if (STAGE != 1) {
 #pragma unroll
-        for (int k = 0; k < 16; ++k) A2pad = fmaf(rl(a1pad, k), W.w2a[k], A2pad);
-    }
+    for (int k = 0; k < 16; ++k) A2pad = fmaf(rl(a1pad, k), W.w2a[k], A2pad);
     int V = in.info[LISEC_VI_NVOX];
     if (V > in.cap) V = in.cap;
     const int nE = in.ncells - V;
@@ -168,9 +231,9 @@ k_vfe_stage(VfeIn in, const float* __restrict__ W1, const float* __restrict__ W2
     };
     auto load_ymm = [&](int v, float& mx1, float& mn1, float& mx2, float& mn2) {
         mx1 = mn1 = mx2 = mn2 = 0.0f;
-        if (v < nvox) {
-            if (STAGE == 2 || STAGE == 3) { mx1 = ymm1[(size_t)v * 32 + c1]; mn1 = ymm1[(size_t)v * 32 + 16 + c1]; }
-            if (STAGE == 3) { mx2 = ymm2[(size_t)v * 64 + c2]; mn2 = ymm2[(size_t)v * 64 + 32 + c2]; }
+        if (STAGE == 3 && v < nvox) {
+            mx1 = ymm1[(size_t)v * 32 + c1]; mn1 = ymm1[(size_t)v * 32 + 16 + c1];
+            mx2 = ymm2[(size_t)v * 64 + c2]; mn2 = ymm2[(size_t)v * 64 + 32 + c2];
         }
     };
     int v = blockIdx.x * kFwdWaves + w;
@@ -192,9 +255,8 @@ k_vfe_stage(VfeIn in, const float* __restrict__ W1, const float* __restrict__ W2
         const bool has_pad = virt || s < in.T;
         const double wpad = virt ? (double)in.T * (double)nE : (double)(in.T - s);
         float mx1 = pmx1, mn1 = pmn1, mx2 = pmx2, mn2 = pmn2;
-        bool done = false;
-        // ---- pass 1: y1 = x @ W1 --------------------------------------------------------------
-        if (STAGE == 0 || STAGE == 1) {
+        // ---- pass 1: y1 = x @ W1 (per-voxel max / min only) ------------------------------------
+        if (STAGE == 0 || STAGE == 2) {
             mx1 = has_pad ? 0.0f : -INFINITY;               // pad row: 0 @ W1 == 0
             mn1 = has_pad ? 0.0f : INFINITY;
             for (int t = 0; t < s; ++t) {
@@ -202,77 +264,68 @@ k_vfe_stage(VfeIn in, const float* __restrict__ W1, const float* __restrict__ W2
 #pragma unroll
                 for (int k = 0; k < 6; ++k) y = fmaf(rl(xr[k], t), W.w1[k], y);
                 mx1 = fmaxf(mx1, y); mn1 = fminf(mn1, y);
-                if (STAGE == 1) { s1 += (double)y; s2 += (double)y * (double)y; }
             }
-            if (STAGE == 1) {
-                if (lane < 16) { ymm1[(size_t)v * 32 + lane] = mx1; ymm1[(size_t)v * 32 + 16 + lane] = mn1; }
-                done = true;
-            }
+            if (STAGE == 2 && lane < 16) { ymm1[(size_t)v * 32 + lane] = mx1; ymm1[(size_t)v * 32 + 16 + lane] = mn1; }
         }
-        if (!done) {
-            // ---- pass 2: y2 = [pool1, a1] @ W2 -------------------------------------------------
-            const float pool1 = pool_from(mx1, mn1, sc1, sh1);
-            float P2 = 0.0f;
+        // ---- pass 2: y2 = [pool1, a1] @ W2 -----------------------------------------------------
+        const float pool1 = pool_from(mx1, mn1, sc1, sh1);
+        float P2 = 0.0f;
 #pragma unroll
-            for (int k = 0; k < 16; ++k) P2 = fmaf(rl(pool1, k), W.w2p[k], P2);
-            if (STAGE == 0 || STAGE == 2) {
-                const float y2pad = P2 + A2pad;
-                mx2 = has_pad ? y2pad : -INFINITY;
-                mn2 = has_pad ? y2pad : INFINITY;
-                if (STAGE == 2 && has_pad) { s1 += wpad * (double)y2pad; s2 += wpad * (double)y2pad * (double)y2pad; }
-                for (int t = 0; t < s; ++t) {
-                    float y1 = 0.0f;
+        for (int k = 0; k < 16; ++k) P2 = fmaf(rl(pool1, k), W.w2p[k], P2);
+        if (STAGE == 0 || STAGE == 2) {
+            const float y2pad = P2 + A2pad;
+            mx2 = has_pad ? y2pad : -INFINITY;
+            mn2 = has_pad ? y2pad : INFINITY;
+            if (STAGE == 2 && has_pad) { s1 += wpad * (double)y2pad; s2 += wpad * (double)y2pad * (double)y2pad; }
+            for (int t = 0; t < s; ++t) {
+                float y1 = 0.0f;
 #pragma unroll
-                    for (int k = 0; k < 6; ++k) y1 = fmaf(rl(xr[k], t), W.w1[k], y1);
-                    const float a1 = bnrelu(y1, sc1, sh1);
-                    float y = 0.0f;
+                for (int k = 0; k < 6; ++k) y1 = fmaf(rl(xr[k], t), W.w1[k], y1);
+                const float a1 = bnrelu(y1, sc1, sh1);
+                float y = 0.0f;
 #pragma unroll
-                    for (int k = 0; k < 16; ++k) y = fmaf(rl(a1, k), W.w2a[k], y);
-                    y += P2;
-                    mx2 = fmaxf(mx2, y); mn2 = fminf(mn2, y);
-                    if (STAGE == 2) { s1 += (double)y; s2 += (double)y * (double)y; }
-                }
-                if (STAGE == 2) {
-                    if (lane < 32) { ymm2[(size_t)v * 64 + lane] = mx2; ymm2[(size_t)v * 64 + 32 + lane] = mn2; }
-                    done = true;
-                }
+                for (int k = 0; k < 16; ++k) y = fmaf(rl(a1, k), W.w2a[k], y);
+                y += P2;
+                mx2 = fmaxf(mx2, y); mn2 = fminf(mn2, y);
+                if (STAGE == 2) { s1 += (double)y; s2 += (double)y * (double)y; }
             }
-            if (!done) {
-                // ---- pass 3: y3 = [pool2, a2] @ W3 ---------------------------------------------
-                const float pool2 = pool_from(mx2, mn2, sc2, sh2);
-                float P3 = 0.0f;
+            if (STAGE == 2 && lane < 32) { ymm2[(size_t)v * 64 + lane] = mx2; ymm2[(size_t)v * 64 + 32 + lane] = mn2; }
+        }
+        if (STAGE != 2) {
+            // ---- pass 3: y3 = [pool2, a2] @ W3 -------------------------------------------------
+            const float pool2 = pool_from(mx2, mn2, sc2, sh2);
+            float P3 = 0.0f;
 #pragma unroll
-                for (int k = 0; k < 32; ++k) P3 = fmaf(rl(pool2, k), W.w3p[k], P3);
-                float mx3 = -INFINITY, mn3 = INFINITY;
-                if (has_pad) {
-                    const float a2pad = bnrelu(P2 + A2pad, sc2, sh2);
-                    float y = 0.0f;
+            for (int k = 0; k < 32; ++k) P3 = fmaf(rl(pool2, k), W.w3p[k], P3);
+            float mx3 = -INFINITY, mn3 = INFINITY;
+            if (has_pad) {
+                const float a2pad = bnrelu(P2 + A2pad, sc2, sh2);
+                float y = 0.0f;
 #pragma unroll
-                    for (int k = 0; k < 32; ++k) y = fmaf(rl(a2pad, k), W.w3a[k], y);
-                    y += P3;
-                    mx3 = y; mn3 = y;
-                    if (STAGE == 3) { s1 += wpad * (double)y; s2 += wpad * (double)y * (double)y; }
-                }
-                for (int t = 0; t < s; ++t) {
-                    float y1 = 0.0f;
-#pragma unroll
-                    for (int k = 0; k < 6; ++k) y1 = fmaf(rl(xr[k], t), W.w1[k], y1);
-                    const float a1 = bnrelu(y1, sc1, sh1);
-                    float y2 = 0.0f;
-#pragma unroll
-                    for (int k = 0; k < 16; ++k) y2 = fmaf(rl(a1, k), W.w2a[k], y2);
-                    y2 += P2;
-                    const float a2 = bnrelu(y2, sc2, sh2);
-                    float y = 0.0f;
-#pragma unroll
-                    for (int k = 0; k < 32; ++k) y = fmaf(rl(a2, k), W.w3a[k], y);
-                    y += P3;
-                    mx3 = fmaxf(mx3, y); mn3 = fminf(mn3, y);
-                    if (STAGE == 3) { s1 += (double)y; s2 += (double)y * (double)y; }
-                }
-                ymm3[(size_t)v * 128 + lane] = mx3;
-                ymm3[(size_t)v * 128 + 64 + lane] = mn3;
+                for (int k = 0; k < 32; ++k) y = fmaf(rl(a2pad, k), W.w3a[k], y);
+                y += P3;
+                mx3 = y; mn3 = y;
+                if (STAGE == 3) { s1 += wpad * (double)y; s2 += wpad * (double)y * (double)y; }
             }
+            for (int t = 0; t < s; ++t) {
+                float y1 = 0.0f;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) y1 = fmaf(rl(xr[k], t), W.w1[k], y1);
+                const float a1 = bnrelu(y1, sc1, sh1);
+                float y2 = 0.0f;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) y2 = fmaf(rl(a1, k), W.w2a[k], y2);
+                y2 += P2;
+                const float a2 = bnrelu(y2, sc2, sh2);
+                float y = 0.0f;
+#pragma unroll
+                for (int k = 0; k < 32; ++k) y = fmaf(rl(a2, k), W.w3a[k], y);
+                y += P3;
+                mx3 = fmaxf(mx3, y); mn3 = fminf(mn3, y);
+                if (STAGE == 3) { s1 += (double)y; s2 += (double)y * (double)y; }
+            }
+            ymm3[(size_t)v * 128 + lane] = mx3;
+            ymm3[(size_t)v * 128 + 64 + lane] = mn3;
         }
         s_cur = s_nxt; rs_cur = rs_nxt; s_nxt = s_n2; rs_nxt = rs_n2;
 #pragma unroll
@@ -280,18 +333,17 @@ k_vfe_stage(VfeIn in, const float* __restrict__ W1, const float* __restrict__ W2
         pmx1 = nmx1; pmn1 = nmn1; pmx2 = nmx2; pmn2 = nmn2;
     }
     if (STAGE != 0) {
-        constexpr int C = STAGE == 1 ? 16 : (STAGE == 2 ? 32 : 64);
-        __syncthreads();                                     // `red` may still be read by a slow wave's prologue
-        double* r0 = red;                                    // [2][kFwdWaves][64]
-        r0[(0 * kFwdWaves + w) * 64 + lane] = s1;
-        r0[(1 * kFwdWaves + w) * 64 + lane] = s2;
+        constexpr int C = STAGE == 2 ? 32 : 64;
+        __syncthreads();                                     // `red` was used by the prologue
+        red[(0 * kFwdWaves + w) * 64 + lane] = s1;
+        red[(1 * kFwdWaves + w) * 64 + lane] = s2;
         __syncthreads();
         if (threadIdx.x < 2 * C) {
             const int q = threadIdx.x / C, c = threadIdx.x % C;
             double a = 0.0;
 #pragma unroll
-            for (int k = 0; k < kFwdWaves; ++k) a += r0[(q * kFwdWaves + k) * 64 + c];
-            parts_out[((size_t)blockIdx.x * 2 + q) * C + c] = a;
+            for (int k = 0; k < kFwdWaves; ++k) a += red[(q * kFwdWaves + k) * 64 + c];
+            if (a != 0.0) acc_add<C>(acc_out, q, c, a);
         }
     } else if (blockIdx.x == 0) {
         // inference: the grid writer reads bn3 from `saved`
@@ -300,50 +352,38 @@ k_vfe_stage(VfeIn in, const float* __restrict__ W1, const float* __restrict__ W2
     }
 }
 
-// Statistics of the last layer: one workgroup per channel sums the kFwdBlocks partials (fixed tree order).
-__global__ void __launch_bounds__(kFwdBlocks)
-k_vfe_final3(const double* __restrict__ parts, double N, const float* __restrict__ gamma,
-             const float* __restrict__ beta, float* __restrict__ mmean, float* __restrict__ mvar,
-             float* __restrict__ st) {
-    constexpr int C = 64;
-    __shared__ double r1[kFwdBlocks], r2[kFwdBlocks];
-    const int c = blockIdx.x, t = threadIdx.x;
-    r1[t] = parts[((size_t)t * 2 + 0) * C + c];
-    r2[t] = parts[((size_t)t * 2 + 1) * C + c];
-    __syncthreads();
-    for (int o = kFwdBlocks / 2; o > 0; o >>= 1) {
-        if (t < o) { r1[t] += r1[t + o]; r2[t] += r2[t + o]; }
-        __syncthreads();
-    }
-    if (t == 0) {
-        const double mean = r1[0] / N;
-        double var = r2[0] / N - mean * mean;
-        if (var < 0.0) var = 0.0;
-        const double inv = 1.0 / sqrt(var + (double)kBnEps);
-        const double scale = (double)gamma[c] * inv;
-        st[c] = (float)scale;
-        st[C + c] = (float)((double)beta[c] - mean * scale);
-        st[2 * C + c] = (float)mean;
-        st[3 * C + c] = (float)inv;
-        mmean[c] = (float)((double)mmean[c] * (double)kBnMomentum + mean * (1.0 - (double)kBnMomentum));
-        mvar[c] = (float)((double)mvar[c] * (double)kBnMomentum + var * (1.0 - (double)kBnMomentum));
-    }
-}
-
 // Dense (ncells, 64) grid: occupied cells from their voxel's ymm3, empty cells from the virtual voxel.
+// acc3 != NULL (training): the statistics of layer 3 are finalised here, by every workgroup, from the accumulators
+// stage 3 filled (workgroup 0 stores bnstate / moving statistics and re-zeroes stage 2's accumulators, acc2_zero);
+// acc3 == NULL: bn3 is read from `saved` (inference, or a rewrite of the grid).
 // On the side (vout != NULL) the compact per-voxel outputs: vout[v] = the grid value of voxel v (v == V: the
 // constant every empty cell holds, 0 when the grid has no empty cell), delta[v] = vout[v] - vout[V] (what the
 // first Conv3D's sparse backward contracts against).
 __global__ void __launch_bounds__(256)
 k_vfe_grid(const int* __restrict__ info, const int* __restrict__ cell_voxel, int ncells, int cap,
-           const float* __restrict__ ymm3, const float* __restrict__ bn3, float* __restrict__ grid,
-           float* __restrict__ vout, float* __restrict__ delta) {
+           const float* __restrict__ ymm3, float* __restrict__ bn3, float* __restrict__ grid,
+           float* __restrict__ vout, float* __restrict__ delta, const long long* __restrict__ acc3, double N,
+           const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ mmean,
+           float* __restrict__ mvar, long long* __restrict__ acc2_zero) {
+    __shared__ float sbn3[128];
+    __shared__ double ssum[128];
+    if (acc3) {
+        if (threadIdx.x < 128) ssum[threadIdx.x] = acc_read<64>(acc3, threadIdx.x >> 6, threadIdx.x & 63);
+        __syncthreads();
+        if (threadIdx.x < 64)
+            bn_from_sums<64>(threadIdx.x, ssum[threadIdx.x], ssum[64 + threadIdx.x], N, gamma, beta, mmean, mvar, bn3, sbn3);
+        if (blockIdx.x == 0 && acc2_zero)
+            for (int i = threadIdx.x; i < kAccReplicas * 2 * 32 * 2; i += 256) acc2_zero[i] = 0;
+    } else if (threadIdx.x < 128) {
+        sbn3[threadIdx.x] = bn3[threadIdx.x];
+    }
+    __syncthreads();
     int V = info[LISEC_VI_NVOX];
     if (V > cap) V = cap;
     const bool has_empty = ncells - V > 0;                 // otherwise row V of ymm3 was never written
     const int q = threadIdx.x & 15;
-    const float4 sc = reinterpret_cast<const float4*>(bn3)[q];
-    const float4 sh = reinterpret_cast<const float4*>(bn3 + 64)[q];
+    const float4 sc = reinterpret_cast<const float4*>(sbn3)[q];
+    const float4 sh = reinterpret_cast<const float4*>(sbn3 + 64)[q];
     auto value = [&](int v) {
         const float4 mx = reinterpret_cast<const float4*>(ymm3 + (size_t)v * 128)[q];
         const float4 mn = reinterpret_cast<const float4*>(ymm3 + (size_t)v * 128 + 64)[q];
@@ -392,15 +432,16 @@ extern "C" size_t lisec_vfe_saved_floats(int cap_voxels) {
     return VfeSaved(nullptr, cap_voxels).floats;
 }
 
-// three partial tables (one per layer: stage L+1 reads table L while it writes table L+1)
+// the accumulators of layer 3 (+ a row_stats block for callers that pass none)
 extern "C" size_t lisec_vfe_workspace_bytes(void) {
-    return 3 * align_up(sizeof(double) * (size_t)kFwdBlocks * 2 * 64, 256);
+    return align_up(sizeof(long long) * (size_t)kAccReplicas * 2 * 64 * 2, 256) +
+           align_up(sizeof(long long) * (size_t)LISEC_ROW_STATS_WORDS, 256);
 }
 
 extern "C" int lisec_vfe_forward(const lisec_vfe_params* p, const int32_t* info,
                                  const int32_t* cell_voxel, const int32_t* npts,
-                                 const int32_t* row_start, const float* rows, int ncells, int T,
-                                 int cap_voxels, int training, float* saved, void* workspace,
+                                 const int32_t* row_start, const float* rows, int64_t* row_stats_, int ncells,
+                                 int T, int cap_voxels, int training, float* saved, void* workspace,
                                  size_t workspace_bytes, float* grid, lisec_stream_t stream_) {
     LISEC_CHECK_ARG(p && info && cell_voxel && npts && row_start && rows && saved && workspace && grid,
                     "NULL pointer");
@@ -416,9 +457,8 @@ extern "C" int lisec_vfe_forward(const lisec_vfe_params* p, const int32_t* info,
     VfeSaved sv(saved, cap_voxels);
     VfeIn in{info, npts, row_start, rows, ncells, T, cap_voxels};
     Carver carve(workspace);
-    double* parts1 = carve.take<double>((size_t)kFwdBlocks * 2 * 64);
-    double* parts2 = carve.take<double>((size_t)kFwdBlocks * 2 * 64);
-    double* parts3 = carve.take<double>((size_t)kFwdBlocks * 2 * 64);
+    long long* acc3 = carve.take<long long>((size_t)kAccReplicas * 2 * 64 * 2);
+    long long* own_stats = carve.take<long long>(LISEC_ROW_STATS_WORDS);
     const double N = (double)ncells * (double)T;        // dense rows Keras reduces over (B = 1)
     StageBn bn;
     float* saved_bn[3] = {sv.bn1, sv.bn2, sv.bn3};
@@ -429,22 +469,32 @@ extern "C" int lisec_vfe_forward(const lisec_vfe_params* p, const int32_t* info,
     }
     dim3 g(kFwdBlocks), b(kFwdThreads);
     if (training) {
-        hipLaunchKernelGGL(k_vfe_stage<1>, g, b, 0, st, in, p->kernel[0], p->kernel[1], p->kernel[2], bn, N,
-                           sv.ymm1, sv.ymm2, sv.ymm3, (const double*)nullptr, parts1);
+        long long* stats = reinterpret_cast<long long*>(row_stats_);
+        if (!stats) {                                   // no moments from the voxeliser: sum them here
+            stats = own_stats;
+            hipLaunchKernelGGL(k_vfe_stats_zero, dim3(1), dim3(1024), 0, st, stats);
+            hipLaunchKernelGGL(k_vfe_stats, dim3(kFwdBlocks), dim3(256), 0, st, in, stats);
+        }
+        long long* acc2 = stats + LISEC_ROW_STATS_MOMENT_WORDS;       // zero on entry, re-zeroed by the grid writer
         hipLaunchKernelGGL(k_vfe_stage<2>, g, b, 0, st, in, p->kernel[0], p->kernel[1], p->kernel[2], bn, N,
-                           sv.ymm1, sv.ymm2, sv.ymm3, (const double*)parts1, parts2);
+                           sv.ymm1, sv.ymm2, sv.ymm3, (const long long*)stats, (const long long*)nullptr, acc2, acc3);
         hipLaunchKernelGGL(k_vfe_stage<3>, g, b, 0, st, in, p->kernel[0], p->kernel[1], p->kernel[2], bn, N,
-                           sv.ymm1, sv.ymm2, sv.ymm3, (const double*)parts2, parts3);
-        hipLaunchKernelGGL(k_vfe_final3, dim3(64), dim3(kFwdBlocks), 0, st, (const double*)parts3, N, p->gamma[2],
-                           p->beta[2], p->moving_mean[2], p->moving_var[2], sv.bn3);
+                           sv.ymm1, sv.ymm2, sv.ymm3, (const long long*)nullptr, (const long long*)acc2, acc3,
+                           (long long*)nullptr);
         LISEC_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_vfe_grid, dim3(2048), dim3(256), 0, st, info, cell_voxel, ncells, cap_voxels,
+                           sv.ymm3, sv.bn3, grid, sv.vout, sv.delta, (const long long*)acc3, N, p->gamma[2],
+                           p->beta[2], p->moving_mean[2], p->moving_var[2], acc2);
     } else {
         hipLaunchKernelGGL(k_vfe_stage<0>, g, b, 0, st, in, p->kernel[0], p->kernel[1], p->kernel[2], bn, N,
-                           sv.ymm1, sv.ymm2, sv.ymm3, (const double*)nullptr, (double*)nullptr);
+                           sv.ymm1, sv.ymm2, sv.ymm3, (const long long*)nullptr, (const long long*)nullptr,
+                           (long long*)nullptr, (long long*)nullptr);
         LISEC_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_vfe_grid, dim3(2048), dim3(256), 0, st, info, cell_voxel, ncells, cap_voxels,
+                           sv.ymm3, sv.bn3, grid, sv.vout, sv.delta, (const long long*)nullptr, N,
+                           (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (float*)nullptr,
+                           (long long*)nullptr);
     }
-    hipLaunchKernelGGL(k_vfe_grid, dim3(4096), dim3(256), 0, st, info, cell_voxel, ncells, cap_voxels,
-                       sv.ymm3, sv.bn3, grid, sv.vout, sv.delta);
     LISEC_LAUNCH_CHECK();
     return LISEC_OK;
 }
@@ -453,8 +503,10 @@ extern "C" int lisec_vfe_grid_from_saved(const int32_t* info, const int32_t* cel
                                          int cap_voxels, const float* saved, float* grid, lisec_stream_t stream_) {
     LISEC_CHECK_ARG(info && cell_voxel && saved && grid && ncells > 0 && cap_voxels >= 0, "bad arguments");
     VfeSaved sv(const_cast<float*>(saved), cap_voxels);
-    hipLaunchKernelGGL(k_vfe_grid, dim3(4096), dim3(256), 0, static_cast<hipStream_t>(stream_), info, cell_voxel,
-                       ncells, cap_voxels, sv.ymm3, sv.bn3, grid, (float*)nullptr, (float*)nullptr);
+    hipLaunchKernelGGL(k_vfe_grid, dim3(2048), dim3(256), 0, static_cast<hipStream_t>(stream_), info, cell_voxel,
+                       ncells, cap_voxels, sv.ymm3, sv.bn3, grid, (float*)nullptr, (float*)nullptr,
+                       (const long long*)nullptr, 0.0, (const float*)nullptr, (const float*)nullptr, (float*)nullptr,
+                       (float*)nullptr, (long long*)nullptr);
     LISEC_LAUNCH_CHECK();
     return LISEC_OK;
 }

@@ -17,7 +17,10 @@
 //                                           ascending order (deterministic stand-in for the
 //                                           unseeded np.random.choice, model_training.py:132),
 //                                           centroid = sequential fp64 sum / s (np.mean order,
-//                                           :135), rows [x,y,z,x-cx,y-cy,z-cz] rounded to fp32
+//                                           :135), rows [x,y,z,x-cx,y-cy,z-cz] rounded to fp32;
+//                                           on the side the 6 + 21 first / second moments of the
+//                                           rows it writes (row_stats: what the VFE's first
+//                                           BatchNormalization needs, see lisec_hip.h)
 // All of it is HBM/latency-bound integer work: no MFMA, LDS only as per-wave scratch.
 #include "common.h"
 
@@ -84,9 +87,12 @@ __global__ void k_cell_totals(const int* __restrict__ cell_count, GridDims g,
 
 // single block: exclusive scan of the per-block totals, header words
 __global__ void k_scan_totals(int* __restrict__ totals, int nblk, int cap_voxels,
-                              int* __restrict__ info, int* __restrict__ row_start) {
+                              int* __restrict__ info, int* __restrict__ row_start,
+                              long long* __restrict__ row_stats) {
     __shared__ int carry[3];
     __shared__ int wsum[3][16];
+    if (row_stats)                                   // moments + the VFE's scratch start every sweep at zero
+        for (int i = threadIdx.x; i < LISEC_ROW_STATS_WORDS; i += blockDim.x) row_stats[i] = 0;
     if (threadIdx.x < 3) carry[threadIdx.x] = 0;
     __syncthreads();
     for (int b0 = 0; b0 < nblk; b0 += blockDim.x) {
@@ -217,10 +223,13 @@ __global__ void __launch_bounds__(256)
 k_features(const T* __restrict__ pts, int stride, const int* __restrict__ info, int cap_voxels,
            int Tmax, const int* __restrict__ counts, const int* __restrict__ pt_start,
            const int* __restrict__ row_start, const int* __restrict__ bucket,
-           float* __restrict__ rows, int* __restrict__ row_point) {
+           float* __restrict__ rows, int* __restrict__ row_point, long long* __restrict__ row_stats) {
     __shared__ double spt[4][64][3];
     __shared__ int ssel[4][64];
     const int lane = lane_id(), w = threadIdx.x >> 6;
+    double mom[27];                          // this lane's share of sum x_k (6) and sum x_j*x_k (21, j <= k)
+#pragma unroll
+    for (int k = 0; k < 27; ++k) mom[k] = 0.0;
     int V = info[LISEC_VI_NVOX];
     if (V > cap_voxels) V = cap_voxels;
     const int nwaves = gridDim.x * 4;
@@ -265,11 +274,36 @@ k_features(const T* __restrict__ pts, int stride, const int* __restrict__ info, 
         if (lane < s) {
             int row = row_start[v] + lane;
             float* o = rows + (size_t)row * 6;
-            o[0] = (float)px; o[1] = (float)py; o[2] = (float)pz;
-            o[3] = (float)(px - cx); o[4] = (float)(py - cy); o[5] = (float)(pz - cz);
+            const float fr[6] = {(float)px, (float)py, (float)pz, (float)(px - cx), (float)(py - cy), (float)(pz - cz)};
+#pragma unroll
+            for (int k = 0; k < 6; ++k) o[k] = fr[k];
             if (row_point) row_point[row] = mine;
+            if (row_stats) {                 // moments of the fp32 values the VFE will read
+                const double f[6] = {(double)fr[0], (double)fr[1], (double)fr[2], (double)fr[3], (double)fr[4], (double)fr[5]};
+                int q = 6;
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    mom[j] += f[j];
+#pragma unroll
+                    for (int k = j; k < 6; ++k) mom[q++] += f[j] * f[k];
+                }
+            }
         }
         __threadfence_block();               // LDS scratch is reused by the next voxel
+    }
+    if (row_stats) {
+        __shared__ double smom[4][27];
+#pragma unroll
+        for (int k = 0; k < 27; ++k) {
+            const double t = wave_sum(mom[k]);
+            if (lane == 0) smom[w][k] = t;
+        }
+        __syncthreads();
+        if (threadIdx.x < 27) {
+            const double t = ((smom[0][threadIdx.x] + smom[1][threadIdx.x]) + smom[2][threadIdx.x]) + smom[3][threadIdx.x];
+            if (t != 0.0)
+                fx_atomic_add(row_stats + ((size_t)(blockIdx.x % LISEC_ROW_STATS_REPLICAS) * 27 + threadIdx.x) * 2, t);
+        }
     }
 }
 
@@ -338,7 +372,7 @@ extern "C" int lisec_voxelize(const lisec_voxel_cfg* cfg, const void* points, in
                               size_t workspace_bytes, int cap_voxels, int32_t* info,
                               int32_t* cell_voxel, int32_t* coords, int32_t* counts,
                               int32_t* npts, int32_t* row_start, float* rows, int32_t* row_point,
-                              lisec_stream_t stream_) {
+                              int64_t* row_stats, lisec_stream_t stream_) {
     GridDims g;
     if (int rc = make_dims(cfg, &g)) return rc;
     LISEC_CHECK_ARG(n_points >= 0 && point_stride >= 3, "n_points/point_stride invalid");
@@ -367,8 +401,9 @@ extern "C" int lisec_voxelize(const lisec_voxel_cfg* cfg, const void* points, in
         LISEC_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(k_cell_totals, dim3(nblk), dim3(kScanThreads), 0, st, w.cell_count, g, w.totals);
+    long long* stats = reinterpret_cast<long long*>(row_stats);
     hipLaunchKernelGGL(k_scan_totals, dim3(1), dim3(1024), 0, st, w.totals, nblk, cap_voxels, info,
-                       row_start);
+                       row_start, stats);
     hipLaunchKernelGGL(k_cell_assign, dim3(nblk), dim3(kScanThreads), 0, st, w.cell_count, w.totals, g,
                        cap_voxels, cell_voxel, coords, counts, npts, w.pt_start, row_start, info);
     LISEC_LAUNCH_CHECK();
@@ -381,11 +416,11 @@ extern "C" int lisec_voxelize(const lisec_voxel_cfg* cfg, const void* points, in
         if (dtype == 0)
             hipLaunchKernelGGL(k_features<float>, dim3(fb), dim3(256), 0, st, (const float*)points,
                                point_stride, info, cap_voxels, g.T, counts, w.pt_start, row_start,
-                               w.bucket, rows, row_point);
+                               w.bucket, rows, row_point, stats);
         else
             hipLaunchKernelGGL(k_features<double>, dim3(fb), dim3(256), 0, st, (const double*)points,
                                point_stride, info, cap_voxels, g.T, counts, w.pt_start, row_start,
-                               w.bucket, rows, row_point);
+                               w.bucket, rows, row_point, stats);
         LISEC_LAUNCH_CHECK();
     }
     return LISEC_OK;

@@ -17,7 +17,7 @@ import torch
 from . import Constants, _lib
 from .network import LisecNet
 from .params import ParamStore
-from .voxelizer import VoxelSample, Voxelizer
+from .voxelizer import VoxelSample, Voxelizer, host_row_stats
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -111,7 +111,7 @@ def dense_to_sample(dense, device=None):
                     t(cell_voxel, torch.int32), t(coords if V else np.zeros((1, 3)), torch.int32),
                     t(npts if V else np.zeros(1), torch.int32), t(npts if V else np.zeros(1), torch.int32),
                     t(np.arange(max(V, 1) + 1) * T, torch.int32), t(rows, torch.float32),
-                    t(np.arange(n_rows), torch.int32))
+                    t(np.arange(n_rows), torch.int32), t(host_row_stats(rows[:V * T]), torch.int64))
     return s
 
 
@@ -292,26 +292,38 @@ class Model:
         dev = self.net.device
         hist = History()
         o = self.optimizer
+        # targets live on the device for the whole fit when they fit comfortably (1.28 MB per sample)
+        on_dev = n * ycls[0].size * 4 * 8 < (2 << 30)
+        if on_dev:
+            ycls_d = torch.from_numpy(np.ascontiguousarray(ycls[:n])).to(dev)
+            yreg_d = torch.from_numpy(np.ascontiguousarray(yreg[:n])).to(dev)
+        target = (lambda i: (ycls_d[i], yreg_d[i])) if on_dev else (
+            lambda i: (torch.from_numpy(np.ascontiguousarray(ycls[i])).to(dev),
+                       torch.from_numpy(np.ascontiguousarray(yreg[i])).to(dev)))
+        captured = self._captured_step(samples)
         for _ in range(epochs):
             order = list(np.random.permutation(idx)) if shuffle else list(idx)
             # the running loss stays on the device: reading it back every step would stall the host behind the GPU and
-            # expose the ~2 ms it needs to enqueue the next step; the progress line is refreshed ~20 times per epoch
+            # expose the time it needs to enqueue the next step; the progress line is refreshed ~20 times per epoch
             tot_dev = torch.zeros(3, dtype=torch.float64, device=dev)
             every = max(1, steps // 20)
             t0 = time.time()
             for st in range(steps):
                 i = int(order[st % len(order)])
-                yc = torch.from_numpy(np.ascontiguousarray(ycls[i])).to(dev)
-                yr = torch.from_numpy(np.ascontiguousarray(yreg[i])).to(dev)
-                self.net.forward(samples[i], training=True)
-                if self.dp is not None:
-                    avg = self.dp.bucketed()
-                    self.net.backward(yc, yr, loss=self.loss,
-                                      rpn_grads_ready=lambda lo, hi, avg=avg: avg.start_tail(self.net.grad, lo, hi))
-                    avg.finish(self.net.grad)
+                yc, yr = target(i)
+                if captured is not None:
+                    # the whole step (voxelise + forward + backward + update) replayed as one HIP graph
+                    captured(samples[i]._keepalive, yc, yr)
                 else:
-                    self.net.backward(yc, yr, loss=self.loss)
-                self.net.apply_gradients(lr=o.lr, decay=o.decay, momentum=o.momentum)
+                    self.net.forward(samples[i], training=True)
+                    if self.dp is not None:
+                        avg = self.dp.bucketed()
+                        self.net.backward(yc, yr, loss=self.loss,
+                                          rpn_grads_ready=lambda lo, hi, avg=avg: avg.start_tail(self.net.grad, lo, hi))
+                        avg.finish(self.net.grad)
+                    else:
+                        self.net.backward(yc, yr, loss=self.loss)
+                    self.net.apply_gradients(lr=o.lr, decay=o.decay, momentum=o.momentum)
                 tot_dev += self.net.loss_out
                 if verbose and ((st + 1) % every == 0 or st + 1 == steps):
                     print(f"\r{st + 1}/{steps} - loss: {float(tot_dev[0].item()) / (st + 1):.4f}", end="", flush=True)
@@ -321,6 +333,34 @@ class Model:
             for key, v in zip(("loss", "ClassificationLayer_loss", "RegressionLayer_loss"), tot / max(steps, 1)):
                 hist.history.setdefault(key, []).append(float(v))
         return hist
+
+    def _captured_step(self, samples):
+        """The HIP-graph form of the step (lisec_amd.network.CapturedStep) when it applies: one GPU, every sample a
+        voxelised sweep that still holds its device points, one grid.  LISEC_GRAPH=0 keeps the eager schedule."""
+        if self.dp is not None or os.environ.get("LISEC_GRAPH", "1") == "0" or not samples:
+            return None
+        pts = [getattr(s, "_keepalive", None) for s in samples]
+        if any(p is None or not p.is_cuda for p in pts):
+            return None                       # e.g. dense arrays turned into samples: no point cloud to re-voxelise
+        c0 = samples[0].cfg
+        key0 = (c0.xSize, c0.ySize, c0.zSize, c0.sampleSize, c0.maxVoxelX, c0.maxVoxelY, c0.maxVoxelZ)
+        for s_ in samples:
+            c = s_.cfg
+            if (c.xSize, c.ySize, c.zSize, c.sampleSize, c.maxVoxelX, c.maxVoxelY, c.maxVoxelZ) != key0:
+                return None
+        dtype = torch.float64 if any(p.dtype == torch.float64 for p in pts) else torch.float32
+        need = max(int(p.shape[0]) for p in pts)
+        o = self.optimizer
+        key = (key0, dtype, self.loss, o.lr, o.decay, o.momentum)
+        cur = getattr(self, "_captured", None)
+        if cur is not None and cur[0] == key and cur[1].capacity >= need:
+            return cur[1]
+        from .network import CapturedStep
+        capacity = max(1024, -(-need // 4096) * 4096)        # a little head-room: later fits reuse the capture
+        step = CapturedStep(self.net, Voxelizer(*key0[:3], key0[3], *key0[4:], device=self.net.device), capacity,
+                            dtype=dtype, loss=self.loss, lr=o.lr, decay=o.decay, momentum=o.momentum)
+        self._captured = (key, step)
+        return step
 
     def predict(self, x):
         """predict(testVFEPointsDense) -> [prob (n,Ho,Wo,2), regress (n,Ho,Wo,14)] (Predict.py:38);

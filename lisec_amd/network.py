@@ -125,8 +125,20 @@ class LisecNet:
         self.state_version = 0
         self._folded = {}
         self._train_ready = False
-        self.iterations = 0
+        # optimizer iteration count: the device copy drives the learning-rate decay (lisec_sgd_nesterov_step_dev), so
+        # that a captured step can be replayed; the host mirror is what save()/load_model() and the tests read
+        self._iter_dev = torch.zeros(2, dtype=torch.int64, device=dev)
+        self._iterations = 0
         self.loss_out = torch.zeros(3, dtype=f32, device=dev)
+
+    @property
+    def iterations(self):
+        return self._iterations
+
+    @iterations.setter
+    def iterations(self, k):
+        self._iterations = int(k)
+        self._iter_dev.copy_(torch.tensor([int(k), 0], dtype=torch.int64))
 
     # ------------------------------------------------------------------------------------------------
     def _pack_all(self):
@@ -468,9 +480,9 @@ class LisecNet:
 
     def apply_gradients(self, lr=0.01, decay=1e-6, momentum=0.9):
         """optimizers.SGD(lr=0.01, decay=1e-6, momentum=0.9, nesterov=True) (model_training.py:295)."""
-        lr_t = lr / (1.0 + decay * self.iterations)
-        ops.sgd_nesterov_step(self.params.theta, self.grad, self.velocity, lr_t, momentum)
-        self.iterations += 1
+        # lr_t = lr / (1 + decay * iterations), derived on the device from its own iteration counter
+        ops.sgd_nesterov_step_dev(self.params.theta, self.grad, self.velocity, lr, decay, momentum, self._iter_dev)
+        self._iterations += 1
         self.params_version += 1
 
     def train_step(self, sample, y_cls, y_reg, loss="mse", allreduce=None):
@@ -487,3 +499,80 @@ class LisecNet:
                 allreduce(self.grad)
         self.apply_gradients()
         return self.loss_out
+
+
+class CapturedStep:
+    """One whole fit() step -- voxelise, forward, backward (both streams, fork/join events included), SGD-Nesterov --
+    captured ONCE as a HIP graph and replayed: the ~250 launches of a step cost the host one graph launch instead of
+    ~2 ms of ctypes calls.  The schedule is static; what varies from sample to sample lives in device memory:
+
+      points   a fixed-capacity (capacity, 3) buffer; a sweep with fewer points is padded with points far outside
+               the grid, which the voxeliser's range test (model_training.py:118-120) drops -- kept points, their
+               order and therefore every voxel and feature row are exactly those of the unpadded sweep
+      targets  (Ho,Wo,2) / (Ho,Wo,14) static buffers
+      lr_t     derived by the SGD kernel from the device iteration counter (lisec_sgd_nesterov_step_dev)
+
+    Single-GPU only: the data-parallel step keeps the eager schedule (its RCCL exchange is not captured)."""
+
+    PAD = 1.0e6          # metres: floor(1e6 / 0.5) is far beyond maxVoxelX, the point is dropped like any other outlier
+
+    def __init__(self, net, voxelizer, capacity, dtype=torch.float32, loss="mse", lr=0.01, decay=1e-6, momentum=0.9,
+                 warmup=2):
+        self.net, self.vox, self.capacity, self.loss = net, voxelizer, int(capacity), loss
+        dev = net.device
+        self.points = torch.full((self.capacity, 3), self.PAD, dtype=dtype, device=dev)
+        self.ycls = torch.zeros((net.Ho, net.Wo, 2), dtype=torch.float32, device=dev)
+        self.yreg = torch.zeros((net.Ho, net.Wo, 14), dtype=torch.float32, device=dev)
+        self.hyper = (lr, decay, momentum)
+        net._prepare_training()
+        p = net.params
+        keep = (p.theta.clone(), p.state.clone(), net.velocity.clone(), net._iter_dev.clone(), net._iterations,
+                net.params_version, net.state_version)
+        # eager warm-up on a side stream (lazy workspaces, descriptor tables, events), then the capture itself
+        s = torch.cuda.Stream(device=dev)
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(max(1, warmup)):
+                self._enqueue()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self._enqueue()
+        # the warm-up steps trained on the padding: put every variable back
+        p.theta.copy_(keep[0]); p.state.copy_(keep[1]); net.velocity.copy_(keep[2]); net._iter_dev.copy_(keep[3])
+        net._iterations, net.params_version, net.state_version = keep[4], keep[5] + 1000, keep[6] + 1000
+        p.touch()
+        torch.cuda.synchronize(dev)
+
+    def _enqueue(self):
+        net = self.net
+        self.sample = self.vox(self.points)
+        net.forward(self.sample, training=True)
+        net.backward(self.ycls, self.yreg, loss=self.loss)
+        net.apply_gradients(*self.hyper)
+
+    def load(self, points, ycls, yreg):
+        """Stage one sweep: points (n <= capacity, >= 3 columns; device or host tensor / numpy), targets (Ho,Wo,2|14)."""
+        pts = torch.as_tensor(points)
+        n = int(pts.shape[0])
+        if n > self.capacity:
+            raise ValueError(f"sweep of {n} points exceeds the captured capacity {self.capacity}")
+        self.points[:n].copy_(pts[:, :3], non_blocking=True)
+        if n < self.capacity:
+            self.points[n:].fill_(self.PAD)
+        self.ycls.copy_(torch.as_tensor(ycls).reshape(self.ycls.shape), non_blocking=True)
+        self.yreg.copy_(torch.as_tensor(yreg).reshape(self.yreg.shape), non_blocking=True)
+
+    def replay(self):
+        """Runs the captured step on what load() staged; returns net.loss_out (device, [total, class, regression])."""
+        net = self.net
+        self.graph.replay()
+        net._iterations += 1
+        net.params_version += 1          # theta moved: an eager forward after this repacks / refolds
+        net.state_version += 1
+        return net.loss_out
+
+    def __call__(self, points, ycls, yreg):
+        self.load(points, ycls, yreg)
+        return self.replay()

@@ -206,6 +206,13 @@ def sgd_nesterov_step(theta, grad, velocity, lr_t, momentum):
                                                    theta.numel(), lr_t, momentum, _lib.current_stream()))
 
 
+def sgd_nesterov_step_dev(theta, grad, velocity, lr, decay, momentum, state):
+    """state: int64[2] device tensor {iterations, 0}; lr_t is derived on the device (graph-replayable)."""
+    _lib.check(_lib.load().lisec_sgd_nesterov_step_dev(_lib.ptr(theta), _lib.ptr(grad), _lib.ptr(velocity),
+                                                       theta.numel(), float(lr), float(decay), momentum,
+                                                       _lib.ptr(state), _lib.current_stream()))
+
+
 def scale_(x, s):
     _lib.check(_lib.load().lisec_scale(_lib.ptr(x), x.numel(), s, _lib.current_stream()))
 

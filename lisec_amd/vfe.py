@@ -43,8 +43,8 @@ class VFEStack:
         cp = self._cparams()
         _lib.check(self.lib.lisec_vfe_forward(
             ctypes.byref(cp), _lib.ptr(sample.info), _lib.ptr(sample.cell_voxel), _lib.ptr(sample.npts),
-            _lib.ptr(sample.row_start), _lib.ptr(sample.rows), ncells, sample.cfg.sampleSize, sample.cap,
-            1 if training else 0, _lib.ptr(self._saved), _lib.ptr(self._ws), self._ws.numel(),
+            _lib.ptr(sample.row_start), _lib.ptr(sample.rows), _lib.ptr(getattr(sample, "row_stats", None)),
+            ncells, sample.cfg.sampleSize, sample.cap, 1 if training else 0, _lib.ptr(self._saved), _lib.ptr(self._ws), self._ws.numel(),
             _lib.ptr(grid), _lib.current_stream()))
         self._sample = sample
         return grid

@@ -23,14 +23,15 @@ class VoxelSample:
     row_start   int32[cap+1]
     rows        float32[n,6]      compact feature rows
     row_point   int32[n]          original point index per row
+    row_stats   int64[LISEC_ROW_STATS_WORDS]  first / second moments of the rows (fixed point) + VFE scratch
     """
 
     def __init__(self, cfg, n_points, cap, info, cell_voxel, coords, counts, npts, row_start, rows,
-                 row_point):
+                 row_point, row_stats=None):
         self.cfg, self.n_points, self.cap = cfg, n_points, cap
         self.info, self.cell_voxel, self.coords = info, cell_voxel, coords
         self.counts, self.npts, self.row_start = counts, npts, row_start
-        self.rows, self.row_point = rows, row_point
+        self.rows, self.row_point, self.row_stats = rows, row_point, row_stats
         self._host_info = None
 
     @property
@@ -72,6 +73,19 @@ class VoxelSample:
                                                   _lib.ptr(self.row_start), _lib.ptr(self.rows), T, V,
                                                   _lib.ptr(padded), _lib.current_stream()))
         return padded[:V]
+
+
+def host_row_stats(rows):
+    """row_stats for rows that did not come from lisec_voxelize (a dense array turned into a sample): the 6 + 21
+    moments in the same two-limb fixed-point layout (everything in replica 0), VFE scratch zeroed."""
+    r = np.asarray(rows, dtype=np.float64).reshape(-1, 6)
+    vals = [r[:, j].sum() for j in range(6)] + [(r[:, j] * r[:, k]).sum() for j in range(6) for k in range(j, 6)]
+    out = np.zeros(_lib.ROW_STATS_WORDS, dtype=np.int64)
+    for i, s in enumerate(vals):
+        hi = np.floor(s * 256.0)
+        out[2 * i] = int(hi)
+        out[2 * i + 1] = int(np.rint((s - hi / 256.0) * 1099511627776.0))
+    return out
 
 
 class Voxelizer:
@@ -116,12 +130,13 @@ class Voxelizer:
         row_start = torch.empty(max(cap, 1) + 1, dtype=i32, device=dev)
         rows = torch.empty((max(n, 1), 6), dtype=torch.float32, device=dev)
         row_point = torch.empty(max(n, 1), dtype=i32, device=dev)
+        row_stats = torch.empty(_lib.ROW_STATS_WORDS, dtype=torch.int64, device=dev)
         _lib.check(self.lib.lisec_voxelize(
             ctypes.byref(self.cfg), _lib.ptr(pts), 0 if pts.dtype == torch.float32 else 1, n, stride,
             _lib.ptr(ws), ws.numel(), cap, _lib.ptr(info), _lib.ptr(cell_voxel), _lib.ptr(coords),
             _lib.ptr(counts), _lib.ptr(npts), _lib.ptr(row_start), _lib.ptr(rows), _lib.ptr(row_point),
-            _lib.current_stream()))
+            _lib.ptr(row_stats), _lib.current_stream()))
         s = VoxelSample(self.cfg, n, cap, info, cell_voxel, coords, counts, npts, row_start, rows,
-                        row_point)
+                        row_point, row_stats)
         s._keepalive = pts
         return s

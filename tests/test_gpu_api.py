@@ -177,3 +177,59 @@ def test_gpu_lidar_ingest_matches_oracle(tmp_path):
         b = mt.VFE_preprocessing(ref, 0.5, 0.25, 0.25, 35, 100, 200, 8).sample.to_host()
         # identical clouds up to the last float64 bit -> identical voxels unless a point grazes a cell border
         assert len(a["coords"]) == len(b["coords"]) and np.array_equal(a["coords"], b["coords"])
+
+
+def test_captured_step_equals_eager_steps():
+    """lisec_amd.network.CapturedStep (the whole fit() step as one HIP graph: voxelise + forward + backward on both
+    streams + SGD with the device-side iteration counter) gives BIT-IDENTICAL variables to the eager schedule, with
+    sweeps of different sizes padded into the fixed-capacity point buffer."""
+    import torch
+    from lisec_amd.network import CapturedStep, LisecNet
+    from lisec_amd.params import ParamStore
+    from lisec_amd.voxelizer import Voxelizer
+    cfg = dict(xSize=0.5, ySize=0.25, zSize=0.25, sampleSize=35, maxVoxelX=8, maxVoxelY=16, maxVoxelZ=8)
+    dev = torch.device("cuda")
+    rng = np.random.default_rng(3)
+    clouds = [np.stack([rng.uniform(-4.2, 4.2, n), rng.uniform(-4.2, 4.2, n), rng.uniform(0.0, 2.1, n)], 1).astype(np.float32)
+              for n in (2500, 1700, 3000, 1)]
+    ys = [(rng.integers(0, 3, (8, 16, 2)).astype(np.float32), rng.normal(0, 1, (8, 16, 14)).astype(np.float32))
+          for _ in clouds]
+    init = ParamStore(dev).to_dict()
+
+    def padded(pts, capacity=3000):
+        out = np.full((capacity, 3), CapturedStep.PAD, np.float32)
+        out[:len(pts)] = pts
+        return out
+
+    def run(captured, pad=True):
+        net = LisecNet(16, 32, 8, 35, params=ParamStore(dev, init=init))
+        vox = Voxelizer(**cfg)
+        net._prepare_training()
+        net.iterations = 5                                   # a non-zero start: the decay term is live
+        losses = []
+        step = CapturedStep(net, vox, 3000) if captured else None
+        if captured:
+            assert net.iterations == 5                       # the warm-up steps of the capture left no trace
+        for pts, (yc, yr) in zip(clouds, ys):
+            d_pts, d_yc, d_yr = (torch.from_numpy(a).to(dev) for a in (pts, yc, yr))
+            if captured:
+                lo = step(d_pts, d_yc, d_yr)
+            else:
+                # same capacity as the captured buffer: the row-list kernels plan their K slices per capacity
+                lo = net.train_step(vox(torch.from_numpy(padded(pts)).to(dev) if pad else d_pts), d_yc, d_yr)
+            losses.append(lo.cpu().numpy().copy())
+        torch.cuda.synchronize()
+        assert net.iterations == 5 + len(clouds) and int(net._iter_dev[0].item()) == net.iterations
+        # an eager inference pass after captured steps sees the updated variables (packed copies are refreshed)
+        cls, _ = net.forward(vox(torch.from_numpy(clouds[0]).to(dev)), training=False)
+        return net.params.theta.cpu().numpy(), net.params.state.cpu().numpy(), np.stack(losses), cls.cpu().numpy().copy()
+
+    t_e, s_e, l_e, c_e = run(False)
+    t_g, s_g, l_g, c_g = run(True)
+    assert np.array_equal(l_e, l_g)
+    assert np.array_equal(t_e, t_g) and np.array_equal(s_e, s_g)
+    assert np.array_equal(c_e, c_g)
+    # padding itself: the unpadded sweeps give the same voxels, hence the same step up to fp32 summation order
+    t_u, s_u, l_u, _ = run(False, pad=False)
+    assert np.allclose(l_u, l_e, rtol=1e-6) and np.allclose(t_u, t_e, rtol=1e-4, atol=1e-6)
+    assert np.allclose(s_u, s_e, rtol=1e-5, atol=1e-7)

@@ -260,7 +260,8 @@ def u20k(seed, n=20000):
 def full_grid_gradient_report(pts, loss, seed=5, wseed=77):
     """One training step at the Lyft grid on the GPU and in the CPU oracle (fp64 = truth, fp32 = what the SAME math
     gives in the product's arithmetic).  Returns (maps/loss dict, rows) with rows = (name, max|ref|, gpu relative
-    error, fp32-oracle relative error), both relative to max|ref| of that tensor."""
+    error, fp32-oracle relative error), both relative to max|ref| of that tensor; out["l2"][name] = relative L2
+    distances (gpu vs fp64, fp32 oracle vs fp64, gpu vs fp32 oracle)."""
     from conftest import LYFT
     from lisec_amd.network import LisecNet
     from lisec_amd.params import ParamStore
@@ -278,17 +279,20 @@ def full_grid_gradient_report(pts, loss, seed=5, wseed=77):
     torch.cuda.synchronize()
     cls_t, reg_t, loss_r, grads_r = _hybrid_oracle_lyft(op, pts, True, y_cls, y_reg, loss=loss)
     _, _, _, grads_32 = _hybrid_oracle_lyft(op, pts, True, y_cls, y_reg, dtype=torch.float32, loss=loss)
-    rows = []
+    rows, l2 = [], {}
     for name, ref in grads_r.items():
-        got = net.params.grad_view(net.grad, name).cpu().numpy()
+        got = net.params.grad_view(net.grad, name).cpu().numpy().astype(np.float64)
         scale = np.abs(ref).max()
+        nrm = max(float(np.linalg.norm(ref)), 1e-300)
+        l2[name] = (float(np.linalg.norm(got - ref)) / nrm, float(np.linalg.norm(grads_32[name] - ref)) / nrm,
+                    float(np.linalg.norm(got - grads_32[name])) / nrm)
         if ".conv" in name and name.endswith(".bias") and scale < 1e-10:
             # bias of a conv feeding a training-mode BatchNormalization: the exact gradient is 0
             assert np.abs(got).max() < 1e-5, name
             continue
         rows.append((name, scale, np.abs(got - ref).max() / scale, np.abs(grads_32[name] - ref).max() / scale))
     out = dict(head=net.act["head"].cpu().numpy(), cls=cls_t[0].numpy(), reg=reg_t[0].numpy(), loss=float(lo[0].item()),
-               loss_ref=loss_r)
+               loss_ref=loss_r, l2=l2)
     return out, rows
 
 

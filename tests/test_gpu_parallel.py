@@ -25,8 +25,8 @@ def _targets(seed):
 
 
 def _worker(rank, world, port, out_dir):
-    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                      LISEC_DIST_BACKEND="gloo")
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), LISEC_DIST_BACKEND="gloo", LISEC_BENCH_DEVICE="0")   # both ranks on cuda:0
     from lisec_amd import model_training as mt
     np.random.seed(0)
     model = mt.createModel(16, 32, 8, 35)                 # WORLD_SIZE=2 -> DataParallel inside, params broadcast

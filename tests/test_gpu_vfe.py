@@ -144,3 +144,46 @@ def test_vfe_backward_vs_sparse_oracle(grid):
     for name, r in ref.items():
         got = store.grad_view(grad, name).cpu().numpy()
         _close(got, r, rtol=2e-3)
+
+
+def _decode_row_stats(words):
+    """int64 row_stats -> the 27 moments (sum over replicas of hi * 2^-8 + lo * 2^-40)."""
+    from lisec_amd import _lib
+    w = np.asarray(words[:_lib.ROW_STATS_MOMENT_WORDS], dtype=np.int64).reshape(_lib.ROW_STATS_REPLICAS, 27, 2)
+    return w[:, :, 0].sum(0) / 256.0 + w[:, :, 1].sum(0) / 1099511627776.0
+
+
+def test_voxeliser_row_moments_and_vfe_without_them():
+    """lisec_voxelize's side output row_stats: the 6 first and 21 second moments of the feature rows it wrote (what
+    the closed-form statistics of the VFE's first BatchNormalization are made of), and the scratch behind them left
+    zeroed by a training forward.  A caller without row_stats (NULL) gets the same grid: lisec_vfe_forward then sums
+    the moments itself."""
+    from lisec_amd import _lib
+    from lisec_amd.params import ParamStore
+    from lisec_amd.vfe import VFEStack
+    from lisec_amd.voxelizer import Voxelizer, host_row_stats
+    rng = np.random.default_rng(11)
+    n = 20000
+    pts = np.stack([rng.uniform(-55, 55, n), rng.uniform(-55, 55, n), rng.uniform(-0.5, 2.5, n)], 1).astype(np.float32)
+    sample = Voxelizer(**LYFT)(pts)
+    h = sample.to_host()
+    rows = h["rows"].astype(np.float64)
+    want = np.array([rows[:, j].sum() for j in range(6)] +
+                    [(rows[:, j] * rows[:, k]).sum() for j in range(6) for k in range(j, 6)])
+    got = _decode_row_stats(sample.row_stats.cpu().numpy())
+    assert np.allclose(got, want, rtol=1e-12, atol=1e-9)
+    assert np.allclose(_decode_row_stats(host_row_stats(h["rows"])), want, rtol=1e-12, atol=1e-9)
+    assert (sample.row_stats.cpu().numpy()[_lib.ROW_STATS_MOMENT_WORDS:] == 0).all()
+    op = _oracle_params(9)
+    dev = torch.device("cuda")
+    a = VFEStack(ParamStore(dev, init=op))
+    g1 = a.forward(sample, training=True).cpu().numpy()
+    assert (sample.row_stats.cpu().numpy()[_lib.ROW_STATS_MOMENT_WORDS:] == 0).all()        # scratch re-zeroed
+    g1b = a.forward(sample, training=True).cpu().numpy()                                    # same sample again
+    assert np.array_equal(g1, g1b)
+    keep, sample.row_stats = sample.row_stats, None
+    b = VFEStack(ParamStore(dev, init=op))
+    g2 = b.forward(sample, training=True).cpu().numpy()
+    sample.row_stats = keep
+    assert np.allclose(g1, g2, rtol=1e-6, atol=1e-7)
+    assert np.allclose(a.params.state.cpu().numpy()[:16], b.params.state.cpu().numpy()[:16], rtol=1e-6)

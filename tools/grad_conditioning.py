@@ -15,5 +15,7 @@ out, rows = T.full_grid_gradient_report(pts, loss, seed=5 if cloud == "u20k" els
 print(f"{cloud} {loss}: loss {out['loss']:.8g} ref {out['loss_ref']:.8g}")
 for n, sc, e, o in rows:
     flag = "" if e <= max(T.FLAT, T.OWN * o) else "  <-- beyond max(FLAT, OWN x own)"
-    print(f"{n:26s} max|ref| {sc:9.3e}  gpu {e:9.3e}  fp32-oracle {o:9.3e}  ratio {e / max(o, 1e-30):6.2f}{flag}")
+    a, b, c = out["l2"][n]
+    print(f"{n:20s} max|ref| {sc:8.2e} max-norm: gpu {e:8.2e} o32 {o:8.2e} r {e / max(o, 1e-30):5.2f} | "
+          f"L2: gpu {a:8.2e} o32 {b:8.2e} r {a / max(b, 1e-30):5.2f} gpu-vs-o32 {c:8.2e}{flag}")
 print("worst gpu", max(r[2] for r in rows), "worst fp32 oracle", max(r[3] for r in rows))
