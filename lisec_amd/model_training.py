@@ -335,9 +335,10 @@ class Model:
         return hist
 
     def _captured_step(self, samples):
-        """The HIP-graph form of the step (lisec_amd.network.CapturedStep) when it applies: one GPU, every sample a
-        voxelised sweep that still holds its device points, one grid.  LISEC_GRAPH=0 keeps the eager schedule."""
-        if self.dp is not None or os.environ.get("LISEC_GRAPH", "1") == "0" or not samples:
+        """The HIP-graph form of the step (lisec_amd.network.CapturedStep), opt-in with LISEC_GRAPH=1, when it
+        applies: one GPU, every sample a voxelised sweep that still holds its device points, one grid.  Off by default:
+        on ROCm 7.2 the replay of the 260-node two-stream graph is 2x slower than the eager launches."""
+        if self.dp is not None or os.environ.get("LISEC_GRAPH", "0") != "1" or not samples:
             return None
         pts = [getattr(s, "_keepalive", None) for s in samples]
         if any(p is None or not p.is_cuda for p in pts):

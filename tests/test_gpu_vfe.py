@@ -178,6 +178,7 @@ def test_voxeliser_row_moments_and_vfe_without_them():
     dev = torch.device("cuda")
     a = VFEStack(ParamStore(dev, init=op))
     g1 = a.forward(sample, training=True).cpu().numpy()
+    state1 = a.params.state.cpu().numpy().copy()
     assert (sample.row_stats.cpu().numpy()[_lib.ROW_STATS_MOMENT_WORDS:] == 0).all()        # scratch re-zeroed
     g1b = a.forward(sample, training=True).cpu().numpy()                                    # same sample again
     assert np.array_equal(g1, g1b)
@@ -186,4 +187,4 @@ def test_voxeliser_row_moments_and_vfe_without_them():
     g2 = b.forward(sample, training=True).cpu().numpy()
     sample.row_stats = keep
     assert np.allclose(g1, g2, rtol=1e-6, atol=1e-7)
-    assert np.allclose(a.params.state.cpu().numpy()[:16], b.params.state.cpu().numpy()[:16], rtol=1e-6)
+    assert np.allclose(state1, b.params.state.cpu().numpy(), rtol=1e-6, atol=1e-9)      # moving statistics too

@@ -14,7 +14,7 @@ pts = T.u20k(5) if cloud == "u20k" else T.dense_sweep(6)
 out, rows = T.full_grid_gradient_report(pts, loss, seed=5 if cloud == "u20k" else 6)
 print(f"{cloud} {loss}: loss {out['loss']:.8g} ref {out['loss_ref']:.8g}")
 for n, sc, e, o in rows:
-    flag = "" if e <= max(T.FLAT, T.OWN * o) else "  <-- beyond max(FLAT, OWN x own)"
+    flag = "" if out["l2"][n][0] <= max(T.FLAT, T.SPREAD * out["l2"][n][1]) else "  <-- beyond max(FLAT, SPREAD x own)"
     a, b, c = out["l2"][n]
     print(f"{n:20s} max|ref| {sc:8.2e} max-norm: gpu {e:8.2e} o32 {o:8.2e} r {e / max(o, 1e-30):5.2f} | "
           f"L2: gpu {a:8.2e} o32 {b:8.2e} r {a / max(b, 1e-30):5.2f} gpu-vs-o32 {c:8.2e}{flag}")
