@@ -241,11 +241,38 @@ size_t lisec_conv_forward_rows_workspace_bytes(const lisec_conv_geom* g, int row
  *                stats_partials (required; lisec_conv_num_mblocks_bwd(g) rows) then receives per tile
  *                (sum dz, sum dz*yhat), dz = dA * (bwd_relu ? bn(y) > 0 : 1), yhat = (y - mean)*invstd -- pass 1 of
  *                lisec_bn_backward, folded into the store; finish with lisec_bn_backward_apply. */
+/* Optional destination of the per-tile BatchNormalization sums of a contraction (instead of the stats_partials
+ * table + a lisec_bn_finalize / lisec_bn_backward_apply finaliser launch): the sums are added into order-independent
+ * fixed-point accumulators and the LAST workgroup of the call finalises them in place -- deterministic, no extra launch.
+ *   acc   device, lisec_bn_sink_words(Cout) int64 words, ZERO before the first use; every call leaves it zeroed
+ *   kind  LISEC_SINK_FORWARD: (sum y, sum y^2) -> bnstate as lisec_bn_finalize writes it (+ moving statistics when
+ *         moving_mean/moving_var are set)
+ *         LISEC_SINK_BACKWARD (with bwd_y): (sum dz, sum dz*yhat) -> dgamma, dbeta and coef float[2*Cout] =
+ *         (mean dz, mean dz*yhat), the input of lisec_bn_backward_apply_coef */
+#define LISEC_SINK_FORWARD 1
+#define LISEC_SINK_BACKWARD 2
+typedef struct lisec_bn_sink {
+    void* acc;
+    int kind;
+    int unbiased_moving;
+    double n_rows;
+    const float* gamma;
+    const float* beta;
+    float* moving_mean;
+    float* moving_var;
+    float* bnstate;
+    float* dgamma;
+    float* dbeta;
+    float* coef;
+} lisec_bn_sink;
+size_t lisec_bn_sink_words(int C);
+
 typedef struct lisec_conv_extras {
     const float* out_mask;
     const float* bwd_y;
     const float* bwd_bnstate;
     int bwd_relu;
+    const lisec_bn_sink* sink;
 } lisec_conv_extras;
 int lisec_conv_num_mblocks_bwd(const lisec_conv_geom* g);
 int lisec_conv_forward_ex(const lisec_conv_geom* g, const float* in, const float* packed_w, const float* bias,
@@ -326,6 +353,11 @@ int lisec_bn_backward(const float* dA, int da_stride, const float* y, const floa
 int lisec_bn_backward_apply(const float* dA, int da_stride, const float* y, const float* bnstate, long long M, int C,
                             int relu, const double* partials, int nparts, float* dgamma, float* dbeta, float* dy,
                             void* workspace, size_t workspace_bytes, lisec_stream_t stream);
+
+/* The apply pass alone, for coefficients a lisec_bn_sink (LISEC_SINK_BACKWARD) produced: coef float[2*C] =
+ * (mean dz, mean dz*yhat); dy = scale * (dz - coef[c] - yhat * coef[C + c]); dy may alias dA. */
+int lisec_bn_backward_apply_coef(const float* dA, int da_stride, const float* y, const float* bnstate, long long M, int C,
+                                 int relu, const float* coef, float* dy, lisec_stream_t stream);
 
 /* n strided 2-D float copies in one launch: dst[r*dst_stride + c] = src[r*src_stride + c], r < rows, c < cols.
  * `device_table` lives in device memory (the pointers are fixed for the life of a model). */

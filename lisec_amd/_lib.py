@@ -31,9 +31,15 @@ class RpnCfg(Structure):
                 ("anchors", (c_double * 4) * 2)]
 
 
+class BnSinkDesc(ctypes.Structure):           # lisec_bn_sink
+    _fields_ = [("acc", c_void_p), ("kind", c_int), ("unbiased_moving", c_int), ("n_rows", c_double),
+                ("gamma", c_void_p), ("beta", c_void_p), ("moving_mean", c_void_p), ("moving_var", c_void_p),
+                ("bnstate", c_void_p), ("dgamma", c_void_p), ("dbeta", c_void_p), ("coef", c_void_p)]
+
+
 class ConvExtras(ctypes.Structure):           # lisec_conv_extras
     _fields_ = [("out_mask", ctypes.c_void_p), ("bwd_y", ctypes.c_void_p), ("bwd_bnstate", ctypes.c_void_p),
-                ("bwd_relu", ctypes.c_int)]
+                ("bwd_relu", ctypes.c_int), ("sink", POINTER(BnSinkDesc))]
 
 
 class CopyDesc(Structure):                     # lisec_copy_desc
@@ -123,6 +129,10 @@ def _declare(lib):
     lib.lisec_conv_num_mblocks_bwd.argtypes = [POINTER(ConvGeom)]
     lib.lisec_bn_backward_apply.restype = c_int
     lib.lisec_bn_backward_apply.argtypes = [P, c_int, P, P, LL, c_int, c_int, P, c_int, P, P, P, P, c_size_t, P]
+    lib.lisec_bn_sink_words.restype = c_size_t
+    lib.lisec_bn_sink_words.argtypes = [c_int]
+    lib.lisec_bn_backward_apply_coef.restype = c_int
+    lib.lisec_bn_backward_apply_coef.argtypes = [P, c_int, P, P, LL, c_int, c_int, P, P, P]
     lib.lisec_conv_forward_masked.restype = c_int
     lib.lisec_conv_forward_masked.argtypes = [POINTER(ConvGeom), P, P, P, P, c_int, P, P, P, P, c_size_t, P, P, c_int, P]
     lib.lisec_conv_forward_workspace_bytes.restype = c_size_t

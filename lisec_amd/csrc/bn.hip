@@ -1,5 +1,6 @@
 // BatchNormalization statistic finalisation (tiny, latency-bound kernels).
 #include "bn.h"
+#include "conv.h"
 
 namespace lisec {
 namespace {
@@ -165,6 +166,8 @@ extern "C" int lisec_bn_finalize(const double* partials, int nparts, int C, doub
     return launch_bn_finalize(partials, nparts, C, n_rows, gamma, beta, moving_mean, moving_var, unbiased_moving,
                               bnstate, static_cast<hipStream_t>(stream));
 }
+
+extern "C" size_t lisec_bn_sink_words(int C) { return C > 0 ? bn_sink_words(C) : 0; }
 
 extern "C" int lisec_bn_fold(const float* gamma, const float* beta, const float* moving_mean,
                              const float* moving_var, int C, float* bnstate, lisec_stream_t stream) {

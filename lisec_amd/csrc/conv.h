@@ -4,6 +4,20 @@
 
 namespace lisec {
 
+// Where a contraction's per-tile BatchNormalization sums go when the caller passes a lisec_bn_sink: order-independent
+// fixed-point accumulators (common.h) instead of a partial table, and the LAST workgroup of the call to arrive
+// finalises them -- no finaliser launch.  acc: long long[kSinkReplicas][2][C][2 limbs] + a ticket word.
+constexpr int kSinkReplicas = 4;
+struct BnSink {
+    long long* acc;          // nullptr: off
+    int kind, C, unbiased;   // kind 1: forward batch statistics -> bnstate (+ moving statistics); 2: backward -> coef
+    unsigned total;          // workgroups that feed the sink in this call (all launches together)
+    double N;                // dense rows the statistics are over
+    const float* gamma; const float* beta; float* mmean; float* mvar; float* bnstate;
+    float* dgamma; float* dbeta; float* coef;
+};
+inline size_t bn_sink_words(int C) { return (size_t)kSinkReplicas * 2 * C * 2 + 2; }
+
 struct ConvGeom {
     int Di, Hi, Wi;          // tensor that is gathered from
     int Do, Ho, Wo;          // tensor that is written (M = Do*Ho*Wo rows)
@@ -28,9 +42,68 @@ struct ConvGeom {
     const float* bwd_y;      // (positions, Cout) raw conv output of the layer the gradient belongs to, row stride Cout
     const float* bwd_bn;     // its bnstate float[4*Cout]
     int bwd_relu;
+    BnSink sink;             // optional destination of the per-tile sums (acc == nullptr: the partial table, if any)
 };
 
 int conv_geom_check(const lisec_conv_geom* c, ConvGeom* g);
+
+#ifdef __HIPCC__
+__device__ __forceinline__ void sink_add(const BnSink& s, int which, int ch, double v) {
+    if (v != 0.0) fx_atomic_add(s.acc + ((size_t)((blockIdx.x % kSinkReplicas) * 2 + which) * s.C + ch) * 2, v);
+}
+
+// Called by EVERY thread of the workgroup once its sink_add calls are issued.  The adds are waited for (vmcnt covers
+// atomics), the workgroup takes a ticket, and the one that takes the last ticket of the call reads the totals
+// (everything went through device-scope atomics: no fence needed), writes the BatchNormalization state or the
+// backward coefficients -- the arithmetic of k_bn_finalize / k_bn_bwd_finalize -- and leaves the accumulators zeroed.
+__device__ __forceinline__ void sink_finish(const BnSink& s) {
+    __shared__ int sink_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    unsigned long long* ticket = reinterpret_cast<unsigned long long*>(s.acc + (size_t)kSinkReplicas * 2 * s.C * 2);
+    if (threadIdx.x == 0) sink_last = atomicAdd(ticket, 1ULL) == (unsigned long long)s.total - 1;
+    __syncthreads();
+    if (!sink_last) return;
+    for (int c = threadIdx.x; c < s.C; c += blockDim.x) {
+        double v[2];
+#pragma unroll
+        for (int which = 0; which < 2; ++which) {
+            long long hi = 0, lo = 0;
+#pragma unroll
+            for (int r = 0; r < kSinkReplicas; ++r) {
+                long long* p = s.acc + ((size_t)(r * 2 + which) * s.C + c) * 2;
+                hi += __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                lo += __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(p, 0LL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(p + 1, 0LL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            v[which] = fx_join(hi, lo);
+        }
+        if (s.kind == 1) {
+            const double mean = v[0] / s.N;
+            double var = v[1] / s.N - mean * mean;        // biased; fp64 so the cancellation is harmless
+            if (var < 0.0) var = 0.0;
+            const double inv = 1.0 / sqrt(var + 1e-3);    // kBnEps
+            const double scale = (double)s.gamma[c] * inv;
+            s.bnstate[c] = (float)scale;
+            s.bnstate[s.C + c] = (float)((double)s.beta[c] - mean * scale);
+            s.bnstate[2 * s.C + c] = (float)mean;
+            s.bnstate[3 * s.C + c] = (float)inv;
+            if (s.mmean) {
+                const double u = s.unbiased && s.N > 1.0 ? var * (s.N / (s.N - 1.0)) : var;
+                s.mmean[c] = (float)((double)s.mmean[c] * 0.99 + mean * (1.0 - 0.99));       // kBnMomentum
+                s.mvar[c] = (float)((double)s.mvar[c] * 0.99 + u * (1.0 - 0.99));
+            }
+        } else {
+            s.dbeta[c] = (float)v[0];
+            s.dgamma[c] = (float)v[1];
+            s.coef[c] = (float)(v[0] / s.N);              // mean(dz)
+            s.coef[s.C + c] = (float)(v[1] / s.N);        // mean(dz * yhat)
+        }
+    }
+    if (threadIdx.x == 0) __hip_atomic_store(ticket, 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+#endif
 
 #ifdef __HIPCC__
 // rows that exist: M, or the device-side count of a row list

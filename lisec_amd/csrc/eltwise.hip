@@ -314,6 +314,26 @@ extern "C" int lisec_bn_backward_apply(const float* dA, int da_stride, const flo
     return LISEC_OK;
 }
 
+extern "C" int lisec_bn_backward_apply_coef(const float* dA, int da_stride, const float* y, const float* bnstate,
+                                            long long M, int C, int relu, const float* coef, float* dy,
+                                            lisec_stream_t stream_) {
+    LISEC_CHECK_ARG(dA && y && bnstate && coef && dy, "NULL pointer");
+    LISEC_CHECK_ARG(M > 0 && C >= 4 && C <= 256 && C % 4 == 0 && (kEwThreads * 4) % C == 0 && da_stride % 4 == 0,
+                    "bn_backward: C must divide 1024 and be a multiple of 4");
+    hipStream_t st = static_cast<hipStream_t>(stream_);
+    const int rows_per_iter = kEwThreads / (C / 4);
+    int nb = (int)((M + rows_per_iter - 1) / rows_per_iter);
+    if (nb > kEwBlocks) nb = kEwBlocks;
+    if (relu)
+        hipLaunchKernelGGL(k_bn_bwd_apply<true>, dim3(nb), dim3(kEwThreads), 0, st, dA, da_stride, y, bnstate, coef, M, C, dy,
+                           (double*)nullptr);
+    else
+        hipLaunchKernelGGL(k_bn_bwd_apply<false>, dim3(nb), dim3(kEwThreads), 0, st, dA, da_stride, y, bnstate, coef, M, C, dy,
+                           (double*)nullptr);
+    LISEC_LAUNCH_CHECK();
+    return LISEC_OK;
+}
+
 // n small strided 2-D copies in one launch (a workgroup per descriptor): the head kernels / biases and their gradients
 // move between the Keras-shaped variables and the merged (768,16) head layout without one tiny launch per slice
 __global__ void k_copy2d_batched(const lisec_copy_desc* __restrict__ tab) {

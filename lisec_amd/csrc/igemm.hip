@@ -124,7 +124,7 @@ __device__ __forceinline__ void store_tile(const ConvGeom& g, const f32x16& acc0
             }
         }
     }
-    if (stats) {
+    if (stats || g.sink.acc) {
         // per-channel partial sums of this 128-row tile (BatchNormalization batch statistics)
         __syncthreads();
         float* red = smem;                       // [4 waves][4][32]
@@ -141,8 +141,12 @@ __device__ __forceinline__ void store_tile(const ConvGeom& g, const f32x16& acc0
 #pragma unroll
             for (int k = 0; k < 4; ++k) v += (double)red[(k * 4 + q) * 32 + c];
             const int n = n0 + (q >> 1) * 32 + c;
-            if (n < g.Cout) stats[((size_t)mb * 2 + (q & 1)) * g.Cout + n] = v;
+            if (n < g.Cout) {
+                if (g.sink.acc) sink_add(g.sink, q & 1, n, v);
+                else stats[((size_t)mb * 2 + (q & 1)) * g.Cout + n] = v;
+            }
         }
+        if (g.sink.acc) sink_finish(g.sink);
     }
 }
 
@@ -583,7 +587,7 @@ k_splitk_reduce(const float* __restrict__ partial, int nsplit, int M, int Cout, 
                 const float* __restrict__ bias, int flags, float* __restrict__ out, int out_stride,
                 double* __restrict__ stats, int tile0, const int32_t* __restrict__ row_count,
                 const float* __restrict__ out_mask, int pc_span, int pc_rows, int Wo,
-                const float* __restrict__ bwd_y, const float* __restrict__ bwd_bn, int bwd_relu) {
+                const float* __restrict__ bwd_y, const float* __restrict__ bwd_bn, int bwd_relu, BnSink sink) {
     __shared__ float red[2][kSkThreads][4];
     if (row_count && *row_count < M) M = *row_count;          // row list shorter than its capacity
     constexpr int cq = BN / 4;                       // one 64-channel slab per blockIdx.y
@@ -655,7 +659,7 @@ k_splitk_reduce(const float* __restrict__ partial, int nsplit, int M, int Cout, 
             }
         }
     }
-    if (stats) {
+    if (stats || sink.acc) {
         red[0][threadIdx.x][0] = s1.x; red[0][threadIdx.x][1] = s1.y; red[0][threadIdx.x][2] = s1.z; red[0][threadIdx.x][3] = s1.w;
         red[1][threadIdx.x][0] = s2.x; red[1][threadIdx.x][1] = s2.y; red[1][threadIdx.x][2] = s2.z; red[1][threadIdx.x][3] = s2.w;
         __syncthreads();
@@ -663,8 +667,12 @@ k_splitk_reduce(const float* __restrict__ partial, int nsplit, int M, int Cout, 
             const int which = threadIdx.x / BN, cl = threadIdx.x % BN, ch = blockIdx.y * BN + cl;
             double a = 0.0;
             for (int k = 0; k < rows_per_iter; ++k) a += (double)red[which][k * cq + cl / 4][cl % 4];
-            if (ch < Cout) stats[((size_t)tile * 2 + which) * Cout + ch] = a;
+            if (ch < Cout) {
+                if (sink.acc) sink_add(sink, which, ch, a);
+                else stats[((size_t)tile * 2 + which) * Cout + ch] = a;
+            }
         }
+        if (sink.acc) sink_finish(sink);
     }
 }
 
@@ -719,6 +727,7 @@ int conv_geom_check(const lisec_conv_geom* c, ConvGeom* g) {
     g->row_coords = nullptr; g->row_count = nullptr; g->out_mask = nullptr;
     g->pc_span = 0; g->pc_rows = 0;
     g->bwd_y = nullptr; g->bwd_bn = nullptr; g->bwd_relu = 0;
+    g->sink.acc = nullptr;
     g->pointwise = c->KD * c->KH * c->KW == 1 && ld == 0 && lh == 0 && lw == 0 && c->pd == 0 && c->ph == 0 && c->pw == 0 &&
                    c->Di == c->Do && c->Hi == c->Ho && c->Wi == c->Wo;
     return 0;
@@ -868,7 +877,7 @@ extern "C" int lisec_conv_forward_masked(const lisec_conv_geom* c, const float* 
                                          const float* out_mask, double* stats_partials, void* workspace,
                                          size_t workspace_bytes, const int32_t* row_coords,
                                          const int32_t* row_count, int row_capacity, lisec_stream_t stream_) {
-    lisec_conv_extras ex = {out_mask, nullptr, nullptr, 0};
+    lisec_conv_extras ex = {out_mask, nullptr, nullptr, 0, nullptr};
     return lisec_conv_forward_ex(c, in, packed_w, bias, in_bnstate, flags, out, &ex, stats_partials, workspace,
                                  workspace_bytes, row_coords, row_count, row_capacity, stream_);
 }
@@ -885,6 +894,16 @@ extern "C" int lisec_conv_forward_ex(const lisec_conv_geom* c, const float* in, 
                     "out_mask: 16-byte aligned, not with a pixel-shuffle store");
     g.out_mask = out_mask;
     const bool bwd_stats = extras && extras->bwd_y;
+    const lisec_bn_sink* sk = extras ? extras->sink : nullptr;
+    if (sk) {
+        LISEC_CHECK_ARG(sk->acc && sk->n_rows > 0 && !row_coords && !c->ps, "bn sink: accumulators, row count, dense rows");
+        LISEC_CHECK_ARG((sk->kind == LISEC_SINK_FORWARD && !bwd_stats && sk->gamma && sk->beta && sk->bnstate &&
+                         (sk->moving_mean == nullptr) == (sk->moving_var == nullptr)) ||
+                        (sk->kind == LISEC_SINK_BACKWARD && bwd_stats && sk->dgamma && sk->dbeta && sk->coef),
+                        "bn sink: kind 1 needs gamma/beta/bnstate and no bwd_y, kind 2 needs bwd_y and dgamma/dbeta/coef");
+        // a dummy non-NULL partial table keeps the statistics code paths on; the sink takes precedence in the kernels
+        if (!stats_partials) stats_partials = reinterpret_cast<double*>(sk->acc);
+    }
     if (bwd_stats) {
         LISEC_CHECK_ARG(extras->bwd_bnstate && stats_partials && !c->ps && !row_coords && c->Cout % 4 == 0 &&
                         ((uintptr_t)extras->bwd_y & 15) == 0 && ((uintptr_t)extras->bwd_bnstate & 15) == 0,
@@ -905,6 +924,14 @@ extern "C" int lisec_conv_forward_ex(const lisec_conv_geom* c, const float* in, 
     ConvPlan plan = make_conv_plan(g);
     if (!workspace || workspace_bytes < plan.ws_bytes) { plan.tile0_tail = cdiv(g.M, BM); plan.nsplit = 1; }
     const int ntiles = cdiv(g.M, BM), nnb = g.CoutP / BN;
+    if (sk) {
+        g.sink.acc = static_cast<long long*>(sk->acc);
+        g.sink.kind = sk->kind; g.sink.C = g.Cout; g.sink.unbiased = sk->unbiased_moving;
+        g.sink.total = (unsigned)ntiles * (unsigned)nnb;          // every (tile, channel slab) stores exactly once
+        g.sink.N = sk->n_rows;
+        g.sink.gamma = sk->gamma; g.sink.beta = sk->beta; g.sink.mmean = sk->moving_mean; g.sink.mvar = sk->moving_var;
+        g.sink.bnstate = sk->bnstate; g.sink.dgamma = sk->dgamma; g.sink.dbeta = sk->dbeta; g.sink.coef = sk->coef;
+    }
     size_t lds = (size_t)(A_FLOATS + B_FLOATS) * sizeof(float);
     hipStream_t st = static_cast<hipStream_t>(stream_);
     const bool xf = in_bnstate != nullptr || (flags & LISEC_CONV_IN_RELU);
@@ -960,7 +987,7 @@ extern "C" int lisec_conv_forward_ex(const lisec_conv_geom* c, const float* in, 
         LISEC_IG_ANY(grid, plan.nsplit, partial, plan.tile0_tail);
         hipLaunchKernelGGL(k_splitk_reduce, dim3(tail, nnb), dim3(kSkThreads), 0, st, partial, plan.nsplit, g.M, g.Cout,
                            g.CoutP, bias, flags, out, g.out_stride, stats_partials, plan.tile0_tail, g.row_count, g.out_mask,
-                           g.pc_span, g.pc_rows, g.Wo, g.bwd_y, g.bwd_bn, g.bwd_relu);
+                           g.pc_span, g.pc_rows, g.Wo, g.bwd_y, g.bwd_bn, g.bwd_relu, g.sink);
     }
 #undef LISEC_IG_ANY
 #undef LISEC_IH

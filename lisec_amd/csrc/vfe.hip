@@ -29,12 +29,11 @@
 // the compact per-voxel outputs (vout / delta) on the side.
 #include "vfe_common.h"
 
+#include <cstdlib>
+
 namespace lisec {
 namespace {
 
-constexpr int kFwdBlocks = 256;      // one workgroup per CU
-constexpr int kFwdThreads = 512;     // 8 waves
-constexpr int kFwdWaves = kFwdThreads / 64;
 constexpr int kAccReplicas = 4;      // replicas of the cross-workgroup statistic accumulators (atomic contention)
 
 // Cross-workgroup statistic accumulators: long long[kAccReplicas][2*C][2] two-limb fixed-point sums (common.h):
@@ -146,8 +145,8 @@ k_vfe_stats(VfeIn in, long long* __restrict__ stats) {
 //          of layer 2 go to the accumulators acc_out.
 // STAGE 3: training, layer 3: statistics of layer 2 read from acc_in, those of layer 3 added to acc_out.
 // STAGE 0: inference, all three layers, statistics from the moving averages.
-template <int STAGE>
-__global__ void __launch_bounds__(kFwdThreads)
+template <int STAGE, int kFwdWaves>
+__global__ void __launch_bounds__(kFwdWaves * 64)
 k_vfe_stage(VfeIn in, const float* __restrict__ W1, const float* __restrict__ W2,
             const float* __restrict__ W3, StageBn bn, double N,
             float* __restrict__ ymm1, float* __restrict__ ymm2, float* __restrict__ ymm3,
@@ -155,10 +154,29 @@ k_vfe_stage(VfeIn in, const float* __restrict__ W1, const float* __restrict__ W2
             long long* __restrict__ acc_out, long long* __restrict__ acc_zero) {
     __shared__ float sbn1[32], sbn2[64];
     __shared__ double red[2 * kFwdWaves * 64];
+    constexpr int kFwdThreads = kFwdWaves * 64;
+    __shared__ float sW2p[16 * 32], sW3p[STAGE == 2 ? 1 : 32 * 64];   // kernel halves that meet the pooled inputs
     const int lane = lane_id(), w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c1 = lane & 15, c2 = lane & 31;
+    // everything the first voxels need is requested before the statistics are finalised
+    int V = in.info[LISEC_VI_NVOX];
     VfeWeights W;
-    W.load(W1, W2, W3, STAGE);       // issued first: in flight while the statistics are finalised
+    W.load(W1, W2, W3, STAGE, /*pooled=*/false);
+    for (int i = threadIdx.x; i < 16 * 32; i += kFwdThreads) sW2p[i] = W2[i];
+    if (STAGE != 2)
+        for (int i = threadIdx.x; i < 32 * 64; i += kFwdThreads) sW3p[i] = W3[i];
+    if (V > in.cap) V = in.cap;
+    const int nE = in.ncells - V;
+    const int nvox = V + (nE > 0 ? 1 : 0);
+    const int nwaves = gridDim.x * kFwdWaves;
+    auto load_meta = [&](int v, int& s, int& rs) {
+        s = 0; rs = 0;
+        if (v < V) { s = in.npts[v]; rs = in.row_start[v]; }
+    };
+    int v = blockIdx.x * kFwdWaves + w;
+    int s_cur, rs_cur, s_nxt, rs_nxt;
+    load_meta(v, s_cur, rs_cur);
+    load_meta(v + nwaves, s_nxt, rs_nxt);
     if (STAGE == 0) {
         block_fold<16>(bn.gamma[0], bn.beta[0], bn.mmean[0], bn.mvar[0], bn.saved[0], sbn1);
         block_fold<32>(bn.gamma[1], bn.beta[1], bn.mmean[1], bn.mvar[1], bn.saved[1], sbn2);
@@ -199,27 +217,6 @@ k_vfe_stage(VfeIn in, const float* __restrict__ W1, const float* __restrict__ W2
                              bn.mmean[1], bn.mvar[1], bn.saved[1], sbn2);
         }
     }
-    __syncthreads();
-    float sc1 = sbn1[c1], sh1 = sbn1[16 + c1], sc2 = 0, sh2 = 0;
-    if (STAGE == 0 || STAGE == 3) { sc2 = sbn2[c2]; sh2 = sbn2[32 + c2]; }
-    // the pad row after layer 1 is the same everywhere: relu(BN1(0)) = relu(shift1)
-    const float a1pad = fmaxf(sh1, 0.0f);
-    float A2pad = 0.0f;                                     // a1pad @ W2[16:, :]
-#pragma unroll
-    for (int k = 0; k < 16; ++k) A2pad = fmaf(rl(a1pad, k), W.w2a[k], A2pad);
-    int V = in.info[LISEC_VI_NVOX];
-    if (V > in.cap) V = in.cap;
-    const int nE = in.ncells - V;
-    const int nvox = V + (nE > 0 ? 1 : 0);
-    const int nwaves = gridDim.x * kFwdWaves;
-    double s1 = 0.0, s2 = 0.0;
-
-    // software pipeline over this wave's voxels: metadata two voxels ahead, input rows (and the saved
-    // per-voxel max/min of the lower layers) one voxel ahead
-    auto load_meta = [&](int v, int& s, int& rs) {
-        s = 0; rs = 0;
-        if (v < V) { s = in.npts[v]; rs = in.row_start[v]; }
-    };
     auto load_rows = [&](int s, int rs, float (&x)[6]) {
 #pragma unroll
         for (int k = 0; k < 6; ++k) x[k] = 0.0f;
@@ -236,13 +233,21 @@ k_vfe_stage(VfeIn in, const float* __restrict__ W1, const float* __restrict__ W2
             mx2 = ymm2[(size_t)v * 64 + c2]; mn2 = ymm2[(size_t)v * 64 + 32 + c2];
         }
     };
-    int v = blockIdx.x * kFwdWaves + w;
-    int s_cur, rs_cur, s_nxt, rs_nxt;
-    load_meta(v, s_cur, rs_cur);
-    load_meta(v + nwaves, s_nxt, rs_nxt);
     float xr[6], pmx1, pmn1, pmx2, pmn2;
     load_rows(s_cur, rs_cur, xr);
     load_ymm(v, pmx1, pmn1, pmx2, pmn2);
+    __syncthreads();
+    float sc1 = sbn1[c1], sh1 = sbn1[16 + c1], sc2 = 0, sh2 = 0;
+    if (STAGE == 0 || STAGE == 3) { sc2 = sbn2[c2]; sh2 = sbn2[32 + c2]; }
+    // read once per voxel, from LDS each time: volatile keeps the compiler from hoisting them back into 48 registers
+    const volatile float* vW2p = sW2p;
+    const volatile float* vW3p = sW3p;
+    // the pad row after layer 1 is the same everywhere: relu(BN1(0)) = relu(shift1)
+    const float a1pad = fmaxf(sh1, 0.0f);
+    float A2pad = 0.0f;                                     // a1pad @ W2[16:, :]
+#pragma unroll
+    for (int k = 0; k < 16; ++k) A2pad = fmaf(rl(a1pad, k), W.w2a[k], A2pad);
+    double s1 = 0.0, s2 = 0.0;
     for (; v < nvox; v += nwaves) {
         int s_n2, rs_n2;
         load_meta(v + 2 * nwaves, s_n2, rs_n2);
@@ -271,7 +276,7 @@ k_vfe_stage(VfeIn in, const float* __restrict__ W1, const float* __restrict__ W2
         const float pool1 = pool_from(mx1, mn1, sc1, sh1);
         float P2 = 0.0f;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) P2 = fmaf(rl(pool1, k), W.w2p[k], P2);
+        for (int k = 0; k < 16; ++k) P2 = fmaf(rl(pool1, k), vW2p[k * 32 + c2], P2);
         if (STAGE == 0 || STAGE == 2) {
             const float y2pad = P2 + A2pad;
             mx2 = has_pad ? y2pad : -INFINITY;
@@ -296,7 +301,7 @@ k_vfe_stage(VfeIn in, const float* __restrict__ W1, const float* __restrict__ W2
             const float pool2 = pool_from(mx2, mn2, sc2, sh2);
             float P3 = 0.0f;
 #pragma unroll
-            for (int k = 0; k < 32; ++k) P3 = fmaf(rl(pool2, k), W.w3p[k], P3);
+            for (int k = 0; k < 32; ++k) P3 = fmaf(rl(pool2, k), vW3p[k * 64 + lane], P3);
             float mx3 = -INFINITY, mn3 = INFINITY;
             if (has_pad) {
                 const float a2pad = bnrelu(P2 + A2pad, sc2, sh2);
@@ -467,34 +472,42 @@ extern "C" int lisec_vfe_forward(const lisec_vfe_params* p, const int32_t* info,
         bn.mmean[i] = p->moving_mean[i]; bn.mvar[i] = p->moving_var[i];
         bn.saved[i] = saved_bn[i];
     }
-    dim3 g(kFwdBlocks), b(kFwdThreads);
+    // launch shape of the stage kernels: (waves per workgroup, workgroups).  The kernels are latency-bound on a 20 k-point
+    // sweep (a handful of voxels per wave): LISEC_VFE_SHAPE picks among the shapes kept for measurement.
+    static const int shape = [] { const char* e = getenv("LISEC_VFE_SHAPE"); return e ? atoi(e) : 1; }();
+#define LISEC_STAGE(ST_, ...)                                                                                   \
+    do {                                                                                                        \
+        if (shape == 0) hipLaunchKernelGGL((k_vfe_stage<ST_, 8>), dim3(256), dim3(512), 0, st, __VA_ARGS__);    \
+        else if (shape == 2) hipLaunchKernelGGL((k_vfe_stage<ST_, 4>), dim3(768), dim3(256), 0, st, __VA_ARGS__); \
+        else if (shape == 3) hipLaunchKernelGGL((k_vfe_stage<ST_, 2>), dim3(1536), dim3(128), 0, st, __VA_ARGS__); \
+        else hipLaunchKernelGGL((k_vfe_stage<ST_, 4>), dim3(512), dim3(256), 0, st, __VA_ARGS__);               \
+    } while (0)
     if (training) {
         long long* stats = reinterpret_cast<long long*>(row_stats_);
         if (!stats) {                                   // no moments from the voxeliser: sum them here
             stats = own_stats;
             hipLaunchKernelGGL(k_vfe_stats_zero, dim3(1), dim3(1024), 0, st, stats);
-            hipLaunchKernelGGL(k_vfe_stats, dim3(kFwdBlocks), dim3(256), 0, st, in, stats);
+            hipLaunchKernelGGL(k_vfe_stats, dim3(256), dim3(256), 0, st, in, stats);
         }
         long long* acc2 = stats + LISEC_ROW_STATS_MOMENT_WORDS;       // zero on entry, re-zeroed by the grid writer
-        hipLaunchKernelGGL(k_vfe_stage<2>, g, b, 0, st, in, p->kernel[0], p->kernel[1], p->kernel[2], bn, N,
-                           sv.ymm1, sv.ymm2, sv.ymm3, (const long long*)stats, (const long long*)nullptr, acc2, acc3);
-        hipLaunchKernelGGL(k_vfe_stage<3>, g, b, 0, st, in, p->kernel[0], p->kernel[1], p->kernel[2], bn, N,
-                           sv.ymm1, sv.ymm2, sv.ymm3, (const long long*)nullptr, (const long long*)acc2, acc3,
-                           (long long*)nullptr);
+        LISEC_STAGE(2, in, p->kernel[0], p->kernel[1], p->kernel[2], bn, N, sv.ymm1, sv.ymm2, sv.ymm3,
+                    (const long long*)stats, (const long long*)nullptr, acc2, acc3);
+        LISEC_STAGE(3, in, p->kernel[0], p->kernel[1], p->kernel[2], bn, N, sv.ymm1, sv.ymm2, sv.ymm3,
+                    (const long long*)nullptr, (const long long*)acc2, acc3, (long long*)nullptr);
         LISEC_LAUNCH_CHECK();
         hipLaunchKernelGGL(k_vfe_grid, dim3(2048), dim3(256), 0, st, info, cell_voxel, ncells, cap_voxels,
                            sv.ymm3, sv.bn3, grid, sv.vout, sv.delta, (const long long*)acc3, N, p->gamma[2],
                            p->beta[2], p->moving_mean[2], p->moving_var[2], acc2);
     } else {
-        hipLaunchKernelGGL(k_vfe_stage<0>, g, b, 0, st, in, p->kernel[0], p->kernel[1], p->kernel[2], bn, N,
-                           sv.ymm1, sv.ymm2, sv.ymm3, (const long long*)nullptr, (const long long*)nullptr,
-                           (long long*)nullptr, (long long*)nullptr);
+        LISEC_STAGE(0, in, p->kernel[0], p->kernel[1], p->kernel[2], bn, N, sv.ymm1, sv.ymm2, sv.ymm3,
+                    (const long long*)nullptr, (const long long*)nullptr, (long long*)nullptr, (long long*)nullptr);
         LISEC_LAUNCH_CHECK();
         hipLaunchKernelGGL(k_vfe_grid, dim3(2048), dim3(256), 0, st, info, cell_voxel, ncells, cap_voxels,
                            sv.ymm3, sv.bn3, grid, sv.vout, sv.delta, (const long long*)nullptr, N,
                            (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (float*)nullptr,
                            (long long*)nullptr);
     }
+#undef LISEC_STAGE
     LISEC_LAUNCH_CHECK();
     return LISEC_OK;
 }

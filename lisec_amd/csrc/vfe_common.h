@@ -24,17 +24,24 @@ struct VfeWeights {          // per lane: column (lane & (C-1)) of each Dense ke
     float w1[6];
     float w2p[16], w2a[16];
     float w3p[32], w3a[32];
-    __device__ void load(const float* W1, const float* W2, const float* W3, int stage) {
+    // pooled: also the halves that multiply the pooled (per-voxel) inputs; the forward keeps those in LDS instead
+    __device__ void load(const float* W1, const float* W2, const float* W3, int stage, bool pooled = true) {
         const int lane = lane_id();
 #pragma unroll
         for (int k = 0; k < 6; ++k) w1[k] = W1[k * 16 + (lane & 15)];
         if (stage != 1) {
 #pragma unroll
-            for (int k = 0; k < 16; ++k) { w2p[k] = W2[k * 32 + (lane & 31)]; w2a[k] = W2[(16 + k) * 32 + (lane & 31)]; }
+            for (int k = 0; k < 16; ++k) {
+                if (pooled) w2p[k] = W2[k * 32 + (lane & 31)];
+                w2a[k] = W2[(16 + k) * 32 + (lane & 31)];
+            }
         }
         if (stage == 0 || stage == 3) {
 #pragma unroll
-            for (int k = 0; k < 32; ++k) { w3p[k] = W3[k * 64 + lane]; w3a[k] = W3[(32 + k) * 64 + lane]; }
+            for (int k = 0; k < 32; ++k) {
+                if (pooled) w3p[k] = W3[k * 64 + lane];
+                w3a[k] = W3[(32 + k) * 64 + lane];
+            }
         }
     }
 };

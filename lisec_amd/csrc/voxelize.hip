@@ -227,9 +227,17 @@ k_features(const T* __restrict__ pts, int stride, const int* __restrict__ info, 
     __shared__ double spt[4][64][3];
     __shared__ int ssel[4][64];
     const int lane = lane_id(), w = threadIdx.x >> 6;
-    double mom[27];                          // this lane's share of sum x_k (6) and sum x_j*x_k (21, j <= k)
-#pragma unroll
-    for (int k = 0; k < 27; ++k) mom[k] = 0.0;
+    // row moments (row_stats): lane k < 27 owns ONE moment -- sum x_k for k < 6, else sum x_a*x_b for the k-th pair
+    // (a <= b) -- and walks the rows of each voxel through LDS, so no cross-lane reduction is ever needed
+    __shared__ float sfeat[4][64][6];
+    double mom = 0.0;
+    int ma = lane < 6 ? lane : 0, mb = -1;
+    if (lane >= 6 && lane < 27) {
+        int q = lane - 6;
+        ma = 0;
+        while (q >= 6 - ma) { q -= 6 - ma; ++ma; }      // pairs in the order (0,0) (0,1) .. (0,5) (1,1) .. (5,5)
+        mb = ma + q;
+    }
     int V = info[LISEC_VI_NVOX];
     if (V > cap_voxels) V = cap_voxels;
     const int nwaves = gridDim.x * 4;
@@ -278,26 +286,23 @@ k_features(const T* __restrict__ pts, int stride, const int* __restrict__ info, 
 #pragma unroll
             for (int k = 0; k < 6; ++k) o[k] = fr[k];
             if (row_point) row_point[row] = mine;
-            if (row_stats) {                 // moments of the fp32 values the VFE will read
-                const double f[6] = {(double)fr[0], (double)fr[1], (double)fr[2], (double)fr[3], (double)fr[4], (double)fr[5]};
-                int q = 6;
+            if (row_stats) {                 // the fp32 values the VFE will read
 #pragma unroll
-                for (int j = 0; j < 6; ++j) {
-                    mom[j] += f[j];
-#pragma unroll
-                    for (int k = j; k < 6; ++k) mom[q++] += f[j] * f[k];
-                }
+                for (int k = 0; k < 6; ++k) sfeat[w][lane][k] = fr[k];
+            }
+        }
+        if (row_stats) {
+            __threadfence_block();
+            if (lane < 27) {
+                for (int r = 0; r < s; ++r)
+                    mom += (double)sfeat[w][r][ma] * (mb < 0 ? 1.0 : (double)sfeat[w][r][mb]);
             }
         }
         __threadfence_block();               // LDS scratch is reused by the next voxel
     }
     if (row_stats) {
         __shared__ double smom[4][27];
-#pragma unroll
-        for (int k = 0; k < 27; ++k) {
-            const double t = wave_sum(mom[k]);
-            if (lane == 0) smom[w][k] = t;
-        }
+        if (lane < 27) smom[w][lane] = mom;
         __syncthreads();
         if (threadIdx.x < 27) {
             const double t = ((smom[0][threadIdx.x] + smom[1][threadIdx.x]) + smom[2][threadIdx.x]) + smom[3][threadIdx.x];

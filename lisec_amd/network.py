@@ -120,6 +120,7 @@ class LisecNet:
         self.head_w = torch.empty(768, 16, dtype=f32, device=dev)
         self.head_b = torch.empty(16, dtype=f32, device=dev)
         self.parts = torch.empty(max_parts, dtype=torch.float64, device=dev)
+        self._sinks, self._bsinks = {}, {}
         self._packed_version = -1
         self.params_version = 0
         self.state_version = 0
@@ -164,13 +165,22 @@ class LisecNet:
         ops.pack_weights(self.head_w, 1, 768, 16, 0, 16, 1, out=self.packed["head"])
         self._packed_version = (self.params_version, self.params.version)
 
+    def _fwd_sink(self, c):
+        """BnSink of a conv layer's BatchNormalization: batch statistics summed and finalised inside the conv call."""
+        s = self._sinks.get(c.bn)
+        if s is None:
+            p = self.params
+            s = self._sinks[c.bn] = ops.BnSink(c.g.Cout, c.M, self.device, gamma=p.view(c.bn + ".gamma"),
+                                               beta=p.view(c.bn + ".beta"), moving_mean=p.view(c.bn + ".moving_mean"),
+                                               moving_var=p.view(c.bn + ".moving_variance"), unbiased=True,
+                                               bnstate=self.bnstate[c.bn])
+        return s
+
     def _bn_after(self, c, training):
         p = self.params
         C = c.g.Cout
         if training:
-            ops.bn_finalize(self.parts, c.nmb, C, c.M, p.view(c.bn + ".gamma"), p.view(c.bn + ".beta"),
-                            p.view(c.bn + ".moving_mean"), p.view(c.bn + ".moving_variance"), True,
-                            self.bnstate[c.bn])
+            # the statistics were finalised by the last workgroup of the conv call (lisec_bn_sink): nothing to launch
             self.state_version += 1               # moving statistics moved, bnstate holds batch statistics
         elif self._folded.get(c.bn) != (self.params_version, self.state_version, p.version):
             # inference: scale/shift from the moving statistics, folded once per weight version (not per sweep)
@@ -181,9 +191,9 @@ class LisecNet:
     def _run_conv(self, c, x, out, training):
         p = self.params
         flags = (ops.IN_RELU if c.in_relu else 0) | (ops.OUT_RELU if c.out_relu else 0)
-        stats = self.parts if (c.bn and training) else None
+        sink = self._fwd_sink(c) if (c.bn and training) else None
         ops.conv_forward(c.g, x, self.packed[c.name], out, bias=p.view(c.bias) if c.bias else None,
-                         in_bn=self.bnstate[c.in_bn] if c.in_bn else None, flags=flags, stats=stats)
+                         in_bn=self.bnstate[c.in_bn] if c.in_bn else None, flags=flags, sink=sink)
         if c.bn:
             self._bn_after(c, training)
 
@@ -296,6 +306,15 @@ class LisecNet:
         self._packed_t_version = -1
         self._train_ready = True
 
+    def _bwd_sink(self, bn_name, C, n_rows):
+        """BnSink of the backward of one BatchNormalization: (sum dz, sum dz*yhat) -> dgamma, dbeta, coefficients."""
+        s = self._bsinks.get(bn_name)
+        if s is None:
+            p = self.params
+            s = self._bsinks[bn_name] = ops.BnSink(C, n_rows, self.device, dgamma=p.grad_view(self.grad, bn_name + ".gamma"),
+                                                   dbeta=p.grad_view(self.grad, bn_name + ".beta"))
+        return s
+
     def _pack_all_t(self):
         if self._packed_t_version == (self.params_version, self.params.version):
             return
@@ -398,13 +417,13 @@ class LisecNet:
             # the LAST contribution to the gradient of a conv output also reduces the statistics its
             # BatchNormalization backward needs (pass 1 of bn_backward folded into the store)
             writes[dst_name] = writes.get(dst_name, 0) + 1
-            bwd = stats = None
+            bwd = sink = None
             if dst_name in self.bn_of and writes[dst_name] == self.consumers[dst_name]:
                 bn_name, C = self.bn_of[dst_name]
-                bwd, stats = (a[dst_name], self.bnstate[bn_name], True), self.bparts
-                bwd_ready[dst_name] = ops.num_mblocks_bwd(self.dgeom[c.name])
+                bwd, sink = (a[dst_name], self.bnstate[bn_name], True), self._bwd_sink(bn_name, C, a[dst_name].numel() // C)
+                bwd_ready[dst_name] = sink
             ops.conv_forward(self.dgeom[c.name], dy, self.packed_t[c.name][0], d[dst_name], flags=flags, out_mask=mask,
-                             bwd=bwd, stats=stats)
+                             bwd=bwd, sink=sink)
             first_write.add(dst_name)
 
         for L in reversed(layers):
@@ -426,9 +445,9 @@ class LisecNet:
                 C = c.g.Cout
                 is_first_rpn = L["name"] == "rpn1.conv0"
                 if dst in bwd_ready:
-                    ops.bn_backward_apply(d[dst], C, a[dst], self.bnstate[c.bn], c.M, C, True, self.bparts,
-                                          bwd_ready.pop(dst), p.grad_view(G, c.bn + ".gamma"),
-                                          p.grad_view(G, c.bn + ".beta"), d[dst])
+                    # dgamma / dbeta / coefficients were finalised inside the data-gradient call that stored d[dst]
+                    ops.bn_backward_apply_coef(d[dst], C, a[dst], self.bnstate[c.bn], c.M, C, True,
+                                               bwd_ready.pop(dst).coef, d[dst])
                 else:
                     ops.bn_backward(d[dst], C, a[dst], self.bnstate[c.bn], c.M, C, True,
                                     p.grad_view(G, c.bn + ".gamma"), p.grad_view(G, c.bn + ".beta"), d[dst])
@@ -446,11 +465,11 @@ class LisecNet:
                 on_side(lambda n=n, dn=dn: ops.conv_wgrad(dn.g, a[n + ".y"], d[n + ".u"], p.grad_view(G, dn.wname),
                                                           self.wgrad_ws, in_bn=self.bnstate[dn.in_bn]))
                 # Dense data gradient; its store also reduces the statistics of the BatchNormalization under it
+                msink = self._bwd_sink(c.bn, 64, c.M)
                 ops.conv_forward(self.dgeom[dn.name], d[n + ".u"], self.packed_t[dn.name][0], d[n + ".z"],
-                                 bwd=(a[n + ".y"], self.bnstate[c.bn], False), stats=self.bparts)
-                ops.bn_backward_apply(d[n + ".z"], 64, a[n + ".y"], self.bnstate[c.bn], c.M, 64, False, self.bparts,
-                                      ops.num_mblocks_bwd(self.dgeom[dn.name]), p.grad_view(G, c.bn + ".gamma"),
-                                      p.grad_view(G, c.bn + ".beta"), d[n + ".z"])
+                                 bwd=(a[n + ".y"], self.bnstate[c.bn], False), sink=msink)
+                ops.bn_backward_apply_coef(d[n + ".z"], 64, a[n + ".y"], self.bnstate[c.bn], c.M, 64, False, msink.coef,
+                                           d[n + ".z"])
                 if L["src"] == "grid":
                     # the grid is a constant on the empty cells + V voxel rows: both gradients reduce to V-row
                     # contractions plus sums of dy over boundary-trimmed boxes (exact; csrc/sparse_grid.hip)

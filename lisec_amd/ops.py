@@ -108,16 +108,39 @@ def conv_workspace(g, device, row_capacity=0):
     return _SPLITK_WS[key]
 
 
+class BnSink:
+    """lisec_bn_sink: the per-tile BatchNormalization sums of a contraction go into fixed-point accumulators and the
+    last workgroup of the call finalises them (no stats table, no finaliser launch).  Forward: bnstate (+ moving
+    statistics); backward: dgamma / dbeta / coef (feed bn_backward_apply_coef)."""
+
+    def __init__(self, C, n_rows, device, gamma=None, beta=None, moving_mean=None, moving_var=None, unbiased=True,
+                 bnstate=None, dgamma=None, dbeta=None):
+        lib = _lib.load()
+        self.acc = torch.zeros(lib.lisec_bn_sink_words(C), dtype=torch.int64, device=device)    # zero before first use
+        self.backward = dgamma is not None
+        self.coef = torch.zeros(2 * C, dtype=torch.float32, device=device) if self.backward else None
+        self.keep = (gamma, beta, moving_mean, moving_var, bnstate, dgamma, dbeta)
+        d = _lib.BnSinkDesc()
+        d.acc, d.kind, d.unbiased_moving, d.n_rows = self.acc.data_ptr(), 2 if self.backward else 1, 1 if unbiased else 0, float(n_rows)
+        d.gamma, d.beta = _lib.ptr(gamma), _lib.ptr(beta)
+        d.moving_mean, d.moving_var, d.bnstate = _lib.ptr(moving_mean), _lib.ptr(moving_var), _lib.ptr(bnstate)
+        d.dgamma, d.dbeta, d.coef = _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(self.coef)
+        self.desc = d
+        self.ref = ctypes.pointer(d)
+
+
 def conv_forward(g, x, wp, out, bias=None, in_bn=None, flags=0, stats=None, splitk=True, rows=None, out_mask=None,
-                 bwd=None):
+                 bwd=None, sink=None):
     """rows: optional (row_coords int32 (cap,3), row_count int32 device scalar, capacity) row list.
     out_mask: optional tensor laid out like `out`; values are stored as 0 where out_mask <= 0.
     bwd: optional (y, bnstate, relu): `out` is a gradient about to cross that BatchNormalization(+ReLU) backwards and
-    `stats` (num_mblocks_bwd(g) rows) receives the per-tile (sum dz, sum dz*yhat) -- see bn_backward_apply."""
+    `stats` (num_mblocks_bwd(g) rows) receives the per-tile (sum dz, sum dz*yhat) -- see bn_backward_apply.
+    sink: optional BnSink taking the per-tile sums instead of `stats` (finalised inside the call)."""
     rc, rn, cap = rows if rows is not None else (None, None, 0)
     ws = conv_workspace(g, out.device, cap) if splitk else None
     ex = _lib.ConvExtras(_lib.ptr(out_mask), _lib.ptr(bwd[0]) if bwd is not None else None,
-                         _lib.ptr(bwd[1]) if bwd is not None else None, 1 if (bwd is not None and bwd[2]) else 0)
+                         _lib.ptr(bwd[1]) if bwd is not None else None, 1 if (bwd is not None and bwd[2]) else 0,
+                         sink.ref if sink is not None else None)
     _lib.check(_lib.load().lisec_conv_forward_ex(ctypes.byref(g), _lib.ptr(x), _lib.ptr(wp), _lib.ptr(bias),
                                                  _lib.ptr(in_bn), flags, _lib.ptr(out), ctypes.byref(ex),
                                                  _lib.ptr(stats), _lib.ptr(ws),
@@ -140,6 +163,13 @@ def bn_backward_apply(dA, da_stride, y, bnstate, M, C, relu, parts, nparts, dgam
                                                    1 if relu else 0, _lib.ptr(parts), nparts, _lib.ptr(dgamma),
                                                    _lib.ptr(dbeta), _lib.ptr(dy), _lib.ptr(ws), ws.numel(),
                                                    _lib.current_stream()))
+
+
+def bn_backward_apply_coef(dA, da_stride, y, bnstate, M, C, relu, coef, dy):
+    """The apply pass alone, with the coefficients a backward BnSink produced."""
+    _lib.check(_lib.load().lisec_bn_backward_apply_coef(_lib.ptr(dA), da_stride, _lib.ptr(y), _lib.ptr(bnstate), M, C,
+                                                        1 if relu else 0, _lib.ptr(coef), _lib.ptr(dy),
+                                                        _lib.current_stream()))
 
 
 def bn_finalize(partials, nparts, C, n_rows, gamma, beta, moving_mean, moving_var, unbiased, bnstate):
