@@ -72,6 +72,54 @@ def event_time_ms(fn, iters):
     return e0.elapsed_time(e1) / iters
 
 
+def voxelizer_leg(vox, dev, skip_cpu=False):
+    """BASELINE.md plan item 1: the HIP voxeliser (lisec_voxelize: 6 launches + 2 memsets) on both synthetic sweeps,
+    points/s and algorithmic bytes/s against the HBM peak, next to the CPU restatement (oracle/voxel_ref.py, numpy,
+    one core) on the same U20k cloud and the reference's own Python loop (2.62 s for 20 000 points measured in the
+    build container, "~15 sec" for ~200 000 in its source, model_training.py:116)."""
+    out = {}
+    for name, cloud in (("u20k", u20k_cloud(0)), ("r200k", r200k_cloud(0))):
+        pts = torch.from_numpy(cloud).to(dev)
+        ms = event_time_ms(lambda: vox(pts), 30)
+        hi = vox(pts).host_info()
+        ncells = vox.ncells
+        # algorithmic bytes (DESIGN 4.1): 12 n read + 24 rows written + the 4-byte cell counters zeroed, counted and
+        # scanned (3 passes) + cell_voxel written + 16 B of per-voxel metadata
+        byt = 12.0 * len(cloud) + 24.0 * hi["rows"] + 4.0 * ncells * 4 + 16.0 * hi["V"]
+        out[name] = dict(points=int(len(cloud)), voxels=hi["V"], rows=hi["rows"], us_per_sweep=ms * 1e3,
+                         points_per_s=len(cloud) / (ms * 1e-3), achieved_gbs=byt / (ms * 1e-3) / 1e9,
+                         frac_hbm=byt / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, bytes_per_sweep=byt)
+    if not skip_cpu:
+        from oracle import voxel_ref
+        from lisec_amd import Constants
+        cfg = dict(xSize=Constants.voxelx, ySize=Constants.voxely, zSize=Constants.voxelz, sampleSize=Constants.maxPoints,
+                   maxVoxelX=Constants.nx // 2, maxVoxelY=Constants.ny // 2, maxVoxelZ=Constants.nz)
+        cloud = u20k_cloud(0).astype(np.float64)
+        t0 = time.perf_counter()
+        reps = 0
+        while reps < 3 or time.perf_counter() - t0 < 2.0:
+            voxel_ref.voxelize_ref(cloud, **cfg)
+            reps += 1
+        sec = (time.perf_counter() - t0) / reps
+        out["cpu_restatement"] = dict(points_per_s=len(cloud) / sec, s_per_sweep=sec, cores=1, kind="port",
+                                      sample=f"oracle/voxel_ref.voxelize_ref (numpy), U20k, {reps} sweeps")
+    secs = []
+    try:
+        for ln in open(os.path.join(ROOT, "tests", "golden", "voxel_goldens_timing.txt")):
+            f = ln.split()
+            if len(f) == 5 and f[0].startswith("voxel_u20k"):
+                secs.append(float(f[4]))
+    except OSError:
+        pass
+    ref_s = sum(secs) / len(secs) if secs else 2.62
+    out["reference"] = dict(s_per_sweep_20k=ref_s, points_per_s=20000 / ref_s,
+                            note="serialize_data.VFE_preprocessing (pure-Python loop) run unmodified on the U20k "
+                                 "fixtures in the build container, one core (tests/golden/voxel_goldens_timing.txt; "
+                                 "2.62 s in the survey's first probe); '~15 sec' at ~200 000 points per its own "
+                                 "source (model_training.py:116)")
+    return out
+
+
 def cpu_baseline(seconds_budget=12.0):
     """Dense torch-CPU oracle (fwd + bwd + update) on a shrunken grid, extrapolated to the Lyft grid."""
     from oracle import model_ref as M
@@ -238,15 +286,23 @@ def main():
             sample = vox(pts)
             return net.train_step(sample, ycls, yreg, loss=args.loss, allreduce=allreduce)
 
-    for _ in range(args.warmup):
-        step()
-    if dp is not None:
-        dp.barrier()
+    # LISEC_MAIN_PRIORITY: run the step's main chain on a stream of that priority (the weight-gradient side stream has
+    # its own, LISEC_SIDE_PRIORITY) -- which of the two hardware queues the dispatcher favours is a scheduling knob
+    import contextlib
+    main_prio = os.environ.get("LISEC_MAIN_PRIORITY")
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    torch.cuda.synchronize()
+    ctx = (torch.cuda.stream(torch.cuda.Stream(device=dev, priority=int(main_prio))) if main_prio not in (None, "")
+           else contextlib.nullcontext())
+    with ctx:
+        for _ in range(args.warmup):
+            step()
+        if dp is not None:
+            dp.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss = step()
+        torch.cuda.synchronize()
     if dp is not None:
         dp.barrier()
     torch.cuda.synchronize()
@@ -273,8 +329,15 @@ def main():
         tf = flops / (ms * 1e-3) / 1e12
         # traffic: HBM bytes per launch from rocprofv3 PMC passes of this kernel (profiles/r01_pmc_summary.txt):
         # FETCH_SIZE 124 820 KiB (x2, the gfx950 correction for wide coalesced reads) + WRITE_SIZE 82 500 KiB
+        # frac_executed: the kernel skips the taps that only read depth padding (kd = 0 of the first of the four output
+        # planes: 9 of 108 plane-taps), so the MFMA pipes execute 11/12 of the algorithmic FLOPs (PMC: 15.79 M of 17.28 M
+        # MFMA instructions, profiles/r01_pmc_summary.txt); clock_ghz: GRBM_GUI_ACTIVE / 8 / duration of this kernel in
+        # the same PMC passes (2.38 GHz on the real, 98 %-constant grid; 2.05-2.11 GHz on random data, where it takes 665 us)
+        executed = sum(sum(1 for kd in range(3) if 0 <= 2 * d - 1 + kd < net.D) for d in range(c.g.Do)) / (3.0 * c.g.Do)
         roofline = dict(bound="mfma", kernel="k_igemm_halo<0,false,1,2> mid1 Conv3D 64->64 k3 s(2,1,1)", achieved=tf,
                         peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s", frac=tf / PEAK_F32_MFMA_TFLOPS,
+                        frac_executed=tf * executed / PEAK_F32_MFMA_TFLOPS, executed_share=executed,
+                        clock_ghz=2.38, clock_note="GRBM_GUI_ACTIVE/8/duration, PMC offline (real grid; 2.05-2.11 on random data)",
                         traffic=(2 * 124820.0 + 82500.0) * 1024, traffic_unit="bytes/launch (PMC, offline)",
                         us_per_launch=ms * 1e3, flops_per_launch=flops)
         sample = vox(pts)
@@ -296,6 +359,21 @@ def main():
                                                    achieved=vfe_bytes / (ms_v * 1e-3) / 1e9,
                                                    frac=vfe_bytes / (ms_v * 1e-3) / 1e9 / PEAK_HBM_GBS,
                                                    launches=5))
+        voxelizer = voxelizer_leg(vox, dev, args.no_cpu_baseline)
+        r200k = None
+        if args.cloud == "u20k" and world == 1 and not use_graph:
+            # real Lyft sweeps are ~200 000 points (model_training.py:116): the same step on the R200k sweep, 10 steps
+            pts2 = torch.from_numpy(r200k_cloud(rank)).to(dev)
+            for _ in range(2):
+                net.train_step(vox(pts2), ycls, yreg, loss=args.loss)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(10):
+                net.train_step(vox(pts2), ycls, yreg, loss=args.loss)
+            torch.cuda.synchronize()
+            d2 = (time.perf_counter() - t1) / 10
+            r200k = dict(value=1.0 / d2, unit="samples/s", ms_per_step=1e3 * d2, points=int(pts2.shape[0]),
+                         voxels=vox(pts2).host_info()["V"], steps=10)
         result = {
             "metric": "lyft_samples_per_sec_fwd_bwd", "value": world * args.steps / dt, "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
@@ -311,7 +389,7 @@ def main():
                        "global_batch": world, "parallelism": f"dp{world}", "points_per_sample": int(len(cloud)),
                        "launch": "hipGraph replay of the captured step" if use_graph else "eager (ctypes launches)",
                        "voxels": hi["V"], "final_loss": loss_val},
-            "roofline": roofline, "roofline_vfe": roofline_vfe,
+            "roofline": roofline, "roofline_vfe": roofline_vfe, "voxelizer": voxelizer, "r200k": r200k,
         }
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline()

@@ -338,16 +338,16 @@ extern "C" int lisec_bn_backward_apply_coef(const float* dA, int da_stride, cons
 // move between the Keras-shaped variables and the merged (768,16) head layout without one tiny launch per slice
 __global__ void k_copy2d_batched(const lisec_copy_desc* __restrict__ tab) {
     const lisec_copy_desc d = tab[blockIdx.x];
-    const long long total = (long long)d.rows * d.cols;
-    for (long long i = threadIdx.x; i < total; i += blockDim.x) {
-        const long long r = i / d.cols, c = i - r * d.cols;
-        d.dst[r * d.dst_stride + c] = d.src[r * d.src_stride + c];
+    const int total = d.rows * d.cols;                      // small slices: 32-bit index arithmetic
+    for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < total; i += gridDim.y * blockDim.x) {
+        const int r = i / d.cols, c = i - r * d.cols;
+        d.dst[(long long)r * d.dst_stride + c] = d.src[(long long)r * d.src_stride + c];
     }
 }
 
 extern "C" int lisec_copy2d_batched(const lisec_copy_desc* device_table, int n, lisec_stream_t stream_) {
     LISEC_CHECK_ARG(device_table && n > 0, "bad batched copy arguments");
-    hipLaunchKernelGGL(k_copy2d_batched, dim3(n), dim3(256), 0, static_cast<hipStream_t>(stream_), device_table);
+    hipLaunchKernelGGL(k_copy2d_batched, dim3(n, 16), dim3(256), 0, static_cast<hipStream_t>(stream_), device_table);
     LISEC_LAUNCH_CHECK();
     return LISEC_OK;
 }

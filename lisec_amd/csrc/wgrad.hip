@@ -13,6 +13,8 @@
 // into the Keras kernel layout.
 #include "conv.h"
 
+#include <cstdlib>
+
 namespace lisec {
 namespace {
 
@@ -486,11 +488,21 @@ WgradPlan make_plan(const ConvGeom& g, int mode = 0, bool dy_xf = false) {
     return p;
 }
 
+// Weight gradients are leaves of the backward graph and run on a second stream beside the latency-critical
+// BatchNormalization-backward / data-gradient chain.  Their workgroups are long-lived; at three per CU they hold all
+// 160 KB of LDS and the chain's short kernels queue behind them.  LISEC_WGRAD_LDS_KB raises the LDS request so that at
+// most two fit per CU and one chain workgroup (<= 52 KB) always finds room.
+inline size_t wgrad_lds_floor() {
+    static const size_t v = [] { const char* e = getenv("LISEC_WGRAD_LDS_KB"); return e ? (size_t)atoi(e) * 1024 : (size_t)0; }();
+    return v;
+}
+
 template <int MODE>
 int launch_wgrad(const ConvGeom& g, const WgradPlan& p, const float* in, const float* in_bn, int flags,
                  const float* dy, const float* dy_bn, float* partial, hipStream_t st) {
     dim3 grid(p.nsplit * p.ngroups, cdiv(g.Cin, BC), cdiv(g.Cout, BC));
     size_t lds = 2 * TILE_FLOATS * sizeof(float);
+    if (lds < wgrad_lds_floor()) lds = wgrad_lds_floor();
 #define LISEC_WG(T)                                                                                               \
     if (g.row_coords)                                                                                             \
         hipLaunchKernelGGL((k_wgrad<MODE, T, true>), grid, dim3(kThreads), lds, st, g, in, in_bn, flags, dy, dy_bn, \
@@ -554,6 +566,7 @@ extern "C" int lisec_conv_wgrad(const lisec_conv_geom* c, const float* in, const
         dim3 grid(p.nsplit * p.ngroups, cdiv(g.Cin, BC), cdiv(g.Cout, BC));
         const int DR = (p.LT + 7) & ~7;
         size_t lds = (size_t)(2 * DR + 2) * BC * sizeof(float);
+        if (lds < wgrad_lds_floor()) lds = wgrad_lds_floor();
         if (in_bnstate || (flags & LISEC_CONV_IN_RELU))
             hipLaunchKernelGGL(k_wgrad_halo<true>, grid, dim3(kThreads), lds, st, g, in, in_bnstate, flags, dy, p.nsplit,
                                p.tiles_per_split, partial, flip ? 1 : 0, p.LT);
