@@ -145,7 +145,7 @@ k_vfe_stats(VfeIn in, long long* __restrict__ stats) {
 //          of layer 2 go to the accumulators acc_out.
 // STAGE 3: training, layer 3: statistics of layer 2 read from acc_in, those of layer 3 added to acc_out.
 // STAGE 0: inference, all three layers, statistics from the moving averages.
-template <int STAGE, int kFwdWaves>
+template <int STAGE, int kFwdWaves, bool LDSW>
 __global__ void __launch_bounds__(kFwdWaves * 64)
 k_vfe_stage(VfeIn in, const float* __restrict__ W1, const float* __restrict__ W2,
             const float* __restrict__ W3, StageBn bn, double N,
@@ -155,16 +155,18 @@ k_vfe_stage(VfeIn in, const float* __restrict__ W1, const float* __restrict__ W2
     __shared__ float sbn1[32], sbn2[64];
     __shared__ double red[2 * kFwdWaves * 64];
     constexpr int kFwdThreads = kFwdWaves * 64;
-    __shared__ float sW2p[16 * 32], sW3p[STAGE == 2 ? 1 : 32 * 64];   // kernel halves that meet the pooled inputs
+    __shared__ float sW2p[LDSW ? 16 * 32 : 1], sW3p[(LDSW && STAGE != 2) ? 32 * 64 : 1];   // halves for the pooled inputs
     const int lane = lane_id(), w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c1 = lane & 15, c2 = lane & 31;
     // everything the first voxels need is requested before the statistics are finalised
     int V = in.info[LISEC_VI_NVOX];
     VfeWeights W;
-    W.load(W1, W2, W3, STAGE, /*pooled=*/false);
-    for (int i = threadIdx.x; i < 16 * 32; i += kFwdThreads) sW2p[i] = W2[i];
-    if (STAGE != 2)
-        for (int i = threadIdx.x; i < 32 * 64; i += kFwdThreads) sW3p[i] = W3[i];
+    W.load(W1, W2, W3, STAGE, /*pooled=*/!LDSW);
+    if (LDSW) {
+        for (int i = threadIdx.x; i < 16 * 32; i += kFwdThreads) sW2p[i] = W2[i];
+        if (STAGE != 2)
+            for (int i = threadIdx.x; i < 32 * 64; i += kFwdThreads) sW3p[i] = W3[i];
+    }
     if (V > in.cap) V = in.cap;
     const int nE = in.ncells - V;
     const int nvox = V + (nE > 0 ? 1 : 0);
@@ -239,9 +241,6 @@ k_vfe_stage(VfeIn in, const float* __restrict__ W1, const float* __restrict__ W2
     __syncthreads();
     float sc1 = sbn1[c1], sh1 = sbn1[16 + c1], sc2 = 0, sh2 = 0;
     if (STAGE == 0 || STAGE == 3) { sc2 = sbn2[c2]; sh2 = sbn2[32 + c2]; }
-    // read once per voxel, from LDS each time: volatile keeps the compiler from hoisting them back into 48 registers
-    const volatile float* vW2p = sW2p;
-    const volatile float* vW3p = sW3p;
     // the pad row after layer 1 is the same everywhere: relu(BN1(0)) = relu(shift1)
     const float a1pad = fmaxf(sh1, 0.0f);
     float A2pad = 0.0f;                                     // a1pad @ W2[16:, :]
@@ -275,8 +274,12 @@ k_vfe_stage(VfeIn in, const float* __restrict__ W1, const float* __restrict__ W2
         // ---- pass 2: y2 = [pool1, a1] @ W2 -----------------------------------------------------
         const float pool1 = pool_from(mx1, mn1, sc1, sh1);
         float P2 = 0.0f;
+        // LDSW: read from LDS once per voxel; the opaque zero keeps the compiler from hoisting the 48 reads back into
+        // registers while still letting it batch them inside the iteration
+        int opq = 0;
+        if (LDSW) asm volatile("" : "+v"(opq));
 #pragma unroll
-        for (int k = 0; k < 16; ++k) P2 = fmaf(rl(pool1, k), vW2p[k * 32 + c2], P2);
+        for (int k = 0; k < 16; ++k) P2 = fmaf(rl(pool1, k), LDSW ? sW2p[k * 32 + c2 + opq] : W.w2p[k], P2);
         if (STAGE == 0 || STAGE == 2) {
             const float y2pad = P2 + A2pad;
             mx2 = has_pad ? y2pad : -INFINITY;
@@ -301,7 +304,7 @@ k_vfe_stage(VfeIn in, const float* __restrict__ W1, const float* __restrict__ W2
             const float pool2 = pool_from(mx2, mn2, sc2, sh2);
             float P3 = 0.0f;
 #pragma unroll
-            for (int k = 0; k < 32; ++k) P3 = fmaf(rl(pool2, k), vW3p[k * 64 + lane], P3);
+            for (int k = 0; k < 32; ++k) P3 = fmaf(rl(pool2, k), LDSW ? sW3p[k * 64 + lane + opq] : W.w3p[k], P3);
             float mx3 = -INFINITY, mn3 = INFINITY;
             if (has_pad) {
                 const float a2pad = bnrelu(P2 + A2pad, sc2, sh2);
@@ -474,13 +477,16 @@ extern "C" int lisec_vfe_forward(const lisec_vfe_params* p, const int32_t* info,
     }
     // launch shape of the stage kernels: (waves per workgroup, workgroups).  The kernels are latency-bound on a 20 k-point
     // sweep (a handful of voxels per wave): LISEC_VFE_SHAPE picks among the shapes kept for measurement.
-    static const int shape = [] { const char* e = getenv("LISEC_VFE_SHAPE"); return e ? atoi(e) : 1; }();
+    static const int shape = [] { const char* e = getenv("LISEC_VFE_SHAPE"); return e ? atoi(e) : 0; }();
 #define LISEC_STAGE(ST_, ...)                                                                                   \
     do {                                                                                                        \
-        if (shape == 0) hipLaunchKernelGGL((k_vfe_stage<ST_, 8>), dim3(256), dim3(512), 0, st, __VA_ARGS__);    \
-        else if (shape == 2) hipLaunchKernelGGL((k_vfe_stage<ST_, 4>), dim3(768), dim3(256), 0, st, __VA_ARGS__); \
-        else if (shape == 3) hipLaunchKernelGGL((k_vfe_stage<ST_, 2>), dim3(1536), dim3(128), 0, st, __VA_ARGS__); \
-        else hipLaunchKernelGGL((k_vfe_stage<ST_, 4>), dim3(512), dim3(256), 0, st, __VA_ARGS__);               \
+        if (shape == 1) hipLaunchKernelGGL((k_vfe_stage<ST_, 8, true>), dim3(256), dim3(512), 0, st, __VA_ARGS__);       \
+        else if (shape == 2) hipLaunchKernelGGL((k_vfe_stage<ST_, 16, false>), dim3(128), dim3(1024), 0, st, __VA_ARGS__); \
+        else if (shape == 3) hipLaunchKernelGGL((k_vfe_stage<ST_, 16, true>), dim3(128), dim3(1024), 0, st, __VA_ARGS__); \
+        else if (shape == 4) hipLaunchKernelGGL((k_vfe_stage<ST_, 4, false>), dim3(256), dim3(256), 0, st, __VA_ARGS__); \
+        else if (shape == 5) hipLaunchKernelGGL((k_vfe_stage<ST_, 8, true>), dim3(512), dim3(512), 0, st, __VA_ARGS__);  \
+        else if (shape == 6) hipLaunchKernelGGL((k_vfe_stage<ST_, 8, true>), dim3(128), dim3(512), 0, st, __VA_ARGS__);  \
+        else hipLaunchKernelGGL((k_vfe_stage<ST_, 8, false>), dim3(256), dim3(512), 0, st, __VA_ARGS__);                 \
     } while (0)
     if (training) {
         long long* stats = reinterpret_cast<long long*>(row_stats_);
