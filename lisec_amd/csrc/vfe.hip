@@ -34,6 +34,15 @@
 namespace lisec {
 namespace {
 
+// Diagnostic only (tools/vfe_stamps.py): 100 MHz s_memrealtime stamps of wave 0 of every workgroup at the phase
+// boundaries of the stage kernels, written to a buffer of their own; NULL (the default) = no stamp executes.
+__device__ unsigned long long* g_vfe_stamps = nullptr;
+#define LISEC_STAMP(K_)                                                                                         \
+    do {                                                                                                        \
+        if (stamps && threadIdx.x == 0)                                                                         \
+            stamps[((size_t)(STAGE == 3) * 4096 + blockIdx.x) * 8 + (K_)] = __builtin_amdgcn_s_memrealtime();   \
+    } while (0)
+
 constexpr int kAccReplicas = 4;      // replicas of the cross-workgroup statistic accumulators (atomic contention)
 
 // Cross-workgroup statistic accumulators: long long[kAccReplicas][2*C][2] two-limb fixed-point sums (common.h):
@@ -158,6 +167,8 @@ k_vfe_stage(VfeIn in, const float* __restrict__ W1, const float* __restrict__ W2
     __shared__ float sW2p[LDSW ? 16 * 32 : 1], sW3p[(LDSW && STAGE != 2) ? 32 * 64 : 1];   // halves for the pooled inputs
     const int lane = lane_id(), w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c1 = lane & 15, c2 = lane & 31;
+    unsigned long long* stamps = g_vfe_stamps;
+    LISEC_STAMP(0);
     // everything the first voxels need is requested before the statistics are finalised
     int V = in.info[LISEC_VI_NVOX];
     VfeWeights W;
@@ -179,6 +190,7 @@ k_vfe_stage(VfeIn in, const float* __restrict__ W1, const float* __restrict__ W2
     int s_cur, rs_cur, s_nxt, rs_nxt;
     load_meta(v, s_cur, rs_cur);
     load_meta(v + nwaves, s_nxt, rs_nxt);
+    LISEC_STAMP(1);
     if (STAGE == 0) {
         block_fold<16>(bn.gamma[0], bn.beta[0], bn.mmean[0], bn.mvar[0], bn.saved[0], sbn1);
         block_fold<32>(bn.gamma[1], bn.beta[1], bn.mmean[1], bn.mvar[1], bn.saved[1], sbn2);
@@ -238,7 +250,9 @@ k_vfe_stage(VfeIn in, const float* __restrict__ W1, const float* __restrict__ W2
     float xr[6], pmx1, pmn1, pmx2, pmn2;
     load_rows(s_cur, rs_cur, xr);
     load_ymm(v, pmx1, pmn1, pmx2, pmn2);
+    LISEC_STAMP(2);
     __syncthreads();
+    LISEC_STAMP(3);
     float sc1 = sbn1[c1], sh1 = sbn1[16 + c1], sc2 = 0, sh2 = 0;
     if (STAGE == 0 || STAGE == 3) { sc2 = sbn2[c2]; sh2 = sbn2[32 + c2]; }
     // the pad row after layer 1 is the same everywhere: relu(BN1(0)) = relu(shift1)
@@ -339,7 +353,9 @@ k_vfe_stage(VfeIn in, const float* __restrict__ W1, const float* __restrict__ W2
 #pragma unroll
         for (int k = 0; k < 6; ++k) xr[k] = xn[k];
         pmx1 = nmx1; pmn1 = nmn1; pmx2 = nmx2; pmn2 = nmn2;
+        if (v == (int)(blockIdx.x * kFwdWaves + w)) LISEC_STAMP(4);        // end of this wave's first voxel
     }
+    LISEC_STAMP(5);
     if (STAGE != 0) {
         constexpr int C = STAGE == 2 ? 32 : 64;
         __syncthreads();                                     // `red` was used by the prologue
@@ -353,6 +369,9 @@ k_vfe_stage(VfeIn in, const float* __restrict__ W1, const float* __restrict__ W2
             for (int k = 0; k < kFwdWaves; ++k) a += red[(q * kFwdWaves + k) * 64 + c];
             if (a != 0.0) acc_add<C>(acc_out, q, c, a);
         }
+        LISEC_STAMP(6);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        LISEC_STAMP(7);
     } else if (blockIdx.x == 0) {
         // inference: the grid writer reads bn3 from `saved`
         __shared__ float sbn3[128];
@@ -527,5 +546,11 @@ extern "C" int lisec_vfe_grid_from_saved(const int32_t* info, const int32_t* cel
                        (const long long*)nullptr, 0.0, (const float*)nullptr, (const float*)nullptr, (float*)nullptr,
                        (float*)nullptr, (long long*)nullptr);
     LISEC_LAUNCH_CHECK();
+    return LISEC_OK;
+}
+
+// Diagnostic (not in lisec_hip.h): points the stage kernels' stamp buffer at `buf` (device, 2*4096*8 uint64) or NULL.
+extern "C" int lisec_debug_vfe_stamps(unsigned long long* buf) {
+    LISEC_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_vfe_stamps), &buf, sizeof(buf)));
     return LISEC_OK;
 }
