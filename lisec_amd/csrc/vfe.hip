@@ -169,10 +169,20 @@ k_vfe_stage(VfeIn in, const float* __restrict__ W1, const float* __restrict__ W2
     const int c1 = lane & 15, c2 = lane & 31;
     unsigned long long* stamps = g_vfe_stamps;
     LISEC_STAMP(0);
-    // everything the first voxels need is requested before the statistics are finalised
+    // everything the first voxels need is requested before the statistics are finalised -- and before the voxel count V
+    // is known: npts / row_start hold `cap` entries, so the speculative reads are in bounds and are masked by V below
     int V = in.info[LISEC_VI_NVOX];
     VfeWeights W;
     W.load(W1, W2, W3, STAGE, /*pooled=*/!LDSW);
+    const int nwaves = gridDim.x * kFwdWaves;
+    auto load_meta_spec = [&](int v, int& s, int& rs) {
+        s = 0; rs = 0;
+        if (v < in.cap) { s = in.npts[v]; rs = in.row_start[v]; }
+    };
+    int v = blockIdx.x * kFwdWaves + w;
+    int s_cur, rs_cur, s_nxt, rs_nxt;
+    load_meta_spec(v, s_cur, rs_cur);
+    load_meta_spec(v + nwaves, s_nxt, rs_nxt);
     if (LDSW) {
         for (int i = threadIdx.x; i < 16 * 32; i += kFwdThreads) sW2p[i] = W2[i];
         if (STAGE != 2)
@@ -181,15 +191,12 @@ k_vfe_stage(VfeIn in, const float* __restrict__ W1, const float* __restrict__ W2
     if (V > in.cap) V = in.cap;
     const int nE = in.ncells - V;
     const int nvox = V + (nE > 0 ? 1 : 0);
-    const int nwaves = gridDim.x * kFwdWaves;
+    if (v >= V) { s_cur = 0; rs_cur = 0; }
+    if (v + nwaves >= V) { s_nxt = 0; rs_nxt = 0; }
     auto load_meta = [&](int v, int& s, int& rs) {
         s = 0; rs = 0;
         if (v < V) { s = in.npts[v]; rs = in.row_start[v]; }
     };
-    int v = blockIdx.x * kFwdWaves + w;
-    int s_cur, rs_cur, s_nxt, rs_nxt;
-    load_meta(v, s_cur, rs_cur);
-    load_meta(v + nwaves, s_nxt, rs_nxt);
     LISEC_STAMP(1);
     if (STAGE == 0) {
         block_fold<16>(bn.gamma[0], bn.beta[0], bn.mmean[0], bn.mvar[0], bn.saved[0], sbn1);
@@ -494,18 +501,15 @@ extern "C" int lisec_vfe_forward(const lisec_vfe_params* p, const int32_t* info,
         bn.mmean[i] = p->moving_mean[i]; bn.mvar[i] = p->moving_var[i];
         bn.saved[i] = saved_bn[i];
     }
-    // launch shape of the stage kernels: (waves per workgroup, workgroups).  The kernels are latency-bound on a 20 k-point
-    // sweep (a handful of voxels per wave): LISEC_VFE_SHAPE picks among the shapes kept for measurement.
-    static const int shape = [] { const char* e = getenv("LISEC_VFE_SHAPE"); return e ? atoi(e) : 0; }();
+    // launch shape of the stage kernels.  Measured on a 20 k-point sweep (tools/bench_vfe.py, tools/vfe_stamps.py): 256
+    // or 512 workgroups of 8 waves, pooled-input weights in registers or LDS -- all within 57.7-58.8 us for the whole
+    // call; fewer (128) or smaller (4-, 2-wave) workgroups are slower.  Default: one 8-wave workgroup per CU, LDS weights.
+    static const int shape = [] { const char* e = getenv("LISEC_VFE_SHAPE"); return e ? atoi(e) : 1; }();
 #define LISEC_STAGE(ST_, ...)                                                                                   \
     do {                                                                                                        \
-        if (shape == 1) hipLaunchKernelGGL((k_vfe_stage<ST_, 8, true>), dim3(256), dim3(512), 0, st, __VA_ARGS__);       \
-        else if (shape == 2) hipLaunchKernelGGL((k_vfe_stage<ST_, 16, false>), dim3(128), dim3(1024), 0, st, __VA_ARGS__); \
-        else if (shape == 3) hipLaunchKernelGGL((k_vfe_stage<ST_, 16, true>), dim3(128), dim3(1024), 0, st, __VA_ARGS__); \
-        else if (shape == 4) hipLaunchKernelGGL((k_vfe_stage<ST_, 4, false>), dim3(256), dim3(256), 0, st, __VA_ARGS__); \
+        if (shape == 0) hipLaunchKernelGGL((k_vfe_stage<ST_, 8, false>), dim3(256), dim3(512), 0, st, __VA_ARGS__);      \
         else if (shape == 5) hipLaunchKernelGGL((k_vfe_stage<ST_, 8, true>), dim3(512), dim3(512), 0, st, __VA_ARGS__);  \
-        else if (shape == 6) hipLaunchKernelGGL((k_vfe_stage<ST_, 8, true>), dim3(128), dim3(512), 0, st, __VA_ARGS__);  \
-        else hipLaunchKernelGGL((k_vfe_stage<ST_, 8, false>), dim3(256), dim3(512), 0, st, __VA_ARGS__);                 \
+        else hipLaunchKernelGGL((k_vfe_stage<ST_, 8, true>), dim3(256), dim3(512), 0, st, __VA_ARGS__);                  \
     } while (0)
     if (training) {
         long long* stats = reinterpret_cast<long long*>(row_stats_);
