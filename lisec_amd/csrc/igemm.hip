@@ -21,6 +21,8 @@
 // summation-order noise (no reduced precision anywhere).
 #include "conv.h"
 
+#include <cstdlib>
+
 namespace lisec {
 namespace {
 
@@ -839,7 +841,10 @@ ConvPlan make_conv_plan(const ConvGeom& g) {
     int ns = (int)(slots / tail_blocks);
     if (ns > nsteps / 3) ns = nsteps / 3;
     if (ns > 8) ns = 8;
-    if (ns < 2) return p;
+    // LISEC_MIN_SPLITK (measurement knob): layers that would only be cut in two run unsplit instead -- the combine pass
+    // of a two-way split costs about what the split saves once the second backward stream competes for the CUs
+    static const int min_split = [] { const char* e = getenv("LISEC_MIN_SPLITK"); return e ? atoi(e) : 2; }();
+    if (ns < 2 || ns < min_split) return p;
     p.tile0_tail = ntiles - tail_tiles;
     p.nsplit = ns;
     p.ws_bytes = align_up(sizeof(float) * (size_t)ns * tail_tiles * BM * g.CoutP, 256);
