@@ -121,6 +121,7 @@ class LisecNet:
         self.head_b = torch.empty(16, dtype=f32, device=dev)
         self.parts = torch.empty(max_parts, dtype=torch.float64, device=dev)
         self._sinks, self._bsinks = {}, {}
+        self.early_pack = os.environ.get("LISEC_PACK_EARLY", "1") == "1"
         self._packed_version = -1
         self.params_version = 0
         self.state_version = 0
@@ -208,9 +209,19 @@ class LisecNet:
             _lib.pin_stream(prev_pin)
 
     def _forward(self, sample, training):
-        self._pack_all()
+        pending = getattr(self, "_pack_pending", False)
+        if pending and (self._packed_version != (self.params_version, self.params.version)):
+            torch.cuda.current_stream().wait_event(self._pack_done)     # variables changed since the early repack
+            self._pack_pending = pending = False
+        if not pending:
+            self._pack_all()
         a = self.act
         self.vfe.forward(sample, training, out=a["grid"])
+        if pending:
+            # the repack of this step's weights was enqueued on the second stream right after the last optimizer step
+            # and ran under this sweep's voxeliser and VFE; the first contraction is the first reader
+            torch.cuda.current_stream().wait_event(self._pack_done)
+            self._pack_pending = False
         for L in self.layers:
             if L["kind"] == "mid":
                 n = L["name"]
@@ -503,6 +514,21 @@ class LisecNet:
         ops.sgd_nesterov_step_dev(self.params.theta, self.grad, self.velocity, lr, decay, momentum, self._iter_dev)
         self._iterations += 1
         self.params_version += 1
+        if self._train_ready and self.early_pack and not torch.cuda.is_current_stream_capturing():
+            # both repacks (forward and transposed layouts, ~75 us) for the NEXT step go to the second stream now: they
+            # only depend on this update, and the next sweep's voxeliser + VFE (~105 us) do not read them
+            if getattr(self, "_pack_done", None) is None:
+                self._pack_fork, self._pack_done = torch.cuda.Event(), torch.cuda.Event()
+            self._pack_fork.record(torch.cuda.current_stream())
+            self.side.wait_event(self._pack_fork)
+            pin = _lib.pin_stream(self.side.cuda_stream)
+            try:
+                self._pack_all()
+                self._pack_all_t()
+            finally:
+                _lib.pin_stream(pin)
+            self._pack_done.record(self.side)
+            self._pack_pending = True
 
     def train_step(self, sample, y_cls, y_reg, loss="mse", allreduce=None):
         """One fit() step at batch_size=1: forward (batch statistics) + backward + SGD-Nesterov.
@@ -543,6 +569,9 @@ class CapturedStep:
         self.ycls = torch.zeros((net.Ho, net.Wo, 2), dtype=torch.float32, device=dev)
         self.yreg = torch.zeros((net.Ho, net.Wo, 14), dtype=torch.float32, device=dev)
         self.hyper = (lr, decay, momentum)
+        net.early_pack = False           # the repacks belong inside the captured step, on its own streams
+        torch.cuda.synchronize(dev)
+        net._pack_pending = False
         net._prepare_training()
         p = net.params
         keep = (p.theta.clone(), p.state.clone(), net.velocity.clone(), net._iter_dev.clone(), net._iterations,
