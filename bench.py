@@ -327,18 +327,18 @@ def main():
         # algorithmic FLOPs: 2 * positions * 27 taps * 64 * 64; depth-padding taps included
         flops = 2.0 * c.M * 27 * 64 * 64
         tf = flops / (ms * 1e-3) / 1e12
-        # traffic: HBM bytes per launch from rocprofv3 PMC passes of this kernel (profiles/r01_pmc_summary.txt):
-        # FETCH_SIZE 124 820 KiB (x2, the gfx950 correction for wide coalesced reads) + WRITE_SIZE 82 500 KiB
+        # traffic: HBM bytes per launch from rocprofv3 PMC passes of this very launch (profiles/r02_pmc_and_experiments.txt):
+        # FETCH_SIZE 125 952 KiB (x2, the gfx950 correction for wide coalesced reads) + WRITE_SIZE 82 500 KiB
         # frac_executed: the kernel skips the taps that only read depth padding (kd = 0 of the first of the four output
         # planes: 9 of 108 plane-taps), so the MFMA pipes execute 11/12 of the algorithmic FLOPs (PMC: 15.79 M of 17.28 M
-        # MFMA instructions, profiles/r01_pmc_summary.txt); clock_ghz: GRBM_GUI_ACTIVE / 8 / duration of this kernel in
-        # the same PMC passes (2.38 GHz on the real, 98 %-constant grid; 2.05-2.11 GHz on random data, where it takes 665 us)
+        # MFMA instructions, profiles/r02_pmc_and_experiments.txt); clock_ghz: GRBM_GUI_ACTIVE / 8 / duration of this kernel in
+        # the same PMC passes (2.42 GHz on the real, 98 %-constant grid; 2.05-2.11 GHz on random data, where it takes 665 us)
         executed = sum(sum(1 for kd in range(3) if 0 <= 2 * d - 1 + kd < net.D) for d in range(c.g.Do)) / (3.0 * c.g.Do)
         roofline = dict(bound="mfma", kernel="k_igemm_halo<0,false,1,2> mid1 Conv3D 64->64 k3 s(2,1,1)", achieved=tf,
                         peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s", frac=tf / PEAK_F32_MFMA_TFLOPS,
                         frac_executed=tf * executed / PEAK_F32_MFMA_TFLOPS, executed_share=executed,
-                        clock_ghz=2.38, clock_note="GRBM_GUI_ACTIVE/8/duration, PMC offline (real grid; 2.05-2.11 on random data)",
-                        traffic=(2 * 124820.0 + 82500.0) * 1024, traffic_unit="bytes/launch (PMC, offline)",
+                        clock_ghz=2.42, clock_note="GRBM_GUI_ACTIVE/8/duration, PMC offline (real grid; 2.05-2.11 on random data)",
+                        traffic=(2 * 125952.0 + 82500.0) * 1024, traffic_unit="bytes/launch (PMC, offline)",
                         us_per_launch=ms * 1e3, flops_per_launch=flops)
         sample = vox(pts)
 
@@ -358,7 +358,7 @@ def main():
                             whole_vfe_forward=dict(us_per_call=ms_v * 1e3, bytes_per_call=vfe_bytes,
                                                    achieved=vfe_bytes / (ms_v * 1e-3) / 1e9,
                                                    frac=vfe_bytes / (ms_v * 1e-3) / 1e9 / PEAK_HBM_GBS,
-                                                   launches=5))
+                                                   launches=3))
         voxelizer = voxelizer_leg(vox, dev, args.no_cpu_baseline)
         r200k = None
         if args.cloud == "u20k" and world == 1 and not use_graph:
