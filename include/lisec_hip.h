@@ -120,6 +120,10 @@ typedef struct {
 /* Size (floats) of the `saved` buffer a forward fills and the backward reads: BN batch statistics
  * and the per-voxel pre-BN max/min of each layer. */
 size_t lisec_vfe_saved_floats(int cap_voxels);
+/* The same plus the per-row extras a training forward can leave for the tiled (MFMA) backward: the slot of the first
+ * row holding each per-voxel maximum / minimum, and the layer-2 pre-BN value of every class row.  n_points = the row
+ * capacity (rows <= n_points).  Pass the same n_points to lisec_vfe_forward and LISEC_VFE_BWD_TILED to the backward. */
+size_t lisec_vfe_saved_floats_rows(int cap_voxels, int n_points);
 /* Offsets (in floats) inside `saved` of the compact per-voxel outputs written by every forward:
  *   VOUT  float[(cap+1)*64]  grid value of voxel v; row V = the constant every empty cell holds
  *   DELTA float[(cap+1)*64]  VOUT[v] - VOUT[V] */
@@ -132,11 +136,13 @@ size_t lisec_vfe_workspace_bytes(void);
  * ncells = NZ*NX*NY, T = sampleSize.  training != 0: batch statistics (Keras fit), moving stats
  * updated; training == 0: moving statistics (Keras predict, Predict.py:38).
  * row_stats: the voxeliser's side output (NULL: the moments are summed here, one more launch).
+ * n_points: 0, or the row capacity `saved` was sized for with lisec_vfe_saved_floats_rows (training only: the
+ *           per-row extras are then written).
  * grid  dev float32[ncells*64]: (D,H,W,64), every cell written (empty cells hold relu(BN3(.)) != 0).
  */
 int lisec_vfe_forward(const lisec_vfe_params* p, const int32_t* info, const int32_t* cell_voxel,
                       const int32_t* npts, const int32_t* row_start, const float* rows, int64_t* row_stats,
-                      int ncells, int T, int cap_voxels, int training, float* saved, void* workspace,
+                      int n_points, int ncells, int T, int cap_voxels, int training, float* saved, void* workspace,
                       size_t workspace_bytes, float* grid, lisec_stream_t stream);
 
 /* Re-materialises the dense grid from the `saved` buffer of the last lisec_vfe_forward (the HBM-bound
@@ -152,6 +158,8 @@ typedef struct {
     float* gamma[3];
     float* beta[3];
 } lisec_vfe_grads;
+#define LISEC_VFE_BWD_TILED 1   /* flags: `saved` carries the per-row extras of lisec_vfe_forward(n_points > 0): layers 3
+                                   and 2 run on 32-row tiles on the matrix cores instead of row by row per voxel */
 size_t lisec_vfe_backward_workspace_bytes(int cap_voxels, int n_points);
 /* Pass EITHER dgrid (dense gradient of the grid) OR the compact form the sparse backward of the first middle
  * layer produces: dout_rows float[(cap_voxels+1)*64] with rows [0,V) = gradient at the occupied cells (row V is
@@ -159,7 +167,7 @@ size_t lisec_vfe_backward_workspace_bytes(int cap_voxels, int n_points);
 int lisec_vfe_backward(const lisec_vfe_params* p, const int32_t* info, const int32_t* cell_voxel,
                        const int32_t* npts, const int32_t* row_start, const float* rows, int n_points,
                        int ncells, int T, int cap_voxels, const float* saved, const float* dgrid,
-                       float* dout_rows, const float* g_all, const lisec_vfe_grads* grads, void* workspace,
+                       float* dout_rows, const float* g_all, const lisec_vfe_grads* grads, int flags, void* workspace,
                        size_t workspace_bytes, lisec_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------

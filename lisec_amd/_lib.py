@@ -101,7 +101,7 @@ def _declare(lib):
     lib.lisec_vfe_backward_workspace_bytes.argtypes = [c_int, c_int]
     lib.lisec_vfe_backward.restype = c_int
     lib.lisec_vfe_backward.argtypes = [POINTER(VfeParams), P, P, P, P, P, c_int, c_int, c_int, c_int, P, P, P, P,
-                                       POINTER(VfeGrads), P, c_size_t, P]
+                                       POINTER(VfeGrads), c_int, P, c_size_t, P]
     lib.lisec_vfe_saved_field_offset.restype = c_size_t
     lib.lisec_vfe_saved_field_offset.argtypes = [c_int, c_int]
     lib.lisec_conv_tap_sums_workspace_bytes.restype = c_size_t
@@ -172,8 +172,10 @@ def _declare(lib):
     lib.lisec_bn_fold.restype = c_int
     lib.lisec_bn_fold.argtypes = [P, P, P, P, c_int, P, P]
     lib.lisec_vfe_forward.restype = c_int
-    lib.lisec_vfe_forward.argtypes = [POINTER(VfeParams), P, P, P, P, P, P, c_int, c_int, c_int, c_int, P, P,
+    lib.lisec_vfe_forward.argtypes = [POINTER(VfeParams), P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, P,
                                       c_size_t, P, P]
+    lib.lisec_vfe_saved_floats_rows.restype = c_size_t
+    lib.lisec_vfe_saved_floats_rows.argtypes = [c_int, c_int]
 
 
 def load():

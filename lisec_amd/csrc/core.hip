@@ -16,7 +16,7 @@ void set_error(const char* fmt, ...) {
 
 extern "C" const char* lisec_last_error(void) { return lisec::g_err; }
 
-extern "C" int lisec_abi_version(void) { return 8; }
+extern "C" int lisec_abi_version(void) { return 9; }
 
 extern "C" int lisec_device_info(char* name, int cap) {
     int dev = 0;

@@ -160,7 +160,9 @@ k_vfe_stage(VfeIn in, const float* __restrict__ W1, const float* __restrict__ W2
             const float* __restrict__ W3, StageBn bn, double N,
             float* __restrict__ ymm1, float* __restrict__ ymm2, float* __restrict__ ymm3,
             const long long* __restrict__ row_stats, const long long* __restrict__ acc_in,
-            long long* __restrict__ acc_out, long long* __restrict__ acc_zero) {
+            long long* __restrict__ acc_out, long long* __restrict__ acc_zero,
+            unsigned char* __restrict__ arg1, unsigned char* __restrict__ arg2, unsigned char* __restrict__ arg3,
+            float* __restrict__ y2rows) {
     __shared__ float sbn1[32], sbn2[64];
     __shared__ double red[2 * kFwdWaves * 64];
     constexpr int kFwdThreads = kFwdWaves * 64;
@@ -284,13 +286,19 @@ k_vfe_stage(VfeIn in, const float* __restrict__ W1, const float* __restrict__ W2
         if (STAGE == 0 || STAGE == 2) {
             mx1 = has_pad ? 0.0f : -INFINITY;               // pad row: 0 @ W1 == 0
             mn1 = has_pad ? 0.0f : INFINITY;
+            int ax = 0, an = 0;                              // slot of the first row holding the max / min (0 = pad row)
             for (int t = 0; t < s; ++t) {
                 float y = 0.0f;
 #pragma unroll
                 for (int k = 0; k < 6; ++k) y = fmaf(rl(xr[k], t), W.w1[k], y);
+                if (y > mx1) ax = t + 1;
+                if (y < mn1) an = t + 1;
                 mx1 = fmaxf(mx1, y); mn1 = fminf(mn1, y);
             }
-            if (STAGE == 2 && lane < 16) { ymm1[(size_t)v * 32 + lane] = mx1; ymm1[(size_t)v * 32 + 16 + lane] = mn1; }
+            if (STAGE == 2 && lane < 16) {
+                ymm1[(size_t)v * 32 + lane] = mx1; ymm1[(size_t)v * 32 + 16 + lane] = mn1;
+                if (arg1) { arg1[(size_t)v * 32 + lane] = (unsigned char)ax; arg1[(size_t)v * 32 + 16 + lane] = (unsigned char)an; }
+            }
         }
         // ---- pass 2: y2 = [pool1, a1] @ W2 -----------------------------------------------------
         const float pool1 = pool_from(mx1, mn1, sc1, sh1);
@@ -305,7 +313,10 @@ k_vfe_stage(VfeIn in, const float* __restrict__ W1, const float* __restrict__ W2
             const float y2pad = P2 + A2pad;
             mx2 = has_pad ? y2pad : -INFINITY;
             mn2 = has_pad ? y2pad : INFINITY;
+            int ax = 0, an = 0;
+            const size_t slot0 = (size_t)(virt ? in.info[LISEC_VI_NROWS] : rs_cur) + v;     // row_start[v] + v
             if (STAGE == 2 && has_pad) { s1 += wpad * (double)y2pad; s2 += wpad * (double)y2pad * (double)y2pad; }
+            if (STAGE == 2 && y2rows && lane < 32) y2rows[slot0 * 32 + lane] = y2pad;
             for (int t = 0; t < s; ++t) {
                 float y1 = 0.0f;
 #pragma unroll
@@ -315,10 +326,16 @@ k_vfe_stage(VfeIn in, const float* __restrict__ W1, const float* __restrict__ W2
 #pragma unroll
                 for (int k = 0; k < 16; ++k) y = fmaf(rl(a1, k), W.w2a[k], y);
                 y += P2;
+                if (y > mx2) ax = t + 1;
+                if (y < mn2) an = t + 1;
                 mx2 = fmaxf(mx2, y); mn2 = fminf(mn2, y);
                 if (STAGE == 2) { s1 += (double)y; s2 += (double)y * (double)y; }
+                if (STAGE == 2 && y2rows && lane < 32) y2rows[(slot0 + t + 1) * 32 + lane] = y;
             }
-            if (STAGE == 2 && lane < 32) { ymm2[(size_t)v * 64 + lane] = mx2; ymm2[(size_t)v * 64 + 32 + lane] = mn2; }
+            if (STAGE == 2 && lane < 32) {
+                ymm2[(size_t)v * 64 + lane] = mx2; ymm2[(size_t)v * 64 + 32 + lane] = mn2;
+                if (arg2) { arg2[(size_t)v * 64 + lane] = (unsigned char)ax; arg2[(size_t)v * 64 + 32 + lane] = (unsigned char)an; }
+            }
         }
         if (STAGE != 2) {
             // ---- pass 3: y3 = [pool2, a2] @ W3 -------------------------------------------------
@@ -327,6 +344,7 @@ k_vfe_stage(VfeIn in, const float* __restrict__ W1, const float* __restrict__ W2
 #pragma unroll
             for (int k = 0; k < 32; ++k) P3 = fmaf(rl(pool2, k), LDSW ? sW3p[k * 64 + lane + opq] : W.w3p[k], P3);
             float mx3 = -INFINITY, mn3 = INFINITY;
+            int ax3 = 0, an3 = 0;
             if (has_pad) {
                 const float a2pad = bnrelu(P2 + A2pad, sc2, sh2);
                 float y = 0.0f;
@@ -350,11 +368,14 @@ k_vfe_stage(VfeIn in, const float* __restrict__ W1, const float* __restrict__ W2
 #pragma unroll
                 for (int k = 0; k < 32; ++k) y = fmaf(rl(a2, k), W.w3a[k], y);
                 y += P3;
+                if (y > mx3) ax3 = t + 1;
+                if (y < mn3) an3 = t + 1;
                 mx3 = fmaxf(mx3, y); mn3 = fminf(mn3, y);
                 if (STAGE == 3) { s1 += (double)y; s2 += (double)y * (double)y; }
             }
             ymm3[(size_t)v * 128 + lane] = mx3;
             ymm3[(size_t)v * 128 + 64 + lane] = mn3;
+            if (STAGE == 3 && arg3) { arg3[(size_t)v * 128 + lane] = (unsigned char)ax3; arg3[(size_t)v * 128 + 64 + lane] = (unsigned char)an3; }
         }
         s_cur = s_nxt; rs_cur = rs_nxt; s_nxt = s_n2; rs_nxt = rs_n2;
 #pragma unroll
@@ -466,6 +487,11 @@ extern "C" size_t lisec_vfe_saved_floats(int cap_voxels) {
     return VfeSaved(nullptr, cap_voxels).floats;
 }
 
+extern "C" size_t lisec_vfe_saved_floats_rows(int cap_voxels, int n_points) {
+    if (cap_voxels < 0 || n_points < 0) return 0;
+    return VfeSaved(nullptr, cap_voxels, n_points).floats;
+}
+
 // the accumulators of layer 3 (+ a row_stats block for callers that pass none)
 extern "C" size_t lisec_vfe_workspace_bytes(void) {
     return align_up(sizeof(long long) * (size_t)kAccReplicas * 2 * 64 * 2, 256) +
@@ -474,12 +500,12 @@ extern "C" size_t lisec_vfe_workspace_bytes(void) {
 
 extern "C" int lisec_vfe_forward(const lisec_vfe_params* p, const int32_t* info,
                                  const int32_t* cell_voxel, const int32_t* npts,
-                                 const int32_t* row_start, const float* rows, int64_t* row_stats_, int ncells,
-                                 int T, int cap_voxels, int training, float* saved, void* workspace,
+                                 const int32_t* row_start, const float* rows, int64_t* row_stats_, int n_points,
+                                 int ncells, int T, int cap_voxels, int training, float* saved, void* workspace,
                                  size_t workspace_bytes, float* grid, lisec_stream_t stream_) {
     LISEC_CHECK_ARG(p && info && cell_voxel && npts && row_start && rows && saved && workspace && grid,
                     "NULL pointer");
-    LISEC_CHECK_ARG(ncells > 0 && T >= 1 && T <= 64 && cap_voxels >= 0, "bad sizes");
+    LISEC_CHECK_ARG(ncells > 0 && T >= 1 && T <= 64 && cap_voxels >= 0 && n_points >= 0, "bad sizes");
     for (int i = 0; i < 3; ++i)
         LISEC_CHECK_ARG(p->kernel[i] && p->gamma[i] && p->beta[i] && p->moving_mean[i] && p->moving_var[i],
                         "NULL VFE parameter pointer");
@@ -488,7 +514,7 @@ extern "C" int lisec_vfe_forward(const lisec_vfe_params* p, const int32_t* info,
         return LISEC_ENOSPC;
     }
     hipStream_t st = static_cast<hipStream_t>(stream_);
-    VfeSaved sv(saved, cap_voxels);
+    VfeSaved sv(saved, cap_voxels, training ? n_points : 0);       // n_points > 0: `saved` carries the per-row extras
     VfeIn in{info, npts, row_start, rows, ncells, T, cap_voxels};
     Carver carve(workspace);
     long long* acc3 = carve.take<long long>((size_t)kAccReplicas * 2 * 64 * 2);
@@ -520,16 +546,18 @@ extern "C" int lisec_vfe_forward(const lisec_vfe_params* p, const int32_t* info,
         }
         long long* acc2 = stats + LISEC_ROW_STATS_MOMENT_WORDS;       // zero on entry, re-zeroed by the grid writer
         LISEC_STAGE(2, in, p->kernel[0], p->kernel[1], p->kernel[2], bn, N, sv.ymm1, sv.ymm2, sv.ymm3,
-                    (const long long*)stats, (const long long*)nullptr, acc2, acc3);
+                    (const long long*)stats, (const long long*)nullptr, acc2, acc3, sv.arg1, sv.arg2, sv.arg3, sv.y2rows);
         LISEC_STAGE(3, in, p->kernel[0], p->kernel[1], p->kernel[2], bn, N, sv.ymm1, sv.ymm2, sv.ymm3,
-                    (const long long*)nullptr, (const long long*)acc2, acc3, (long long*)nullptr);
+                    (const long long*)nullptr, (const long long*)acc2, acc3, (long long*)nullptr, sv.arg1, sv.arg2,
+                    sv.arg3, sv.y2rows);
         LISEC_LAUNCH_CHECK();
         hipLaunchKernelGGL(k_vfe_grid, dim3(2048), dim3(256), 0, st, info, cell_voxel, ncells, cap_voxels,
                            sv.ymm3, sv.bn3, grid, sv.vout, sv.delta, (const long long*)acc3, N, p->gamma[2],
                            p->beta[2], p->moving_mean[2], p->moving_var[2], acc2);
     } else {
         LISEC_STAGE(0, in, p->kernel[0], p->kernel[1], p->kernel[2], bn, N, sv.ymm1, sv.ymm2, sv.ymm3,
-                    (const long long*)nullptr, (const long long*)nullptr, (long long*)nullptr, (long long*)nullptr);
+                    (const long long*)nullptr, (const long long*)nullptr, (long long*)nullptr, (long long*)nullptr,
+                    (unsigned char*)nullptr, (unsigned char*)nullptr, (unsigned char*)nullptr, (float*)nullptr);
         LISEC_LAUNCH_CHECK();
         hipLaunchKernelGGL(k_vfe_grid, dim3(2048), dim3(256), 0, st, info, cell_voxel, ncells, cap_voxels,
                            sv.ymm3, sv.bn3, grid, sv.vout, sv.delta, (const long long*)nullptr, N,

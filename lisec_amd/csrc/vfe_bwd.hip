@@ -411,6 +411,339 @@ k_l1(VfeIn in, const float* __restrict__ W1, const float* __restrict__ bn1, cons
     block_dw_out<6>(acc, 16, sDW, dw1_parts, w, lane);
 }
 
+
+// ================================================================================================================
+// Tiled (MFMA) backward of layers 3 and 2.  The per-voxel kernels above walk a voxel's rows one after the other with
+// lane = channel and v_readlane broadcasts: fine for a 20 k-point sweep (2.6 class rows per voxel), 0.6 ms on a
+// 200 k-point one.  Here the class rows ("slots": slot of row j of voxel v = row_start[v] + v + j, slot 0 = pad row)
+// are cut into 32-slot tiles regardless of voxel borders; per tile and layer three contractions run on the matrix cores
+//   y3 = [pool2 | a2] @ W3            (layer 3 only: the layer-2 pre-BN rows come from the forward, `y2rows`)
+//   dW += [pool | a]^T @ gy           (64x64 / 32x32 accumulators kept in registers across the wave's tiles)
+//   gh  = gy @ W^T                    (gradient wrt the layer's 2C inputs, stored per slot)
+// and the max-pool routing needs no search: the forward recorded the slot of the first row holding each per-voxel
+// maximum / minimum (`arg`), so "is this the winner row" is an integer compare.  What stays per voxel and sequential
+// (k_post: the pooled half of gh summed over the voxel's rows and handed to the winner row one layer down, the ReLU
+// gate, the BN-backward statistics) is elementwise.  lane = slot for everything elementwise (lanes l and l+32 hold the
+// same slot: an MFMA A operand wants k = 2*step + lane/32), LDS tiles with a 68-float row stride for the transposes.
+constexpr int kLdT = 68;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct TileCtx {
+    const int* slot_vox;      // voxel of every slot
+    const float* pool1;       // [nvox][16] pooled output of layer 1 per voxel
+    const float* pool2;       // [nvox][32]
+    const unsigned char* aw1; // [nvox][16] winner slot of layer 1 (max or min picked by the sign of the BN scale)
+    const unsigned char* aw2; // [nvox][32]
+    const unsigned char* aw3; // [nvox][64]
+};
+
+// per voxel: which slots it owns, its pooled inputs, its winner slots
+__global__ void __launch_bounds__(256)
+k_slot_prep(VfeIn in, const float* __restrict__ bn1, const float* __restrict__ bn2, const float* __restrict__ bn3,
+            const float* __restrict__ ymm1, const float* __restrict__ ymm2, const unsigned char* __restrict__ arg1,
+            const unsigned char* __restrict__ arg2, const unsigned char* __restrict__ arg3, int* __restrict__ slot_vox,
+            float* __restrict__ pool1, float* __restrict__ pool2, unsigned char* __restrict__ aw1,
+            unsigned char* __restrict__ aw2, unsigned char* __restrict__ aw3) {
+    const int lane = lane_id(), w = threadIdx.x >> 6;
+    int V = in.info[LISEC_VI_NVOX];
+    if (V > in.cap) V = in.cap;
+    const int nvox = V + (in.ncells - V > 0 ? 1 : 0);
+    const int c1 = lane & 15, c2 = lane & 31;
+    const float sc1 = bn1[c1], sh1 = bn1[16 + c1], sc2 = bn2[c2], sh2 = bn2[32 + c2], sc3 = bn3[lane];
+    for (int v = blockIdx.x * 4 + w; v < nvox; v += gridDim.x * 4) {
+        const bool virt = v == V;
+        const int s = virt ? 0 : in.npts[v];
+        const int base = (virt ? in.info[LISEC_VI_NROWS] : in.row_start[v]) + v;
+        if (lane <= s) slot_vox[base + lane] = v;
+        if (lane < 16) {
+            pool1[(size_t)v * 16 + lane] = pool_from(ymm1[(size_t)v * 32 + lane], ymm1[(size_t)v * 32 + 16 + lane], sc1, sh1);
+            aw1[(size_t)v * 16 + lane] = arg1[(size_t)v * 32 + (sc1 >= 0.f ? 0 : 16) + lane];
+        }
+        if (lane < 32) {
+            pool2[(size_t)v * 32 + lane] = pool_from(ymm2[(size_t)v * 64 + lane], ymm2[(size_t)v * 64 + 32 + lane], sc2, sh2);
+            aw2[(size_t)v * 32 + lane] = arg2[(size_t)v * 64 + (sc2 >= 0.f ? 0 : 32) + lane];
+        }
+        aw3[(size_t)v * 64 + lane] = arg3[(size_t)v * 128 + (sc3 >= 0.f ? 0 : 64) + lane];
+    }
+}
+
+struct SlotInfo {
+    int v, j;
+    bool valid;
+    float wr;
+    int row;      // index into in.rows of the slot's point (-1: pad row)
+};
+
+__device__ __forceinline__ SlotInfo slot_info(const VfeIn& in, const int* __restrict__ slot_vox, int sl, int S, int V,
+                                              int nE) {
+    SlotInfo q;
+    const bool inb = sl < S;
+    q.v = inb ? slot_vox[sl] : 0;
+    const bool virt = q.v == V;
+    const int s = (!inb || virt) ? 0 : in.npts[q.v];
+    const int rs = virt ? in.info[LISEC_VI_NROWS] : in.row_start[q.v];
+    q.j = sl - (rs + q.v);
+    const bool has_pad = virt || s < in.T;
+    q.valid = inb && (q.j > 0 || has_pad);
+    q.wr = q.j == 0 ? (virt ? (float)in.T * (float)nE : (float)(in.T - s)) : 1.f;
+    q.row = q.j > 0 ? rs + q.j - 1 : -1;
+    return q;
+}
+
+// LAYER 3: C = 64 channels, A' = [pool2 (32) | a2 (32)];  LAYER 2: C = 32, A' = [pool1 (16) | a1 (16)].
+// dyn LDS: per wave two tiles [32][kLdT]; then W [2C'][C] and W^T (C' = C input half-width * 2 = C), constants.
+template <int LAYER>
+__global__ void __launch_bounds__(256, 1)          // one wave per SIMD: the whole 512-register file
+k_bwd_tile(VfeIn in, TileCtx cx, const float* __restrict__ Wl /* (C, C) kernel of the layer */,
+           const float* __restrict__ W1, const float* __restrict__ bn_lo /* bnstate of the layer below */,
+           const float* __restrict__ bn_l /* bnstate of this layer */, const float* __restrict__ coef,
+           const float* __restrict__ y2rows, const float* __restrict__ dsrc /* L3: dout[v][64]; L2: gz2[slot][32] */,
+           float* __restrict__ ghbuf, double* __restrict__ dw_parts) {
+    constexpr int C = LAYER == 3 ? 64 : 32;         // channels of this layer == width of A'
+    constexpr int H = C / 2;                        // pooled / pointwise half width
+    constexpr int NB = C / 32;                      // 32-column blocks
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = lane_id(), w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    float* T1 = smem + w * (2 * 32 * kLdT);          // A' tile (lane = slot rows)
+    float* T2 = T1 + 32 * kLdT;                      // y3 / gy tile
+    float* sW = smem + 4 * (2 * 32 * kLdT);          // W[k][c]
+    float* sWT = sW + C * C;                         // W^T[c][k]
+    float* sK = sWT + C * C;                         // constants: scale, shift, mean, invstd, m1, m2 of this layer [6][C]
+    float* sLo = sK + 6 * C;                         // scale, shift of the layer below [2][H]
+    float* sW1 = sLo + 2 * H;                        // W1 (6 x 16), layer 2 only
+    for (int i = threadIdx.x; i < C * C; i += 256) {
+        const float v = Wl[i];
+        sW[i] = v;
+        sWT[(i % C) * C + i / C] = v;
+    }
+    for (int i = threadIdx.x; i < 4 * C; i += 256) sK[i] = bn_l[i];
+    for (int i = threadIdx.x; i < 2 * C; i += 256) sK[4 * C + i] = coef[i];
+    for (int i = threadIdx.x; i < 2 * H; i += 256) sLo[i] = bn_lo[i];
+    if (LAYER == 2) for (int i = threadIdx.x; i < 96; i += 256) sW1[i] = W1[i];
+    __syncthreads();
+    int V = in.info[LISEC_VI_NVOX];
+    if (V > in.cap) V = in.cap;
+    const int nE = in.ncells - V;
+    const int S = in.info[LISEC_VI_NROWS] + V + (nE > 0 ? 1 : 0);
+    const int ntiles = (S + 31) / 32;
+    f32x16 dW[NB][NB];
+#pragma unroll
+    for (int a = 0; a < NB; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) dW[a][b] = {0};
+    for (int tile = blockIdx.x * 4 + w; tile < ntiles; tile += gridDim.x * 4) {
+        const int sl = tile * 32 + l31;
+        const SlotInfo q = slot_info(in, cx.slot_vox, sl, S, V, nE);
+        // Lanes l and l + 32 hold the same slot; each OWNS the channels 2*i + half (what an MFMA A operand wants of it).
+        // ---- A' = [pooled inputs of the voxel | this slot's activation of the layer below], own half: Ah[i] = A'[2i+half]
+        float Ah[C / 2];
+        {
+            const float4* pp = reinterpret_cast<const float4*>((LAYER == 3 ? cx.pool2 : cx.pool1) + (size_t)q.v * H);
+#pragma unroll
+            for (int i = 0; i < H / 4; ++i) {
+                const float4 t = pp[i];
+                Ah[2 * i] = half ? t.y : t.x;
+                Ah[2 * i + 1] = half ? t.w : t.z;
+            }
+        }
+        float y2h[16];                                  // layer-2 pre-BN row of the slot, own half
+        {
+            const float4* yp = reinterpret_cast<const float4*>(y2rows + (size_t)(sl < S ? sl : 0) * 32);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float4 t = yp[i];
+                y2h[2 * i] = half ? t.y : t.x;
+                y2h[2 * i + 1] = half ? t.w : t.z;
+            }
+        }
+        if (LAYER == 3) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) Ah[H / 2 + i] = bnrelu(y2h[i], sLo[2 * i + half], sLo[H + 2 * i + half]);
+        } else {
+            float x[6] = {0, 0, 0, 0, 0, 0};
+            if (q.row >= 0) {
+                const float2* r = reinterpret_cast<const float2*>(in.rows + (size_t)q.row * 6);
+                const float2 p0 = r[0], p1 = r[1], p2 = r[2];
+                x[0] = p0.x; x[1] = p0.y; x[2] = p1.x; x[3] = p1.y; x[4] = p2.x; x[5] = p2.y;
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int c = 2 * i + half;
+                float y1 = 0.f;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) y1 = fmaf(x[k], sW1[k * 16 + c], y1);
+                Ah[H / 2 + i] = bnrelu(y1, sLo[c], sLo[H + c]);
+            }
+        }
+        if (!q.valid) {                                 // unused pad slot of a full voxel / beyond the last slot: its
+#pragma unroll                                          // saved rows were never written
+            for (int i = 0; i < C / 2; ++i) Ah[i] = 0.f;
+        }
+        // ---- gy, own half: gyh[i] = gy[2i + half] ----------------------------------------------------------------
+        float gyh[C / 2];
+        if (LAYER == 3) {
+            f32x16 acc[2] = {{0}, {0}};
+#pragma unroll
+            for (int kk = 0; kk < 32; ++kk) {
+                const float* wr_ = sW + (2 * kk + half) * 64 + l31;
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(Ah[kk], wr_[0], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(Ah[kk], wr_[32], acc[1], 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+                T2[row * kLdT + l31] = acc[0][r];
+                T2[row * kLdT + 32 + l31] = acc[1][r];
+            }
+            __threadfence_block();
+            const unsigned char* ap = cx.aw3 + (size_t)q.v * 64;
+            const float* dp = dsrc + (size_t)q.v * 64;
+#pragma unroll
+            for (int c4 = 0; c4 < 16; ++c4) {
+                const float4 d4 = *reinterpret_cast<const float4*>(dp + 4 * c4);
+                const uchar4 a4 = *reinterpret_cast<const uchar4*>(ap + 4 * c4);
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int i = 2 * c4 + u, c = 2 * i + half;          // c = 4*c4 + 2*u + half
+                    const float yv = T2[l31 * kLdT + c];
+                    const float dv = u ? (half ? d4.w : d4.z) : (half ? d4.y : d4.x);
+                    const int av = u ? (half ? a4.w : a4.z) : (half ? a4.y : a4.x);
+                    const float sc = sK[c], sh = sK[C + c], mu = sK[2 * C + c], is = sK[3 * C + c];
+                    const float m1 = sK[4 * C + c], m2 = sK[5 * C + c];
+                    const float gz = (av == q.j && fmaf(yv, sc, sh) > 0.f) ? dv : 0.f;
+                    const float yh = (yv - mu) * is;
+                    gyh[i] = q.valid ? sc * (gz - q.wr * m1 - q.wr * yh * m2) : 0.f;
+                }
+            }
+            __threadfence_block();                      // T2 is rewritten below
+        } else {
+            const float* gp = dsrc + (size_t)(sl < S ? sl : 0) * 32;
+#pragma unroll
+            for (int c4 = 0; c4 < 8; ++c4) {
+                const float4 g4 = *reinterpret_cast<const float4*>(gp + 4 * c4);
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int i = 2 * c4 + u, c = 2 * i + half;
+                    const float gv = u ? (half ? g4.w : g4.z) : (half ? g4.y : g4.x);
+                    const float sc = sK[c], mu = sK[2 * C + c], is = sK[3 * C + c];
+                    const float m1 = sK[4 * C + c], m2 = sK[5 * C + c];
+                    const float yh = (y2h[i] - mu) * is;
+                    gyh[i] = q.valid ? sc * (gv - q.wr * m1 - q.wr * yh * m2) : 0.f;
+                }
+            }
+        }
+        // ---- dW += A'^T gy : operands through LDS ([slot][channel] tiles), every lane stores the channels it owns
+#pragma unroll
+        for (int i = 0; i < C / 2; ++i) {
+            T1[l31 * kLdT + 2 * i + half] = Ah[i];
+            T2[l31 * kLdT + 2 * i + half] = gyh[i];
+        }
+        __threadfence_block();
+#pragma unroll
+        for (int s2 = 0; s2 < 16; ++s2) {
+            const float* ar = T1 + (2 * s2 + half) * kLdT + l31;
+            const float* br = T2 + (2 * s2 + half) * kLdT + l31;
+#pragma unroll
+            for (int mb = 0; mb < NB; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+                    dW[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[mb * 32], br[nb * 32], dW[mb][nb], 0, 0, 0);
+        }
+        // ---- gh = gy W^T, stored per slot ---------------------------------------------------------------------
+        f32x16 gh[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) gh[nb] = {0};
+#pragma unroll
+        for (int cc = 0; cc < C / 2; ++cc) {
+            const float* wt = sWT + (2 * cc + half) * C + l31;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+                gh[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(gyh[cc], wt[nb * 32], gh[nb], 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int slot = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (slot < S) {
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) ghbuf[(size_t)slot * C + nb * 32 + l31] = gh[nb][r];
+            }
+        }
+        __threadfence_block();                          // the tiles are reused by the wave's next tile
+    }
+    // ---- dW of the four waves, added in wave order, as per-workgroup fp64 partials [k][c] -----------------------
+    float* sDW = smem;                                   // C x C floats (the tile area is free now)
+    for (int round = 0; round < 4; ++round) {
+        __syncthreads();
+        if (w == round) {
+#pragma unroll
+            for (int mb = 0; mb < NB; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int k = mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, c = nb * 32 + l31;
+                        sDW[k * C + c] = (round == 0 ? 0.f : sDW[k * C + c]) + dW[mb][nb][r];
+                    }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < C * C; i += 256) dw_parts[(size_t)blockIdx.x * C * C + i] = (double)sDW[i];
+}
+
+// Per voxel, rows in order (lane = channel of the layer BELOW, C2 = 32 for LAYER 3, 16 for LAYER 2): the pooled half
+// of gh summed over the voxel's rows goes to that layer's winner row, the ReLU gate, the gradient wrt the pre-BN value
+// of the layer below per slot, and its BatchNormalization-backward statistics.
+template <int LAYER>
+__global__ void __launch_bounds__(256)
+k_post(VfeIn in, const float* __restrict__ W1, const float* __restrict__ bn_lo, const unsigned char* __restrict__ aw_lo,
+       const float* __restrict__ y2rows, const float* __restrict__ ghbuf, float* __restrict__ gzbuf,
+       double* __restrict__ st_parts) {
+    constexpr int C = LAYER == 3 ? 64 : 32, C2 = C / 2;
+    const int lane = lane_id(), w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane & (C2 - 1);
+    int V = in.info[LISEC_VI_NVOX];
+    if (V > in.cap) V = in.cap;
+    const int nE = in.ncells - V;
+    const int nvox = V + (nE > 0 ? 1 : 0);
+    const float sc = bn_lo[c], sh = bn_lo[C2 + c], mu = bn_lo[2 * C2 + c], is = bn_lo[3 * C2 + c];
+    float w1[6] = {0, 0, 0, 0, 0, 0};
+    if (LAYER == 2) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) w1[k] = W1[k * 16 + c];
+    }
+    double s1 = 0.0, s2 = 0.0;
+    for (int v = blockIdx.x * 4 + w; v < nvox; v += gridDim.x * 4) {
+        Vox x = load_vox(in, v, V, nE);
+        const size_t base = (size_t)(v == V ? in.info[LISEC_VI_NROWS] : x.rs) + v;
+        const int j0 = x.has_pad ? 0 : 1;
+        const int win = aw_lo[(size_t)v * C2 + c];
+        float gpool = 0.f;
+        for (int j = j0; j <= x.s; ++j) gpool += ghbuf[(base + j) * C + c];
+        for (int j = j0; j <= x.s; ++j) {
+            float y;
+            if (LAYER == 3) {
+                y = y2rows[(base + j) * 32 + c];
+            } else {
+                y = 0.f;
+                if (j > 0) {
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) y = fmaf(rl(x.xr[k], j - 1), w1[k], y);
+                }
+            }
+            float ga = ghbuf[(base + j) * C + C2 + c] + (win == j ? gpool : 0.f);
+            if (!(fmaf(y, sc, sh) > 0.f)) ga = 0.f;
+            if (lane < C2) {
+                gzbuf[(base + j) * C2 + lane] = ga;
+                s1 += (double)ga;
+                s2 += (double)ga * (double)((y - mu) * is);
+            }
+        }
+    }
+    block_stats_out(s1, s2, C2, st_parts, w, lane);
+}
+
 }  // namespace
 }  // namespace lisec
 
@@ -420,6 +753,10 @@ namespace {
 struct BwdWs {
     float *dout, *gz2, *gz1, *coef;
     double *parts_a, *parts_dw;
+    // tiled path
+    int* slot_vox;
+    float *pool1, *pool2, *gh;
+    unsigned char *aw1, *aw2, *aw3;
     size_t bytes;
     BwdWs(void* base, int cap, int n_points) {
         Carver c(base);
@@ -430,6 +767,13 @@ struct BwdWs {
         coef = c.take<float>(2 * 64);
         parts_a = c.take<double>((size_t)kBwdBlocks * 4 * 2 * 64);
         parts_dw = c.take<double>((size_t)kBwdBlocks * 64 * 64);
+        slot_vox = c.take<int>(crows + 32);
+        pool1 = c.take<float>((size_t)(cap + 1) * 16);
+        pool2 = c.take<float>((size_t)(cap + 1) * 32);
+        gh = c.take<float>((crows + 32) * 64);
+        aw1 = c.take<unsigned char>((size_t)(cap + 1) * 16);
+        aw2 = c.take<unsigned char>((size_t)(cap + 1) * 32);
+        aw3 = c.take<unsigned char>((size_t)(cap + 1) * 64);
         bytes = c.off;
     }
 };
@@ -443,8 +787,8 @@ extern "C" size_t lisec_vfe_backward_workspace_bytes(int cap_voxels, int n_point
 extern "C" int lisec_vfe_backward(const lisec_vfe_params* p, const int32_t* info, const int32_t* cell_voxel,
                                   const int32_t* npts, const int32_t* row_start, const float* rows, int n_points,
                                   int ncells, int T, int cap_voxels, const float* saved, const float* dgrid,
-                                  float* dout_rows, const float* g_all, const lisec_vfe_grads* g, void* workspace,
-                                  size_t workspace_bytes, lisec_stream_t stream_) {
+                                  float* dout_rows, const float* g_all, const lisec_vfe_grads* g, int flags,
+                                  void* workspace, size_t workspace_bytes, lisec_stream_t stream_) {
     LISEC_CHECK_ARG(p && info && cell_voxel && npts && row_start && rows && saved && g && workspace, "NULL pointer");
     LISEC_CHECK_ARG((dgrid != nullptr) != (dout_rows != nullptr), "pass either dgrid or dout_rows");
     LISEC_CHECK_ARG(!dout_rows || g_all, "dout_rows needs g_all");
@@ -457,7 +801,9 @@ extern "C" int lisec_vfe_backward(const lisec_vfe_params* p, const int32_t* info
         return LISEC_ENOSPC;
     }
     hipStream_t st = static_cast<hipStream_t>(stream_);
-    VfeSaved sv(const_cast<float*>(saved), cap_voxels);
+    const bool tiled = (flags & LISEC_VFE_BWD_TILED) != 0;
+    VfeSaved sv(const_cast<float*>(saved), cap_voxels, tiled ? n_points : 0);
+    LISEC_CHECK_ARG(!tiled || n_points > 0, "the tiled backward needs the per-row extras (n_points > 0)");
     VfeIn in{info, npts, row_start, rows, ncells, T, cap_voxels};
     const double N = (double)ncells * (double)T;
     // 1. route the grid gradient to voxels
@@ -479,20 +825,46 @@ extern "C" int lisec_vfe_backward(const lisec_vfe_params* p, const int32_t* info
     hipLaunchKernelGGL(k_l3_stats, dim3(kBwdBlocks), dim3(256), 0, st, in, sv.bn3, sv.ymm3, ws.dout, ws.parts_a);
     LISEC_LAUNCH_CHECK();
     if (int rc = launch_bn_bwd_finalize(ws.parts_a, kBwdBlocks, 64, N, g->gamma[2], g->beta[2], ws.coef, st)) return rc;
-    size_t lds3 = (size_t)(4 * 2 * kMaxRows * 32 + 64 * 64) * sizeof(float);
-    hipLaunchKernelGGL(k_l3, dim3(kBwdBlocks), dim3(256), lds3, st, in, p->kernel[0], p->kernel[1], p->kernel[2],
-                       sv.bn1, sv.bn2, sv.bn3, ws.coef, sv.ymm1, sv.ymm2, sv.ymm3, ws.dout, ws.gz2, ws.parts_dw,
-                       ws.parts_a);
-    LISEC_LAUNCH_CHECK();
-    if (int rc = launch_reduce_parts(ws.parts_dw, kBwdBlocks, 64 * 64, 1.0, g->kernel[2], nullptr, st)) return rc;
-    if (int rc = launch_bn_bwd_finalize(ws.parts_a, kBwdBlocks, 32, N, g->gamma[1], g->beta[1], ws.coef, st)) return rc;
-    // 3. layer 2
-    size_t lds2 = (size_t)(4 * 2 * kMaxRows * 16 + 32 * 32) * sizeof(float);
-    hipLaunchKernelGGL(k_l2, dim3(kBwdBlocks), dim3(256), lds2, st, in, p->kernel[0], p->kernel[1], sv.bn1, sv.bn2,
-                       ws.coef, sv.ymm1, ws.gz2, ws.gz1, ws.parts_dw, ws.parts_a);
-    LISEC_LAUNCH_CHECK();
-    if (int rc = launch_reduce_parts(ws.parts_dw, kBwdBlocks, 32 * 32, 1.0, g->kernel[1], nullptr, st)) return rc;
-    if (int rc = launch_bn_bwd_finalize(ws.parts_a, kBwdBlocks, 16, N, g->gamma[0], g->beta[0], ws.coef, st)) return rc;
+    if (tiled) {
+        // layers 3 and 2 on 32-slot tiles (matrix cores) + the per-voxel elementwise passes
+        constexpr int kTileBlocks = 256;                 // one 4-wave workgroup per CU (104 KB of LDS for layer 3)
+        TileCtx cx{ws.slot_vox, ws.pool1, ws.pool2, ws.aw1, ws.aw2, ws.aw3};
+        hipLaunchKernelGGL(k_slot_prep, dim3(kBwdBlocks), dim3(256), 0, st, in, sv.bn1, sv.bn2, sv.bn3, sv.ymm1, sv.ymm2,
+                           sv.arg1, sv.arg2, sv.arg3, ws.slot_vox, ws.pool1, ws.pool2, ws.aw1, ws.aw2, ws.aw3);
+        const size_t ldsT3 = (size_t)(4 * 2 * 32 * kLdT + 2 * 64 * 64 + 6 * 64 + 2 * 32 + 96) * sizeof(float);
+        hipLaunchKernelGGL(k_bwd_tile<3>, dim3(kTileBlocks), dim3(256), ldsT3, st, in, cx, p->kernel[2], p->kernel[0],
+                           sv.bn2, sv.bn3, ws.coef, sv.y2rows, ws.dout, ws.gh, ws.parts_dw);
+        LISEC_LAUNCH_CHECK();
+        if (int rc = launch_reduce_parts(ws.parts_dw, kTileBlocks, 64 * 64, 1.0, g->kernel[2], nullptr, st)) return rc;
+        hipLaunchKernelGGL(k_post<3>, dim3(kBwdBlocks), dim3(256), 0, st, in, p->kernel[0], sv.bn2, ws.aw2, sv.y2rows,
+                           ws.gh, ws.gz2, ws.parts_a);
+        LISEC_LAUNCH_CHECK();
+        if (int rc = launch_bn_bwd_finalize(ws.parts_a, kBwdBlocks, 32, N, g->gamma[1], g->beta[1], ws.coef, st)) return rc;
+        const size_t ldsT2 = (size_t)(4 * 2 * 32 * kLdT + 2 * 32 * 32 + 6 * 32 + 2 * 16 + 96) * sizeof(float);
+        hipLaunchKernelGGL(k_bwd_tile<2>, dim3(kTileBlocks), dim3(256), ldsT2, st, in, cx, p->kernel[1], p->kernel[0],
+                           sv.bn1, sv.bn2, ws.coef, sv.y2rows, ws.gz2, ws.gh, ws.parts_dw);
+        LISEC_LAUNCH_CHECK();
+        if (int rc = launch_reduce_parts(ws.parts_dw, kTileBlocks, 32 * 32, 1.0, g->kernel[1], nullptr, st)) return rc;
+        hipLaunchKernelGGL(k_post<2>, dim3(kBwdBlocks), dim3(256), 0, st, in, p->kernel[0], sv.bn1, ws.aw1, sv.y2rows,
+                           ws.gh, ws.gz1, ws.parts_a);
+        LISEC_LAUNCH_CHECK();
+        if (int rc = launch_bn_bwd_finalize(ws.parts_a, kBwdBlocks, 16, N, g->gamma[0], g->beta[0], ws.coef, st)) return rc;
+    } else {
+        size_t lds3 = (size_t)(4 * 2 * kMaxRows * 32 + 64 * 64) * sizeof(float);
+        hipLaunchKernelGGL(k_l3, dim3(kBwdBlocks), dim3(256), lds3, st, in, p->kernel[0], p->kernel[1], p->kernel[2],
+                           sv.bn1, sv.bn2, sv.bn3, ws.coef, sv.ymm1, sv.ymm2, sv.ymm3, ws.dout, ws.gz2, ws.parts_dw,
+                           ws.parts_a);
+        LISEC_LAUNCH_CHECK();
+        if (int rc = launch_reduce_parts(ws.parts_dw, kBwdBlocks, 64 * 64, 1.0, g->kernel[2], nullptr, st)) return rc;
+        if (int rc = launch_bn_bwd_finalize(ws.parts_a, kBwdBlocks, 32, N, g->gamma[1], g->beta[1], ws.coef, st)) return rc;
+        // 3. layer 2
+        size_t lds2 = (size_t)(4 * 2 * kMaxRows * 16 + 32 * 32) * sizeof(float);
+        hipLaunchKernelGGL(k_l2, dim3(kBwdBlocks), dim3(256), lds2, st, in, p->kernel[0], p->kernel[1], sv.bn1, sv.bn2,
+                           ws.coef, sv.ymm1, ws.gz2, ws.gz1, ws.parts_dw, ws.parts_a);
+        LISEC_LAUNCH_CHECK();
+        if (int rc = launch_reduce_parts(ws.parts_dw, kBwdBlocks, 32 * 32, 1.0, g->kernel[1], nullptr, st)) return rc;
+        if (int rc = launch_bn_bwd_finalize(ws.parts_a, kBwdBlocks, 16, N, g->gamma[0], g->beta[0], ws.coef, st)) return rc;
+    }
     // 4. layer 1
     hipLaunchKernelGGL(k_l1, dim3(kBwdBlocks), dim3(256), 0, st, in, p->kernel[0], sv.bn1, ws.coef, ws.gz1,
                        ws.parts_dw);

@@ -47,11 +47,20 @@ struct VfeWeights {          // per lane: column (lane & (C-1)) of each Dense ke
 };
 
 
-struct VfeSaved {            // layout of the caller-owned `saved` float buffer (lisec_vfe_saved_floats)
+struct VfeSaved {            // layout of the caller-owned `saved` float buffer (lisec_vfe_saved_floats / _rows)
     float *bn1, *bn2, *bn3, *ymm1, *ymm2, *ymm3;
     float *vout, *delta;     // per-voxel grid value (row V = the empty-cell constant) and vout[v] - vout[V]
+    // per-row extras of a training forward (only when the buffer was sized with the row capacity, n_points > 0):
+    // what the tiled (MFMA) backward reads instead of recomputing the layers and searching for the max-pool winners.
+    //   arg1/2/3  uint8[(cap+1)][2][C]: class-row slot (0 = the pad row, t+1 = real row t) of the FIRST row holding the
+    //             per-voxel maximum ([0]) / minimum ([1]) of the pre-BN value of layer 1/2/3
+    //   y2rows    float[slots][32]: pre-BN output of layer 2 of every class row; slot of row j of voxel v =
+    //             row_start[v] + v + j (slot 0 of a voxel is its pad row, unused when the voxel is full)
+    unsigned char *arg1, *arg2, *arg3;
+    float* y2rows;
     size_t floats;
-    VfeSaved(float* base, int cap) {
+    static size_t slots(int cap, int n_points) { return (size_t)n_points + (size_t)cap + 2; }
+    VfeSaved(float* base, int cap, int n_points = 0) {
         size_t o = 0;
         bn1 = base + o; o += 4 * 16;
         bn2 = base + o; o += 4 * 32;
@@ -61,6 +70,13 @@ struct VfeSaved {            // layout of the caller-owned `saved` float buffer 
         ymm3 = base + o; o += (size_t)(cap + 1) * 128;
         vout = base + o; o += (size_t)(cap + 1) * 64;
         delta = base + o; o += (size_t)(cap + 1) * 64;
+        arg1 = arg2 = arg3 = nullptr; y2rows = nullptr;
+        if (n_points > 0) {
+            arg1 = reinterpret_cast<unsigned char*>(base + o); o += (size_t)(cap + 1) * 32 / 4;
+            arg2 = reinterpret_cast<unsigned char*>(base + o); o += (size_t)(cap + 1) * 64 / 4;
+            arg3 = reinterpret_cast<unsigned char*>(base + o); o += (size_t)(cap + 1) * 128 / 4;
+            y2rows = base + o; o += slots(cap, n_points) * 32;
+        }
         floats = o;
     }
 };

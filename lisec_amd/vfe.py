@@ -4,6 +4,7 @@ Stands where the reference applies addVFELayer(6,32), addVFELayer(32,64), addFCN
 MaxPoolingVFELayer(combine=True) to the dense (D,H,W,T,6) tensor (model_training.py:231-235).
 """
 import ctypes
+import os
 
 import torch
 
@@ -21,6 +22,9 @@ class VFEStack:
         self._ws = torch.empty(self.lib.lisec_vfe_workspace_bytes(), dtype=torch.uint8, device=self.device)
         self._saved = None
         self._sample = None
+        # LISEC_VFE_BWD=valu: the row-by-row backward of layers 3 and 2 instead of the 32-row MFMA tiles
+        self.tiled = os.environ.get("LISEC_VFE_BWD", "tiled") != "valu"
+        self._saved_rows = 0
 
     def _cparams(self, theta=None):
         p, s = self.params, VfeParams()
@@ -36,15 +40,19 @@ class VFEStack:
         """sample: VoxelSample.  Returns the dense (D, H, W, 64) grid (device tensor)."""
         D, H, W = sample.grid_shape
         ncells = D * H * W
-        need = self.lib.lisec_vfe_saved_floats(sample.cap)
+        # training with the tiled backward: `saved` also carries the per-row extras (winner slots, layer-2 rows)
+        rows_cap = sample.n_points if (training and self.tiled) else 0
+        need = (self.lib.lisec_vfe_saved_floats_rows(sample.cap, rows_cap) if rows_cap
+                else self.lib.lisec_vfe_saved_floats(sample.cap))
         if self._saved is None or self._saved.numel() < need:
             self._saved = torch.empty(need, dtype=torch.float32, device=self.device)
+        self._saved_rows = rows_cap
         grid = out if out is not None else torch.empty((D, H, W, 64), dtype=torch.float32, device=self.device)
         cp = self._cparams()
         _lib.check(self.lib.lisec_vfe_forward(
             ctypes.byref(cp), _lib.ptr(sample.info), _lib.ptr(sample.cell_voxel), _lib.ptr(sample.npts),
             _lib.ptr(sample.row_start), _lib.ptr(sample.rows), _lib.ptr(getattr(sample, "row_stats", None)),
-            ncells, sample.cfg.sampleSize, sample.cap, 1 if training else 0, _lib.ptr(self._saved), _lib.ptr(self._ws), self._ws.numel(),
+            rows_cap, ncells, sample.cfg.sampleSize, sample.cap, 1 if training else 0, _lib.ptr(self._saved), _lib.ptr(self._ws), self._ws.numel(),
             _lib.ptr(grid), _lib.current_stream()))
         self._sample = sample
         return grid
@@ -83,5 +91,5 @@ class VFEStack:
             ctypes.byref(cp), _lib.ptr(sample.info), _lib.ptr(sample.cell_voxel), _lib.ptr(sample.npts),
             _lib.ptr(sample.row_start), _lib.ptr(sample.rows), sample.n_points, D * H * W,
             sample.cfg.sampleSize, sample.cap, _lib.ptr(self._saved), _lib.ptr(dgrid), _lib.ptr(dout_rows),
-            _lib.ptr(g_all), ctypes.byref(g),
+            _lib.ptr(g_all), ctypes.byref(g), 1 if self._saved_rows else 0,
             _lib.ptr(self._bws), self._bws.numel(), _lib.current_stream()))

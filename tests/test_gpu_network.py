@@ -171,7 +171,8 @@ def test_train_step_fully_occupied_grid_vs_oracle():
     net = LisecNet(H, W, D, T, params=ParamStore(dev, init=op))
     sample = mt.dense_to_sample(dense, dev)
     assert sample.host_info()["V"] == D * H * W
-    net.vfe._saved = torch.full((_lib.load().lisec_vfe_saved_floats(sample.cap),), float("nan"), device=dev)
+    net.vfe._saved = torch.full((_lib.load().lisec_vfe_saved_floats_rows(sample.cap, sample.n_points),), float("nan"),
+                                device=dev)
     y_cls = rng.integers(0, 3, (H // 2, W // 2, 2)).astype(np.float32)
     y_reg = rng.normal(0, 1, (H // 2, W // 2, 14)).astype(np.float32)
     p64 = {k: v.double() for k, v in op.items()}

@@ -95,10 +95,12 @@ def test_vfe_full_lyft_grid_vs_sparse_oracle():
     assert np.abs(const).max() > 0
 
 
+@pytest.mark.parametrize("path", ["tiled", "valu"])
 @pytest.mark.parametrize("grid", ["small", "lyft"])
-def test_vfe_backward_vs_sparse_oracle(grid):
+def test_vfe_backward_vs_sparse_oracle(grid, path):
     """Gradients of the VFE variables from a random grid gradient, vs the fp64 row-class oracle
-    (itself proven equal to dense torch autograd in tests/test_oracle_model.py)."""
+    (itself proven equal to dense torch autograd in tests/test_oracle_model.py).  Both backward paths: layers 3 and 2
+    on 32-row MFMA tiles with the forward's saved winner slots (the default), and row by row per voxel."""
     from lisec_amd.params import ParamStore
     from lisec_amd.vfe import VFEStack
     from lisec_amd.voxelizer import Voxelizer
@@ -123,6 +125,7 @@ def test_vfe_backward_vs_sparse_oracle(grid):
     dev = torch.device("cuda")
     store = ParamStore(dev, init=op)
     vfe = VFEStack(store)
+    vfe.tiled = path == "tiled"
     sample = Voxelizer(**cfg)(pts)
     vfe.forward(sample, training=True)
     dgrid = torch.randn(D, H, W, 64, device=dev) * (1.0 / ncells) ** 0.5
