@@ -20,6 +20,9 @@
 // index order (deterministic).
 #include "vfe_common.h"
 
+#include <cstdio>
+#include <cstdlib>
+
 namespace lisec {
 namespace {
 
@@ -825,29 +828,45 @@ extern "C" int lisec_vfe_backward(const lisec_vfe_params* p, const int32_t* info
     hipLaunchKernelGGL(k_l3_stats, dim3(kBwdBlocks), dim3(256), 0, st, in, sv.bn3, sv.ymm3, ws.dout, ws.parts_a);
     LISEC_LAUNCH_CHECK();
     if (int rc = launch_bn_bwd_finalize(ws.parts_a, kBwdBlocks, 64, N, g->gamma[2], g->beta[2], ws.coef, st)) return rc;
+    // LISEC_DEBUG_SYNC=1 (diagnostic): synchronise and report after every launch of this call
+    static const bool dbg = getenv("LISEC_DEBUG_SYNC") != nullptr;
+#define LISEC_DBG(WHAT_)                                                                       \
+    do {                                                                                       \
+        if (dbg) {                                                                             \
+            hipError_t e_ = hipStreamSynchronize(st);                                          \
+            fprintf(stderr, "[lisec_vfe_backward] %s: %s\n", WHAT_, hipGetErrorString(e_));    \
+            if (e_ != hipSuccess) { set_error("%s failed", WHAT_); return LISEC_EHIP; }        \
+        }                                                                                      \
+    } while (0)
+    LISEC_DBG("statistics of layer 3");
     if (tiled) {
         // layers 3 and 2 on 32-slot tiles (matrix cores) + the per-voxel elementwise passes
         constexpr int kTileBlocks = 256;                 // one 4-wave workgroup per CU (104 KB of LDS for layer 3)
         TileCtx cx{ws.slot_vox, ws.pool1, ws.pool2, ws.aw1, ws.aw2, ws.aw3};
         hipLaunchKernelGGL(k_slot_prep, dim3(kBwdBlocks), dim3(256), 0, st, in, sv.bn1, sv.bn2, sv.bn3, sv.ymm1, sv.ymm2,
                            sv.arg1, sv.arg2, sv.arg3, ws.slot_vox, ws.pool1, ws.pool2, ws.aw1, ws.aw2, ws.aw3);
+        LISEC_DBG("k_slot_prep");
         const size_t ldsT3 = (size_t)(4 * 2 * 32 * kLdT + 2 * 64 * 64 + 6 * 64 + 2 * 32 + 96) * sizeof(float);
         hipLaunchKernelGGL(k_bwd_tile<3>, dim3(kTileBlocks), dim3(256), ldsT3, st, in, cx, p->kernel[2], p->kernel[0],
                            sv.bn2, sv.bn3, ws.coef, sv.y2rows, ws.dout, ws.gh, ws.parts_dw);
         LISEC_LAUNCH_CHECK();
+        LISEC_DBG("k_bwd_tile<3>");
         if (int rc = launch_reduce_parts(ws.parts_dw, kTileBlocks, 64 * 64, 1.0, g->kernel[2], nullptr, st)) return rc;
         hipLaunchKernelGGL(k_post<3>, dim3(kBwdBlocks), dim3(256), 0, st, in, p->kernel[0], sv.bn2, ws.aw2, sv.y2rows,
                            ws.gh, ws.gz2, ws.parts_a);
         LISEC_LAUNCH_CHECK();
+        LISEC_DBG("k_post<3>");
         if (int rc = launch_bn_bwd_finalize(ws.parts_a, kBwdBlocks, 32, N, g->gamma[1], g->beta[1], ws.coef, st)) return rc;
         const size_t ldsT2 = (size_t)(4 * 2 * 32 * kLdT + 2 * 32 * 32 + 6 * 32 + 2 * 16 + 96) * sizeof(float);
         hipLaunchKernelGGL(k_bwd_tile<2>, dim3(kTileBlocks), dim3(256), ldsT2, st, in, cx, p->kernel[1], p->kernel[0],
                            sv.bn1, sv.bn2, ws.coef, sv.y2rows, ws.gz2, ws.gh, ws.parts_dw);
         LISEC_LAUNCH_CHECK();
+        LISEC_DBG("k_bwd_tile<2>");
         if (int rc = launch_reduce_parts(ws.parts_dw, kTileBlocks, 32 * 32, 1.0, g->kernel[1], nullptr, st)) return rc;
         hipLaunchKernelGGL(k_post<2>, dim3(kBwdBlocks), dim3(256), 0, st, in, p->kernel[0], sv.bn1, ws.aw1, sv.y2rows,
                            ws.gh, ws.gz1, ws.parts_a);
         LISEC_LAUNCH_CHECK();
+        LISEC_DBG("k_post<2>");
         if (int rc = launch_bn_bwd_finalize(ws.parts_a, kBwdBlocks, 16, N, g->gamma[0], g->beta[0], ws.coef, st)) return rc;
     } else {
         size_t lds3 = (size_t)(4 * 2 * kMaxRows * 32 + 64 * 64) * sizeof(float);
