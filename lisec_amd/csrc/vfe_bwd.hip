@@ -486,11 +486,11 @@ __device__ __forceinline__ SlotInfo slot_info(const VfeIn& in, const int* __rest
     const bool virt = q.v == V;
     const int s = (!inb || virt) ? 0 : in.npts[q.v];
     const int rs = virt ? in.info[LISEC_VI_NROWS] : in.row_start[q.v];
-    q.j = sl - (rs + q.v);
+    q.j = inb ? sl - (rs + q.v) : 0;                 // beyond the last slot (tail of the last tile): no row at all
     const bool has_pad = virt || s < in.T;
     q.valid = inb && (q.j > 0 || has_pad);
     q.wr = q.j == 0 ? (virt ? (float)in.T * (float)nE : (float)(in.T - s)) : 1.f;
-    q.row = q.j > 0 ? rs + q.j - 1 : -1;
+    q.row = (inb && q.j > 0) ? rs + q.j - 1 : -1;
     return q;
 }
 
