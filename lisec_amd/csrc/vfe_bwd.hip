@@ -842,8 +842,13 @@ extern "C" int lisec_vfe_backward(const lisec_vfe_params* p, const int32_t* info
     if (tiled) {
         // layers 3 and 2 on 32-slot tiles (matrix cores) + the per-voxel elementwise passes
         constexpr int kTileBlocks = 256;                 // one 4-wave workgroup per CU (104 KB of LDS for layer 3)
+        // the per-voxel passes are chains of dependent loads: a wave per voxel and enough waves to hide them (the
+        // statistic partials of k_post cap the grid: parts_a holds 2048 rows of 2 x 32 doubles)
+        int vblocks = cdiv((long long)cap_voxels + 1, 4);
+        if (vblocks > 2048) vblocks = 2048;
+        if (vblocks < 1) vblocks = 1;
         TileCtx cx{ws.slot_vox, ws.pool1, ws.pool2, ws.aw1, ws.aw2, ws.aw3};
-        hipLaunchKernelGGL(k_slot_prep, dim3(kBwdBlocks), dim3(256), 0, st, in, sv.bn1, sv.bn2, sv.bn3, sv.ymm1, sv.ymm2,
+        hipLaunchKernelGGL(k_slot_prep, dim3(vblocks), dim3(256), 0, st, in, sv.bn1, sv.bn2, sv.bn3, sv.ymm1, sv.ymm2,
                            sv.arg1, sv.arg2, sv.arg3, ws.slot_vox, ws.pool1, ws.pool2, ws.aw1, ws.aw2, ws.aw3);
         LISEC_DBG("k_slot_prep");
         const size_t ldsT3 = (size_t)(4 * 2 * 32 * kLdT + 2 * 64 * 64 + 6 * 64 + 2 * 32 + 96) * sizeof(float);
@@ -852,22 +857,22 @@ extern "C" int lisec_vfe_backward(const lisec_vfe_params* p, const int32_t* info
         LISEC_LAUNCH_CHECK();
         LISEC_DBG("k_bwd_tile<3>");
         if (int rc = launch_reduce_parts(ws.parts_dw, kTileBlocks, 64 * 64, 1.0, g->kernel[2], nullptr, st)) return rc;
-        hipLaunchKernelGGL(k_post<3>, dim3(kBwdBlocks), dim3(256), 0, st, in, p->kernel[0], sv.bn2, ws.aw2, sv.y2rows,
+        hipLaunchKernelGGL(k_post<3>, dim3(vblocks), dim3(256), 0, st, in, p->kernel[0], sv.bn2, ws.aw2, sv.y2rows,
                            ws.gh, ws.gz2, ws.parts_a);
         LISEC_LAUNCH_CHECK();
         LISEC_DBG("k_post<3>");
-        if (int rc = launch_bn_bwd_finalize(ws.parts_a, kBwdBlocks, 32, N, g->gamma[1], g->beta[1], ws.coef, st)) return rc;
+        if (int rc = launch_bn_bwd_finalize(ws.parts_a, vblocks, 32, N, g->gamma[1], g->beta[1], ws.coef, st)) return rc;
         const size_t ldsT2 = (size_t)(4 * 2 * 32 * kLdT + 2 * 32 * 32 + 6 * 32 + 2 * 16 + 96) * sizeof(float);
         hipLaunchKernelGGL(k_bwd_tile<2>, dim3(kTileBlocks), dim3(256), ldsT2, st, in, cx, p->kernel[1], p->kernel[0],
                            sv.bn1, sv.bn2, ws.coef, sv.y2rows, ws.gz2, ws.gh, ws.parts_dw);
         LISEC_LAUNCH_CHECK();
         LISEC_DBG("k_bwd_tile<2>");
         if (int rc = launch_reduce_parts(ws.parts_dw, kTileBlocks, 32 * 32, 1.0, g->kernel[1], nullptr, st)) return rc;
-        hipLaunchKernelGGL(k_post<2>, dim3(kBwdBlocks), dim3(256), 0, st, in, p->kernel[0], sv.bn1, ws.aw1, sv.y2rows,
+        hipLaunchKernelGGL(k_post<2>, dim3(vblocks), dim3(256), 0, st, in, p->kernel[0], sv.bn1, ws.aw1, sv.y2rows,
                            ws.gh, ws.gz1, ws.parts_a);
         LISEC_LAUNCH_CHECK();
         LISEC_DBG("k_post<2>");
-        if (int rc = launch_bn_bwd_finalize(ws.parts_a, kBwdBlocks, 16, N, g->gamma[0], g->beta[0], ws.coef, st)) return rc;
+        if (int rc = launch_bn_bwd_finalize(ws.parts_a, vblocks, 16, N, g->gamma[0], g->beta[0], ws.coef, st)) return rc;
     } else {
         size_t lds3 = (size_t)(4 * 2 * kMaxRows * 32 + 64 * 64) * sizeof(float);
         hipLaunchKernelGGL(k_l3, dim3(kBwdBlocks), dim3(256), lds3, st, in, p->kernel[0], p->kernel[1], p->kernel[2],

@@ -24,6 +24,7 @@ class VFEStack:
         self._sample = None
         # LISEC_VFE_BWD=valu: the row-by-row backward of layers 3 and 2 instead of the 32-row MFMA tiles
         self.tiled = os.environ.get("LISEC_VFE_BWD", "tiled") != "valu"
+        self.tiled_min_points = int(os.environ.get("LISEC_VFE_TILED_MIN_POINTS", "65536"))
         self._saved_rows = 0
 
     def _cparams(self, theta=None):
@@ -40,8 +41,10 @@ class VFEStack:
         """sample: VoxelSample.  Returns the dense (D, H, W, 64) grid (device tensor)."""
         D, H, W = sample.grid_shape
         ncells = D * H * W
-        # training with the tiled backward: `saved` also carries the per-row extras (winner slots, layer-2 rows)
-        rows_cap = sample.n_points if (training and self.tiled) else 0
+        # training with the tiled backward: `saved` also carries the per-row extras (winner slots, layer-2 rows).  The
+        # tiles pay off on big sweeps (a 200 k-point sweep: 0.6 -> 0.3 ms); on a 20 k-point one the row-by-row kernels
+        # are as fast and need two launches fewer, so the choice follows the sweep's size (known on the host)
+        rows_cap = sample.n_points if (training and self.tiled and sample.n_points >= self.tiled_min_points) else 0
         need = (self.lib.lisec_vfe_saved_floats_rows(sample.cap, rows_cap) if rows_cap
                 else self.lib.lisec_vfe_saved_floats(sample.cap))
         if self._saved is None or self._saved.numel() < need:

@@ -125,7 +125,7 @@ def test_vfe_backward_vs_sparse_oracle(grid, path):
     dev = torch.device("cuda")
     store = ParamStore(dev, init=op)
     vfe = VFEStack(store)
-    vfe.tiled = path == "tiled"
+    vfe.tiled, vfe.tiled_min_points = path == "tiled", 0
     sample = Voxelizer(**cfg)(pts)
     vfe.forward(sample, training=True)
     dgrid = torch.randn(D, H, W, 64, device=dev) * (1.0 / ncells) ** 0.5
