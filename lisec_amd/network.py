@@ -308,6 +308,10 @@ class LisecNet:
         self.bparts = torch.empty(nparts, dtype=torch.float64, device=dev)
         self.head_db = torch.empty(16, dtype=f32, device=dev)
         self.wgrad_ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        # LISEC_MID_WGRAD=main: the weight gradients of the 3D middle layers run on the main stream, after their data
+        # gradient, instead of beside it on the second stream (measurement knob; they need a workspace of their own)
+        self.mid_wgrad_main = os.environ.get("LISEC_MID_WGRAD", "side") == "main"
+        self.wgrad_ws_main = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if self.mid_wgrad_main else None
         # weight gradients are leaves of the backward graph: they run on a second HIP stream next to the
         # BN-backward / data-gradient chain (the RPN layers are too small to fill 256 CUs on their own)
         # ROCm multiplexes same-priority streams onto a few hardware queues round-robin, so a plain second stream
@@ -473,8 +477,12 @@ class LisecNet:
                 dgrad_into(c, d[dst], L["src"])
             else:   # mid layer: conv3d -> BN -> Dense(relu)
                 n, dn = L["name"], L["dense"]
-                on_side(lambda n=n, dn=dn: ops.conv_wgrad(dn.g, a[n + ".y"], d[n + ".u"], p.grad_view(G, dn.wname),
-                                                          self.wgrad_ws, in_bn=self.bnstate[dn.in_bn]))
+                if self.mid_wgrad_main:
+                    ops.conv_wgrad(dn.g, a[n + ".y"], d[n + ".u"], p.grad_view(G, dn.wname), self.wgrad_ws_main,
+                                   in_bn=self.bnstate[dn.in_bn])
+                else:
+                    on_side(lambda n=n, dn=dn: ops.conv_wgrad(dn.g, a[n + ".y"], d[n + ".u"], p.grad_view(G, dn.wname),
+                                                              self.wgrad_ws, in_bn=self.bnstate[dn.in_bn]))
                 # Dense data gradient; its store also reduces the statistics of the BatchNormalization under it
                 msink = self._bwd_sink(c.bn, 64, c.M)
                 ops.conv_forward(self.dgeom[dn.name], d[n + ".u"], self.packed_t[dn.name][0], d[n + ".z"],
@@ -498,9 +506,13 @@ class LisecNet:
                     on_side(sparse_wgrad)
                     ops.conv_forward(dg, d[n + ".z"], self.packed_t[c.name][0], self.dout_rows, rows=rows)
                 else:
-                    on_side(lambda L=L, c=c, n=n: ops.conv_wgrad(c.g, a[L["src"]], d[n + ".z"],
-                                                                 p.grad_view(G, c.wname), self.wgrad_ws))
-                    dgrad_into(c, d[n + ".z"], L["src"])
+                    if self.mid_wgrad_main:
+                        dgrad_into(c, d[n + ".z"], L["src"])
+                        ops.conv_wgrad(c.g, a[L["src"]], d[n + ".z"], p.grad_view(G, c.wname), self.wgrad_ws_main)
+                    else:
+                        on_side(lambda L=L, c=c, n=n: ops.conv_wgrad(c.g, a[L["src"]], d[n + ".z"],
+                                                                     p.grad_view(G, c.wname), self.wgrad_ws))
+                        dgrad_into(c, d[n + ".z"], L["src"])
         # ---- VFE -----------------------------------------------------------------------------------
         self.vfe.backward(None, G, dout_rows=self.dout_rows, g_all=self.g_all)
         done = self._join_event
