@@ -311,6 +311,7 @@ class LisecNet:
         # LISEC_MID_WGRAD=main: the weight gradients of the 3D middle layers run on the main stream, after their data
         # gradient, instead of beside it on the second stream (measurement knob; they need a workspace of their own)
         self.mid_wgrad_main = os.environ.get("LISEC_MID_WGRAD", "side") == "main"
+        self.fork_every = max(1, int(os.environ.get("LISEC_FORK_EVERY", "1")))
         self.wgrad_ws_main = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if self.mid_wgrad_main else None
         # weight gradients are leaves of the backward graph: they run on a second HIP stream next to the
         # BN-backward / data-gradient chain (the RPN layers are too small to fill 256 CUs on their own)
@@ -401,10 +402,13 @@ class LisecNet:
         events = self._fork_events
         nfork = [0]
 
-        def on_side(fn, torch_ops=False):
-            """Runs fn's launches on the second stream after everything issued so far on the main one.  C-ABI launches
-            take the pinned handle; only a fn that also issues torch / torch.distributed work needs torch's (slow)
-            stream context."""
+        fork_every = self.fork_every
+        pending = []
+
+        def flush_side():
+            """Records ONE event on the main stream and runs every pending closure on the second stream behind it."""
+            if not pending:
+                return
             if nfork[0] == len(events):
                 events.append(torch.cuda.Event())
             ev = events[nfork[0]]                       # events are reused step after step
@@ -413,13 +417,24 @@ class LisecNet:
             self.side.wait_event(ev)
             pin = _lib.pin_stream(side_handle)
             try:
-                if torch_ops:
-                    with torch.cuda.stream(self.side):
+                for fn, torch_ops in pending:
+                    if torch_ops:
+                        with torch.cuda.stream(self.side):
+                            fn()
+                    else:
                         fn()
-                else:
-                    fn()
             finally:
                 _lib.pin_stream(pin)
+                del pending[:]
+
+        def on_side(fn, torch_ops=False):
+            """Runs fn's launches on the second stream after everything issued so far on the main one.  C-ABI launches
+            take the pinned handle; only a fn that also issues torch / torch.distributed work needs torch's (slow)
+            stream context.  With fork_every > 1 the closures are handed over in groups: one event record (a marker
+            packet in the main queue, ~6 us of it) per group instead of one per weight gradient."""
+            pending.append((fn, torch_ops))
+            if len(pending) >= fork_every or torch_ops:
+                flush_side()
 
         writes = {}                            # gradient buffer -> contributions stored so far
         bwd_ready = {}                         # gradient buffer -> partial rows of its BN-backward statistics
@@ -514,6 +529,7 @@ class LisecNet:
                                                                      p.grad_view(G, c.wname), self.wgrad_ws))
                         dgrad_into(c, d[n + ".z"], L["src"])
         # ---- VFE -----------------------------------------------------------------------------------
+        flush_side()
         self.vfe.backward(None, G, dout_rows=self.dout_rows, g_all=self.g_all)
         done = self._join_event
         done.record(self.side)
