@@ -84,7 +84,21 @@ class DataParallel:
         self.comm = None                 # lisec_comm_t (RCCL communicator) of the data plane
         self.comm_stream = None
         if self.on_gpu and dist.get_backend() == "nccl" and os.environ.get("LISEC_ALLREDUCE", "rccl") != "torch":
-            self._init_comm()
+            try:
+                self._init_comm()
+            except Exception as e:                     # noqa: BLE001 -- keep training: torch.distributed carries the exchange
+                import sys
+                print(f"[lisec_amd] rank {self.rank}: the C ABI's RCCL communicator could not be made ({e}); "
+                      "gradients go through torch.distributed.all_reduce", file=sys.stderr, flush=True)
+                self.comm = None
+            # every rank must agree on the data plane (a rank without a communicator cannot join the others' all-reduce)
+            if self.world > 1:
+                flags = [None] * self.world
+                dist.all_gather_object(flags, self.comm is not None)
+                if not all(flags) and self.comm is not None:
+                    from . import _lib
+                    _lib.load().lisec_comm_destroy(self.comm)
+                    self.comm = None
 
     def _init_comm(self):
         from . import _lib
