@@ -104,11 +104,17 @@ class DataParallel:
         from . import _lib
         lib = _lib.load()
         ident = ctypes.create_string_buffer(128)                 # LISEC_COMM_ID_BYTES
+        box = [None]
         if self.rank == 0:
-            _lib.check(lib.lisec_comm_unique_id(ident))
-        box = [bytes(ident.raw)]
+            if lib.lisec_comm_unique_id(ident) == 0:             # on failure every rank learns it (None) and falls back
+                box = [bytes(ident.raw)]
+            else:
+                box = [None, lib.lisec_last_error().decode()]
         if self.world > 1:
+            box = box + [None] * (2 - len(box))
             dist.broadcast_object_list(box, src=0)
+        if box[0] is None:
+            raise _lib.LisecError("lisec_comm_unique_id failed on rank 0: " + str(box[1] if len(box) > 1 else ""))
         comm = ctypes.c_void_p()
         with torch.cuda.device(self.device):
             _lib.check(lib.lisec_comm_init(self.rank, self.world, box[0], ctypes.byref(comm)))
