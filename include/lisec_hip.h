@@ -377,6 +377,13 @@ typedef struct lisec_copy_desc {
 } lisec_copy_desc;
 int lisec_copy2d_batched(const lisec_copy_desc* device_table, int n, lisec_stream_t stream);
 
+/* Permute((2,3,4,1)) + Reshape (model_training.py:242-243): in (D,H,W,C) -> out (H,W,C*D), channel c*D + d; HW = H*W.
+ * With the reference's Constants.nz = 8 the depth is 1 there and the fold is a view; other nz need this copy.
+ * inverse != 0: out (D,H,W,C) <- in (H,W,C*D), the gradient's way back, stored as 0 where mask (laid out like out,
+ * optional) is <= 0 -- the ReLU of the Dense layer that produced the folded tensor. */
+int lisec_fold_depth(const float* in, float* out, int D, long long HW, int C, int inverse, const float* mask,
+                     lisec_stream_t stream);
+
 /* grad[i] = act[i] > 0 ? grad[i] : 0   (backward of Dense(..., 'relu'), :195) */
 int lisec_relu_mask(float* grad, const float* act, long long n, lisec_stream_t stream);
 

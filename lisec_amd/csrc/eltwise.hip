@@ -232,6 +232,23 @@ __global__ void k_sgd_nesterov_dev(float* __restrict__ w, const float* __restric
     }
 }
 
+// Permute((2,3,4,1)) + Reshape of the reference (model_training.py:242-243): (D,H,W,C) -> (H,W,C*D), channel c*D + d.
+// inverse: the gradient's way back, optionally gated by the ReLU of the tensor that was folded (mask > 0).
+__global__ void k_fold_depth(const float* __restrict__ in, float* __restrict__ out, int D, long long HW, int C,
+                             int inverse, const float* __restrict__ mask) {
+    const long long total = (long long)D * HW * C;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        // i walks the (D,H,W,C) tensor: coalesced on that side
+        const int c = (int)(i % C);
+        const long long t = i / C;
+        const long long p = t % HW;
+        const int d = (int)(t / HW);
+        const long long j = (p * C + c) * D + d;
+        if (!inverse) out[j] = in[i];
+        else out[i] = (!mask || mask[i] > 0.f) ? in[j] : 0.f;
+    }
+}
+
 __global__ void k_scale(float* __restrict__ x, long long n4, float s) {
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
         float4 a = reinterpret_cast<float4*>(x)[i];
@@ -417,6 +434,15 @@ extern "C" int lisec_sgd_nesterov_step_dev(float* theta, const float* grad, floa
     if (n == 0) return LISEC_OK;
     hipLaunchKernelGGL(k_sgd_nesterov_dev, dim3(ew_blocks(n / 4)), dim3(kEwThreads), 0, static_cast<hipStream_t>(stream_),
                        theta, grad, velocity, n / 4, lr, decay, momentum, state);
+    LISEC_LAUNCH_CHECK();
+    return LISEC_OK;
+}
+
+extern "C" int lisec_fold_depth(const float* in, float* out, int D, long long HW, int C, int inverse, const float* mask,
+                                lisec_stream_t stream_) {
+    LISEC_CHECK_ARG(in && out && D >= 1 && HW >= 1 && C >= 1, "bad fold arguments");
+    hipLaunchKernelGGL(k_fold_depth, dim3(ew_blocks((long long)D * HW * C)), dim3(kEwThreads), 0,
+                       static_cast<hipStream_t>(stream_), in, out, D, HW, C, inverse, mask);
     LISEC_LAUNCH_CHECK();
     return LISEC_OK;
 }

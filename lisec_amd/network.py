@@ -19,7 +19,7 @@ import numpy as np
 import torch
 
 from . import _lib, ops
-from .params import DECONVS, MID, RPN_BLOCKS, ParamStore
+from .params import DECONVS, MID, RPN_BLOCKS, ParamStore, fold_depth
 from .vfe import VFEStack
 
 
@@ -40,7 +40,10 @@ class LisecNet:
         if nx % 8 or ny % 8:
             raise ValueError("nx and ny must be multiples of 8 (three stride-2 RPN blocks)")
         self.H, self.W, self.D, self.T = nx, ny, nz, maxPoints
-        self.params = params if params is not None else ParamStore(self.device)
+        self.dprime = fold_depth(nz)
+        self.params = params if params is not None else ParamStore(self.device, dprime=self.dprime)
+        if self.params.dprime != self.dprime:
+            raise ValueError(f"variables are for a depth fold of {self.params.dprime}, nz={nz} folds to {self.dprime}")
         self.vfe = VFEStack(self.params, self.device)
         dev, f32 = self.device, torch.float32
         D, H, W = self.D, self.H, self.W
@@ -67,10 +70,14 @@ class LisecNet:
                                                        (0, 0, 0), 64, 64),
                                 n + ".dense.kernel", (1, 64, 64, 0, 64, 1), in_bn=n + ".bn", out_relu=True)))
             d_in, prev = d_out, n + ".u"
+        # Permute((2,3,4,1)) + Reshape (model_training.py:242-243): (D',H,W,64) -> (H,W,64*D'), channel c*D' + d.
+        # D' = 1 (Constants.nz = 8): a view, nothing to do; otherwise one permuting copy ("fold") each way
+        h, w, cin = H, W, 64 * d_in
         if d_in != 1:
-            raise ValueError(f"the middle layers must reduce depth to 1 (got {d_in}); nz={nz} unsupported")
-        # ---- RPN (model_training.py:245-255) -----------------------------------------------------
-        h, w, cin = H, W, 64
+            buf("fold", H, W, cin)
+            self.fold_src, prev = prev, "fold"
+        else:
+            self.fold_src = None
         src, src_bn = prev, None
         Ho, Wo = H // 2, W // 2
         buf("concat", Ho, Wo, 768)
@@ -228,6 +235,8 @@ class LisecNet:
                 self._run_conv(L["conv"], a[L["src"]], a[n + ".y"], training)
                 self._run_conv(L["dense"], a[n + ".y"], a[n + ".u"], training)
             elif L["kind"] == "conv":
+                if L["src"] == "fold":
+                    ops.fold_depth(a[self.fold_src], a["fold"], self.dprime, self.H * self.W, 64)
                 self._run_conv(L["conv"], a[L["src"]], a[L["dst"]], training)
             else:
                 b = L["slot"]
@@ -247,7 +256,7 @@ class LisecNet:
         self.velocity = torch.zeros_like(p.theta)
         self.dact = {}
         for name, t in self.act.items():
-            if name.endswith(".u") or name in ("concat", "head") or ".y" in name:
+            if name.endswith(".u") or name in ("concat", "head", "fold") or ".y" in name:
                 self.dact[name] = torch.empty_like(t)
         self.packed_t = {}
         self.dgeom = {}
@@ -490,6 +499,10 @@ class LisecNet:
                     lo = p.offsets["rpn1.conv0.kernel"][1]
                     on_side(lambda lo=lo: rpn_grads_ready(lo, p.n_theta), torch_ops=True)
                 dgrad_into(c, d[dst], L["src"])
+                if L["src"] == "fold":
+                    # back through Permute + Reshape, gated by the ReLU of the last middle block's Dense (:195)
+                    ops.fold_depth(d["fold"], d[self.fold_src], self.dprime, self.H * self.W, 64, inverse=True,
+                                   mask=a[self.fold_src])
             else:   # mid layer: conv3d -> BN -> Dense(relu)
                 n, dn = L["name"], L["dense"]
                 if self.mid_wgrad_main:

@@ -243,6 +243,13 @@ def sgd_nesterov_step_dev(theta, grad, velocity, lr, decay, momentum, state):
                                                        _lib.ptr(state), _lib.current_stream()))
 
 
+def fold_depth(x, out, D, HW, C, inverse=False, mask=None):
+    """(D,H,W,C) <-> (H,W,C*D) (Permute + Reshape of model_training.py:242-243); inverse: gradient, ReLU-gated by mask."""
+    _lib.check(_lib.load().lisec_fold_depth(_lib.ptr(x), _lib.ptr(out), D, HW, C, 1 if inverse else 0, _lib.ptr(mask),
+                                            _lib.current_stream()))
+    return out
+
+
 def scale_(x, s):
     _lib.check(_lib.load().lisec_scale(_lib.ptr(x), x.numel(), s, _lib.current_stream()))
 

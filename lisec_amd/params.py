@@ -19,8 +19,19 @@ MID = (((2, 1, 1), (1, 1, 1)), ((1, 1, 1), (0, 1, 1)), ((2, 1, 1), (1, 1, 1)))  
 TRAINABLE_KINDS = ("kernel", "bias", "gamma", "beta")
 
 
-def param_specs():
-    """[(name, shape, kind)] in forward order."""
+def fold_depth(nz):
+    """Depth left after the three Conv3D layers (model_training.py:236-238): nz = 8 -> 4 -> 2 -> 1.  The RPN input has
+    64 * fold_depth(nz) channels after Permute((2,3,4,1)) + Reshape (:242-243)."""
+    d = int(nz)
+    for stride, pad in MID:
+        d = (d + 2 * pad[0] - 3) // stride[0] + 1
+        if d < 1:
+            raise ValueError(f"nz={nz}: the middle layers leave no depth")
+    return d
+
+
+def param_specs(dprime=1):
+    """[(name, shape, kind)] in forward order.  dprime = fold_depth(nz): the first RPN conv reads 64*dprime channels."""
     specs = []
 
     def bn(prefix, c):
@@ -36,7 +47,7 @@ def param_specs():
         specs.append((f"mid{i+1}.conv.bias", (64,), "bias"))
         bn(f"mid{i+1}.bn", 64)
         specs.append((f"mid{i+1}.dense.kernel", (64, 64), "kernel"))
-    cin = 64
+    cin = 64 * dprime
     for b, (cout, q) in enumerate(RPN_BLOCKS):                                        # :245-252
         for j in range(q + 1):
             specs.append((f"rpn{b+1}.conv{j}.kernel", (3, 3, cin, cout), "kernel"))
@@ -53,12 +64,12 @@ def param_specs():
     return specs
 
 
-def glorot_numpy(seed=1234):
+def glorot_numpy(seed=1234, dprime=1):
     """Keras default initialisers: glorot_uniform kernels, zero biases, BN gamma=1, beta=0,
     moving_mean=0, moving_variance=1.  Returns dict name -> float32 numpy array."""
     rng = np.random.default_rng(seed)
     out = {}
-    for name, shape, kind in param_specs():
+    for name, shape, kind in param_specs(dprime):
         if kind == "kernel":
             rf = int(np.prod(shape[:-2])) if len(shape) > 2 else 1
             limit = math.sqrt(6.0 / (rf * shape[-2] + rf * shape[-1]))
@@ -74,9 +85,14 @@ def glorot_numpy(seed=1234):
 class ParamStore:
     """theta (trainable) + state (BN moving statistics) as flat fp32 device tensors with named views."""
 
-    def __init__(self, device, init=None):
+    def __init__(self, device, init=None, dprime=None):
         self.device = device
-        self.specs = param_specs()
+        if dprime is None:                 # inferred from the first RPN kernel of `init` (64 * dprime input channels)
+            dprime = 1
+            if init is not None and "rpn1.conv0.kernel" in init:
+                dprime = max(1, int(np.asarray(init["rpn1.conv0.kernel"]).shape[2]) // 64)
+        self.dprime = int(dprime)
+        self.specs = param_specs(self.dprime)
         self.offsets = {}
         nt = ns = 0
         for name, shape, kind in self.specs:
@@ -92,7 +108,7 @@ class ParamStore:
         self.version = 0          # bumped by every external write (load_dict / touch): consumers repack on change
         self.theta = torch.zeros(nt, dtype=torch.float32, device=device)
         self.state = torch.zeros(ns, dtype=torch.float32, device=device)
-        self.load_dict(init if init is not None else glorot_numpy())
+        self.load_dict(init if init is not None else glorot_numpy(dprime=self.dprime))
 
     def view(self, name, buf=None):
         """Named view into theta / state (or into `buf`, a buffer laid out like theta).  Views are cached per buffer:

@@ -48,8 +48,10 @@ DECONVS = ((3, 1), (2, 2), (4, 4))                 # (kernel, stride) :246,:249,
 MID = (((2, 1, 1), (1, 1, 1)), ((1, 1, 1), (0, 1, 1)), ((2, 1, 1), (1, 1, 1)))  # (stride, pad) :236-238
 
 
-def param_specs():
-    """[(name, shape, kind)] of every variable, in forward order (trainable and BN moving stats)."""
+def param_specs(dprime=1):
+    """[(name, shape, kind)] of every variable, in forward order (trainable and BN moving stats).  dprime: the depth the
+    three Conv3D layers leave (1 for Constants.nz = 8); Permute + Reshape (model_training.py:242-243) folds it into the
+    channels, so the first RPN conv reads 64 * dprime of them."""
     specs = []
 
     def bn(prefix, c):
@@ -65,7 +67,7 @@ def param_specs():
         specs.append((f"mid{i+1}.conv.bias", (64,), "bias"))
         bn(f"mid{i+1}.bn", 64)
         specs.append((f"mid{i+1}.dense.kernel", (64, 64), "kernel"))
-    cin = 64
+    cin = 64 * dprime
     for b, (cout, q) in enumerate(RPN_BLOCKS):
         for j in range(q + 1):
             specs.append((f"rpn{b+1}.conv{j}.kernel", (3, 3, cin, cout), "kernel"))
@@ -223,12 +225,12 @@ def train_step(params, velocity, x, y_cls, y_reg, iteration):
     return loss.detach(), grads, new_p, new_v, (cls.detach(), reg.detach())
 
 
-def glorot_params(seed=1234, dtype=torch.float32, randomize_bn=False):
+def glorot_params(seed=1234, dtype=torch.float32, randomize_bn=False, dprime=1):
     """Keras default initialisers (glorot_uniform kernels, zero biases, BN gamma=1/beta=0/mean=0/var=1).
     randomize_bn=True draws non-trivial BN variables so parity tests exercise them."""
     rng = np.random.default_rng(seed)
     out = {}
-    for name, shape, kind in param_specs():
+    for name, shape, kind in param_specs(dprime):
         if kind == "kernel":
             rf = int(np.prod(shape[:-2])) if len(shape) > 2 else 1
             limit = math.sqrt(6.0 / (rf * shape[-2] + rf * shape[-1]))

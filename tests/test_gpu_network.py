@@ -201,6 +201,67 @@ def test_train_step_fully_occupied_grid_vs_oracle():
         assert err <= tol, f"grad {name}: err {err:.3e} tol {tol:.3e}"
 
 
+def test_depth_fold_nz12_forward_and_training_step(tmp_path):
+    """Permute((2,3,4,1)) + Reshape in its general form (model_training.py:242-243): nz = 12 leaves a depth of 2 after
+    the three Conv3D layers, the RPN then reads 128 = 64*2 channels with channel index c*2 + d.  (Constants.nz = 8 folds
+    to depth 1, where the pair is a view.)  Forward in both BatchNormalization modes and one training step vs the dense
+    oracle in fp64."""
+    from lisec_amd.network import LisecNet
+    from lisec_amd.params import ParamStore, fold_depth
+    from lisec_amd.voxelizer import Voxelizer
+    from oracle import model_ref as M
+    from oracle import voxel_ref
+
+    assert fold_depth(8) == 1 and fold_depth(12) == 2 and fold_depth(16) == 3
+    cfg = dict(SMALL, maxVoxelZ=12)
+    rng = np.random.default_rng(21)
+    n = 3500
+    pts = np.stack([rng.uniform(-4.2, 4.2, n), rng.uniform(-4.2, 4.2, n), rng.uniform(0.0, 3.1, n)], 1).astype(np.float32)
+    op = M.glorot_params(seed=55, randomize_bn=True, dprime=2)
+    assert tuple(op["rpn1.conv0.kernel"].shape) == (3, 3, 128, 128)
+    dev = torch.device("cuda")
+    net = LisecNet(16, 32, 12, 35, params=ParamStore(dev, init=op))
+    assert net.dprime == 2 and net.act["fold"].shape == (16, 32, 128)
+    sample = Voxelizer(**cfg)(pts)
+    ref_vox = voxel_ref.voxelize_ref(pts.astype(np.float64), **cfg)
+    dense = torch.from_numpy(voxel_ref.to_dense(ref_vox, (12, 16, 32, 35, 6)))[None].double()
+    p64 = {k: v.double() for k, v in op.items()}
+    for training in (False, True):
+        cls, reg = net.forward(sample, training=training)
+        taps = {}
+        cls_r, reg_r = M.forward(p64, dense, training=training, stats={}, taps=taps)
+        close(cls.cpu().numpy(), cls_r.numpy(), what=f"class map (nz=12, training={training})")
+        close(reg.cpu().numpy(), reg_r.numpy(), what=f"regression map (nz=12, training={training})")
+    kink = min(float(v.abs().min()) for k, v in taps.items() if ".z" in k) < 5e-6
+    y_cls = rng.integers(0, 3, (8, 16, 2)).astype(np.float32)
+    y_reg = rng.normal(0, 1, (8, 16, 14)).astype(np.float32)
+    vel = {n_: torch.zeros_like(p64[n_]) for n_, _, k in M.param_specs(2) if M.is_trainable(k)}
+    loss_r, grads_r, _, _, _ = M.train_step(p64, vel, dense, torch.from_numpy(y_cls)[None].double(),
+                                            torch.from_numpy(y_reg)[None].double(), 0)
+    lo = net.train_step(sample, torch.from_numpy(y_cls).to(dev), torch.from_numpy(y_reg).to(dev))
+    torch.cuda.synchronize()
+    assert abs(lo[0].item() - loss_r.item()) <= 1e-5 * abs(loss_r.item())
+    gtol = 1e-1 if kink else 3e-3
+    for name, g in grads_r.items():
+        got = net.params.grad_view(net.grad, name).cpu().numpy()
+        ref = g.numpy()
+        if ".conv" in name and name.endswith(".bias") and np.abs(ref).max() < 1e-12:
+            assert np.abs(got).max() < 1e-5, name
+            continue
+        err, tol = np.abs(got - ref).max(), gtol * np.abs(ref).max() + 1e-7
+        assert err <= tol, f"grad {name}: err {err:.3e} tol {tol:.3e}"
+    # the drop-in surface with this nz: createModel -> predict -> save (Keras-layout .h5 and .npz) -> load_model
+    from lisec_amd import model_training as mt
+    model = mt.createModel(16, 32, 12, 35)
+    want = model.predict(mt.SparseVoxels(sample))
+    for name in ("m12.h5", "m12.npz"):
+        model.save(str(tmp_path / name))
+        again = mt.load_model(str(tmp_path / name))
+        assert again.nz == 12 and again.net.dprime == 2
+        got = again.predict(mt.SparseVoxels(sample))
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+
+
 def _oracle_loss(cls, reg, yc, yr, loss):
     """'mse': compile(loss=['mse','mse']) (model_training.py:296); 'smoothl1_ce': the sigmoid cross-entropy +
     SmoothL1 pair BASELINE.json's config 4 names (lisec_rpn_loss kind 1)."""
