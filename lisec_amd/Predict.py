@@ -26,3 +26,15 @@ def predictMain(samples, outPath, level5Data, model, dataDir=None):
         prob, regress = model.predict(trainVFEPoints)                                     # Predict.py:38
         np.save(os.path.join(outPath, 'sample' + str(i) + '_label.npy'), prob)
         np.save(os.path.join(outPath, 'sample' + str(i) + '_regress.npy'), regress)
+
+
+if __name__ == '__main__':
+    # python -m lisec_amd.Predict [model.h5] [outPath]      (Predict.py:43-59)
+    import sys
+    from .model_training import MaxPoolingVFELayer, RepeatLayer, _lyft_dataset, load_model
+    level5Data = _lyft_dataset()
+    model = load_model(sys.argv[1] if len(sys.argv) > 1 else os.path.join('fixedTheta', '15SampleEpoch0_fixed.h5'),
+                       custom_objects={'RepeatLayer': RepeatLayer, 'MaxPoolingVFELayer': MaxPoolingVFELayer})
+    samples = [level5Data.get('sample', scene['first_sample_token']) for scene in level5Data.scene]
+    print('Testing on ' + str(len(samples)))
+    predictMain(samples, sys.argv[2] if len(sys.argv) > 2 else 'fixedTheta', level5Data, model)

@@ -507,3 +507,24 @@ def train_with_model(samples, level5Data, model_path, save_path):
         print(history.history)
     model.save(save_path)
     return model
+
+
+def _lyft_dataset():
+    """The driver blocks of the reference build a LyftDataset from a hard-coded Windows path (model_training.py:349-355,
+    Predict.py:43-49); here the root comes from Constants.lyft_data_dir ($LISEC_LYFT_DATA_DIR)."""
+    try:
+        from lyft_dataset_sdk.lyftdataset import LyftDataset
+    except ImportError as e:                       # the SDK is not a dependency of the hot path
+        raise SystemExit("the command-line driver needs lyft_dataset_sdk (pip install lyft-dataset-sdk): " + str(e))
+    return LyftDataset(data_path=Constants.lyft_data_dir, json_path=os.path.join(Constants.lyft_data_dir, 'train_data'),
+                       verbose=True)
+
+
+if __name__ == '__main__':
+    # python -m lisec_amd.model_training [save_path]      (model_training.py:349-364)
+    import sys
+    level5Data = _lyft_dataset()
+    save_path = sys.argv[1] if len(sys.argv) > 1 else os.path.join('models', '180SampleEpoch0.h5')
+    samples = [level5Data.get('sample', scene['first_sample_token']) for scene in level5Data.scene]
+    print('Training on ' + str(len(samples)))
+    train(samples[:], level5Data, save_path)
