@@ -318,10 +318,12 @@ def main():
         mid1 = next(L for L in net.layers if L["name"] == "mid1")
         c = mid1["conv"]
 
+        grid = net.dense_grid()
+
         def run_mid1():
             # TAG_ROOFLINE: one un-sliced launch under its own symbol (k_igemm<0,false,1>), so the row of that
             # symbol in the rocprofv3 --stats summary of this command is this layer alone
-            ops.conv_forward(c.g, net.act["grid"], net.packed[c.name], net.act["mid1.y"],
+            ops.conv_forward(c.g, grid, net.packed[c.name], net.act["mid1.y"],
                              bias=net.params.view(c.bias), stats=net.parts, flags=ops.TAG_ROOFLINE)
         ms = event_time_ms(run_mid1, 20)
         # algorithmic FLOPs: 2 * positions * 27 taps * 64 * 64; depth-padding taps included
@@ -343,11 +345,11 @@ def main():
         sample = vox(pts)
 
         def run_vfe():
-            net.vfe.forward(sample, True, out=net.act["grid"])
+            net.vfe.forward(sample, True, out=grid)
         ms_v = event_time_ms(run_vfe, 20)
         hi = sample.host_info()
         vfe_bytes = 12.0 * len(cloud) + 24.0 * hi["rows"] + 4.0 * 64 * net.D * net.H * net.W
-        ms_g = event_time_ms(lambda: net.vfe.rewrite_grid(net.act["grid"]), 50)
+        ms_g = event_time_ms(lambda: net.vfe.rewrite_grid(grid), 50)
         grid_bytes = 4.0 * 64 * net.D * net.H * net.W
         gbs = grid_bytes / (ms_g * 1e-3) / 1e9
         # traffic from PMC: WRITE_SIZE 160 000 KiB (= the algorithmic bytes) + FETCH_SIZE 4 875 KiB x2

@@ -138,7 +138,8 @@ size_t lisec_vfe_workspace_bytes(void);
  * row_stats: the voxeliser's side output (NULL: the moments are summed here, one more launch).
  * n_points: 0, or the row capacity `saved` was sized for with lisec_vfe_saved_floats_rows (training only: the
  *           per-row extras are then written).
- * grid  dev float32[ncells*64]: (D,H,W,64), every cell written (empty cells hold relu(BN3(.)) != 0).
+ * grid  dev float32[ncells*64]: (D,H,W,64), every cell written (empty cells hold relu(BN3(.)) != 0); NULL = only
+ *       the compact per-voxel outputs (VOUT / DELTA in `saved`), the input of lisec_conv_field_forward.
  */
 int lisec_vfe_forward(const lisec_vfe_params* p, const int32_t* info, const int32_t* cell_voxel,
                       const int32_t* npts, const int32_t* row_start, const float* rows, int64_t* row_stats,
@@ -330,6 +331,24 @@ int lisec_conv_tap_sums(const lisec_conv_geom* g, const float* dy, float* S, voi
 int lisec_const_field_grads(const float* W, const float* S, const float* cvec, const int32_t* cvec_row,
                             int cvec_row_max, int ntaps, int Cin, int Cout, float* dW, float* g_all,
                             lisec_stream_t stream);
+
+/* First middle layer, forward over the VFE's compact output instead of the dense grid (csrc/field_conv.hip): the tensor
+ * Conv3D(64, 3, (2,1,1)) reads at model_training.py:236 is a constant vector on the empty cells plus V voxel rows, so
+ *   out[p] = bias + sum_{taps inside the grid} W[tap]^T c + sum_{taps that read voxel v} W[tap]^T delta_v
+ * is evaluated as one V x 64 x (27*64) contraction and one pass that writes `out` -- the same values as
+ * lisec_conv_forward on the dense grid up to fp32 summation order, ~1 GFLOP instead of 70.8 on a Lyft sweep.
+ *   g          mode-0 geometry of the layer, Cin == Cout == 64, at most 3 taps per axis
+ *   vout/delta the VOUT / DELTA fields of lisec_vfe_forward's `saved` buffer ((row_capacity+1, 64) each)
+ *   info, coords, cell_voxel: the voxeliser's outputs; row_capacity: its voxel capacity
+ *   packed_w   the layer's kernel from lisec_conv_pack_weights (the layout lisec_conv_forward takes)
+ *   out        float32 (Do*Ho*Wo, out_stride), every row written
+ *   sink       optional LISEC_SINK_FORWARD sink: BatchNormalization batch statistics of `out`, finalised in the call
+ * Deterministic (every sum in a fixed order, statistics in fixed-point accumulators). */
+size_t lisec_conv_field_forward_workspace_bytes(const lisec_conv_geom* g, int row_capacity);
+int lisec_conv_field_forward(const lisec_conv_geom* g, const float* vout, const float* delta, const int32_t* info,
+                             const int32_t* coords, const int32_t* cell_voxel, int row_capacity,
+                             const float* packed_w, const float* bias, float* out, const lisec_bn_sink* sink,
+                             void* workspace, size_t workspace_bytes, lisec_stream_t stream);
 
 /* BatchNormalization statistics (Keras: axis -1, eps 1e-3, momentum 0.99, biased batch variance).
  * bnstate: float[4*C] {scale = gamma*rsqrt(var+eps), shift = beta - mean*scale, mean, invstd}.

@@ -1,0 +1,269 @@
+// Forward of the FIRST Conv3D over the VFE's compact output (gfx950): a constant field plus V voxel rows.
+//
+// The tensor that layer reads (model_training.py:235-236) holds one constant vector c on every empty cell and a
+// per-voxel value c + delta_v on the V occupied ones (vfe.hip: vout / delta).  The convolution is linear, so
+//     y[p] = bias + sum_{tap reads inside the grid} W[tap]^T c            (depends on p only through the boundary)
+//                 + sum_{tap reads an occupied cell v} W[tap]^T delta_v
+// and the 70.8 GFLOP dense contraction over 640 000 cells (98.5 % of them empty on a Lyft sweep) becomes
+//   1. k_field_taps     Z[tap][v] = W[tap]^T delta_v for the V voxel rows (+ row V: W[tap]^T c): one 128x64x64 MFMA
+//                       tile per (128 rows, tap), skipped when no row of the tile feeds an output through that tap
+//                       (depth stride 2: half of the (row, tap) pairs) -- ~1 GFLOP at 9 400 voxels;
+//   2. k_field_combine  every output position: the boundary-class constant, plus -- where the 27-cell neighbourhood
+//                       holds a voxel (cell_voxel map, staged per output line in LDS) -- its Z rows in tap order;
+//                       writes y once (82 MB, HBM-bound) and feeds the BatchNormalization sums to a lisec_bn_sink.
+// Same numbers as the dense kernel up to fp32 summation order, every sum in a fixed order (deterministic).  The dense
+// grid is never formed: with the sparse backward of sparse_grid.hip neither direction of the training step needs it.
+#include "conv.h"
+
+#include <cstdlib>
+
+namespace lisec {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int FM = 128, FLDA = 68, FC = 64;          // rows per tile, padded LDS row, channels (in == out == 64)
+constexpr int kFieldThreads = 256;
+
+// does input coordinate x feed an output through kernel index k?  (o*stride - pad + k == x for some 0 <= o < n_out)
+__device__ __forceinline__ bool feeds(int x, int k, int ls, int pad, int n_out) {
+    const int t = x + pad - k;
+    return t >= 0 && (t & ((1 << ls) - 1)) == 0 && (t >> ls) < n_out;
+}
+
+__global__ void __launch_bounds__(kFieldThreads)
+k_field_taps(ConvGeom g, const float* __restrict__ vout, const float* __restrict__ delta,
+             const int* __restrict__ info, const int* __restrict__ coords, int cap,
+             const float* __restrict__ wp, float* __restrict__ Z, long long zstride) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ int any_valid;
+    float* sA = smem;
+    float* sB = smem + FM * FLDA;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int V = info[LISEC_VI_NVOX];
+    if (V > cap) V = cap;
+    const int m0 = blockIdx.x * FM;
+    if (m0 > V) return;                                   // rows 0 .. V exist (row V = the empty-cell constant)
+    const int tap = blockIdx.y;
+    const int kw = tap % g.KW, kh = (tap / g.KW) % g.KH, kd = tap / (g.KW * g.KH);
+    if (tid == 0) any_valid = 0;
+    __syncthreads();
+    if (tid < FM) {
+        const int m = m0 + tid;
+        bool ok = m == V;                                 // the constant is needed for every tap
+        if (m < V)
+            ok = feeds(coords[3 * m], kd, g.ls_d, g.pd, g.Do) && feeds(coords[3 * m + 1], kh, g.ls_h, g.ph, g.Ho) &&
+                 feeds(coords[3 * m + 2], kw, g.ls_w, g.pw, g.Wo);
+        if (ok) any_valid = 1;
+    }
+    __syncthreads();
+    if (!any_valid) return;                               // (voxels are sorted by cell: a tile mostly shares its depth)
+
+    const int piece = tid & 15;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        const int r = p * 16 + (tid >> 4), m = m0 + r;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (m <= V) v = *reinterpret_cast<const float4*>((m < V ? delta + (size_t)m * FC : vout + (size_t)V * FC) + piece * 4);
+        *reinterpret_cast<float4*>(sA + r * FLDA + piece * 4) = v;
+    }
+    const float* wt = wp + (size_t)tap * FC * FC;         // packed [k/4][n][4] slab of this tap
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        *reinterpret_cast<float4*>(sB + (i * 256 + tid) * 4) = *reinterpret_cast<const float4*>(wt + (i * 256 + tid) * 4);
+    __syncthreads();
+
+    f32x16 acc0 = {0}, acc1 = {0};
+    const float* aRow = sA + (wave * 32 + (lane & 31)) * FLDA + 4 * (lane >> 5);
+    const float* bCol = sB + ((lane >> 5) * FC + (lane & 31)) * 4;
+#pragma unroll
+    for (int kc = 0; kc < FC / 8; ++kc) {
+        const float4 a = *reinterpret_cast<const float4*>(aRow + kc * 8);
+        const float4 b0 = *reinterpret_cast<const float4*>(bCol + kc * 2 * FC * 4);
+        const float4 b1 = *reinterpret_cast<const float4*>(bCol + kc * 2 * FC * 4 + 32 * 4);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1.x, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b0.y, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1.y, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b0.z, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b1.z, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b0.w, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b1.w, acc1, 0, 0, 0);
+    }
+    float* zt = Z + (size_t)tap * zstride;
+    const int col = lane & 31;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (m <= V) {
+            zt[(size_t)m * FC + col] = acc0[r];
+            zt[(size_t)m * FC + 32 + col] = acc1[r];
+        }
+    }
+}
+
+// One workgroup per segment of an output line (d', h'); 16 lanes x float4 per output position.
+__global__ void __launch_bounds__(kFieldThreads)
+k_field_combine(ConvGeom g, const int* __restrict__ cell_voxel, const int* __restrict__ info, int cap,
+                const float* __restrict__ Z, long long zstride, const float* __restrict__ bias,
+                float* __restrict__ out, int nseg, int seg_len, int LW) {
+    extern __shared__ __attribute__((aligned(16))) int dyn[];
+    __shared__ __attribute__((aligned(16))) float sT[3][FC];      // per kw: sum over the line's valid (kd, kh) of W[tap]^T c
+    __shared__ __attribute__((aligned(16))) float sbase[8][FC];   // per kw-validity mask: bias + those sums
+    __shared__ __attribute__((aligned(16))) float red[2][16][FC];
+    int* sidx = dyn;                                              // [KD*KH][LW] voxel ordinal of the staged cells (-1: none)
+    unsigned* smask = reinterpret_cast<unsigned*>(dyn + g.KD * g.KH * LW);   // [seg_len] taps that read an occupied cell
+    const int tid = threadIdx.x;
+    const int line = blockIdx.x / nseg, seg = blockIdx.x - line * nseg;
+    const int dq = line / g.Ho, hq = line - dq * g.Ho;
+    const int w0 = seg * seg_len;
+    const int wn = g.Wo - w0 < seg_len ? g.Wo - w0 : seg_len;
+    int V = info[LISEC_VI_NVOX];
+    if (V > cap) V = cap;
+    const int nkk = g.KD * g.KH;
+    unsigned jvalid = 0;
+    for (int j = 0; j < nkk; ++j) {
+        const int kd = j / g.KH, kh = j - kd * g.KH;
+        const int di = (dq << g.ls_d) - g.pd + kd, hi = (hq << g.ls_h) - g.ph + kh;
+        if (di >= 0 && di < g.Di && hi >= 0 && hi < g.Hi) jvalid |= 1u << j;
+    }
+    // ---- stage the voxel ordinals of the input lines this segment reads ---------------------------------------
+    const int span = (wn - 1) * (1 << g.ls_w) + g.KW;
+    const int wi0 = (w0 << g.ls_w) - g.pw;
+    for (int j = 0; j < nkk; ++j) {
+        const int kd = j / g.KH, kh = j - kd * g.KH;
+        const int di = (dq << g.ls_d) - g.pd + kd, hi = (hq << g.ls_h) - g.ph + kh;
+        const bool jv = (jvalid >> j) & 1;
+        const int* src = cell_voxel + ((size_t)(jv ? di : 0) * g.Hi + (jv ? hi : 0)) * g.Wi;
+        for (int e = tid; e < span; e += kFieldThreads) {
+            const int wi = wi0 + e;
+            int v = -1;
+            if (jv && wi >= 0 && wi < g.Wi) v = src[wi];
+            sidx[j * LW + e] = v < V ? v : -1;
+        }
+    }
+    // ---- the constant part: per kw, summed over the valid (kd, kh) in index order -----------------------------
+    if (tid < g.KW * FC) {
+        const int kw = tid / FC, n = tid - kw * FC;
+        float s = 0.f;
+        for (int j = 0; j < nkk; ++j)
+            if ((jvalid >> j) & 1) s += Z[(size_t)(j * g.KW + kw) * zstride + (size_t)V * FC + n];
+        sT[kw][n] = s;
+    }
+    __syncthreads();
+    for (int i = tid; i < 8 * FC; i += kFieldThreads) {
+        const int m = i / FC, n = i - m * FC;
+        float b = bias ? bias[n] : 0.f;
+        for (int kw = 0; kw < g.KW; ++kw)
+            if ((m >> kw) & 1) b += sT[kw][n];
+        sbase[m][n] = b;
+    }
+    for (int p = tid; p < wn; p += kFieldThreads) {
+        unsigned m = 0;
+        for (int j = 0; j < nkk; ++j)
+            for (int kw = 0; kw < g.KW; ++kw)
+                if (sidx[j * LW + (p << g.ls_w) + kw] >= 0) m |= 1u << (j * g.KW + kw);
+        smask[p] = m;
+    }
+    __syncthreads();
+    // ---- every output position of the segment ----------------------------------------------------------------
+    const int q = tid & 15, pr = tid >> 4;
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+    float* oline = out + (size_t)line * g.Wo * g.out_stride;
+    for (int p = pr; p < wn; p += 16) {
+        const int w = w0 + p;
+        const int bw = (w << g.ls_w) - g.pw;
+        int wm = 0;
+        for (int kw = 0; kw < g.KW; ++kw) wm |= (bw + kw >= 0 && bw + kw < g.Wi) ? (1 << kw) : 0;
+        float4 val = *reinterpret_cast<const float4*>(&sbase[wm][q * 4]);
+        unsigned m = smask[p];
+        while (m) {
+            const int t = __ffs(m) - 1;
+            m &= m - 1;
+            const int j = t / g.KW, kw = t - j * g.KW;
+            const int v = sidx[j * LW + (p << g.ls_w) + kw];
+            const float4 z = *reinterpret_cast<const float4*>(Z + (size_t)t * zstride + (size_t)v * FC + q * 4);
+            val.x += z.x; val.y += z.y; val.z += z.z; val.w += z.w;
+        }
+        *reinterpret_cast<float4*>(oline + (size_t)w * g.out_stride + q * 4) = val;
+        s1.x += val.x; s1.y += val.y; s1.z += val.z; s1.w += val.w;
+        s2.x = fmaf(val.x, val.x, s2.x); s2.y = fmaf(val.y, val.y, s2.y);
+        s2.z = fmaf(val.z, val.z, s2.z); s2.w = fmaf(val.w, val.w, s2.w);
+    }
+    if (!g.sink.acc) return;
+    *reinterpret_cast<float4*>(&red[0][pr][q * 4]) = s1;
+    *reinterpret_cast<float4*>(&red[1][pr][q * 4]) = s2;
+    __syncthreads();
+    if (tid < 2 * FC) {
+        const int which = tid >> 6, n = tid & 63;
+        double v = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v += (double)red[which][k][n];
+        sink_add(g.sink, which, n, v);
+    }
+    sink_finish(g.sink);
+}
+
+}  // namespace
+}  // namespace lisec
+
+using namespace lisec;
+
+extern "C" size_t lisec_conv_field_forward_workspace_bytes(const lisec_conv_geom* c, int row_capacity) {
+    if (!c || row_capacity < 0) return 0;
+    return align_up(sizeof(float) * (size_t)c->KD * c->KH * c->KW * ((size_t)row_capacity + 1) * FC, 256);
+}
+
+extern "C" int lisec_conv_field_forward(const lisec_conv_geom* c, const float* vout, const float* delta,
+                                        const int32_t* info, const int32_t* coords, const int32_t* cell_voxel,
+                                        int row_capacity, const float* packed_w, const float* bias, float* out,
+                                        const lisec_bn_sink* sk, void* workspace, size_t workspace_bytes,
+                                        lisec_stream_t stream_) {
+    ConvGeom g;
+    if (int rc = conv_geom_check(c, &g)) return rc;
+    LISEC_CHECK_ARG(c->mode == 0 && !c->ps && g.Cin == FC && g.Cout == FC && g.CoutP == FC && g.in_stride == FC,
+                    "field conv: a mode-0 contraction with 64 input and 64 output channels");
+    LISEC_CHECK_ARG(g.KD <= 3 && g.KH <= 3 && g.KW <= 3, "field conv: at most 3 taps per axis");
+    LISEC_CHECK_ARG(vout && delta && info && coords && cell_voxel && packed_w && out && workspace && row_capacity >= 0,
+                    "field conv: NULL pointer");
+    LISEC_CHECK_ARG((((uintptr_t)vout | (uintptr_t)delta | (uintptr_t)packed_w | (uintptr_t)out | (uintptr_t)workspace) & 15) == 0 &&
+                    g.out_stride % 4 == 0, "field conv: 16-byte aligned tensors");
+    if (workspace_bytes < lisec_conv_field_forward_workspace_bytes(c, row_capacity)) {
+        set_error("field conv workspace too small");
+        return LISEC_ENOSPC;
+    }
+    if (sk) {
+        LISEC_CHECK_ARG(sk->acc && sk->n_rows > 0 && sk->kind == LISEC_SINK_FORWARD && sk->gamma && sk->beta && sk->bnstate &&
+                        (sk->moving_mean == nullptr) == (sk->moving_var == nullptr),
+                        "field conv: a forward bn sink needs accumulators, gamma/beta/bnstate");
+    }
+    static const int seg_target = [] {
+        const char* e = std::getenv("LISEC_FIELD_SEG");
+        const int v = e ? std::atoi(e) : 0;
+        return v >= 16 && v <= 1024 ? v : 128;
+    }();
+    const int nseg = cdiv(g.Wo, seg_target), seg_len = cdiv(g.Wo, nseg);
+    const int LW = (seg_len - 1) * (1 << g.ls_w) + g.KW;
+    const int nblocks = g.Do * g.Ho * nseg;
+    if (sk) {
+        g.sink.acc = static_cast<long long*>(sk->acc);
+        g.sink.kind = sk->kind; g.sink.C = g.Cout; g.sink.unbiased = sk->unbiased_moving;
+        g.sink.total = (unsigned)nblocks;
+        g.sink.N = sk->n_rows;
+        g.sink.gamma = sk->gamma; g.sink.beta = sk->beta; g.sink.mmean = sk->moving_mean; g.sink.mvar = sk->moving_var;
+        g.sink.bnstate = sk->bnstate; g.sink.dgamma = nullptr; g.sink.dbeta = nullptr; g.sink.coef = nullptr;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream_);
+    float* Z = static_cast<float*>(workspace);
+    const long long zstride = ((long long)row_capacity + 1) * FC;
+    const int ntaps = g.KD * g.KH * g.KW;
+    hipLaunchKernelGGL(k_field_taps, dim3(cdiv((long long)row_capacity + 1, FM), ntaps), dim3(kFieldThreads),
+                       (size_t)(FM * FLDA + FC * FC) * sizeof(float), st, g, vout, delta, info, coords, row_capacity,
+                       packed_w, Z, zstride);
+    const size_t dyn = sizeof(int) * ((size_t)g.KD * g.KH * LW + seg_len);
+    hipLaunchKernelGGL(k_field_combine, dim3(nblocks), dim3(kFieldThreads), dyn, st, g, cell_voxel, info,
+                       row_capacity, (const float*)Z, zstride, bias, out, nseg, seg_len, LW);
+    LISEC_LAUNCH_CHECK();
+    return LISEC_OK;
+}

@@ -446,12 +446,14 @@ k_vfe_grid(const int* __restrict__ info, const int* __restrict__ cell_voxel, int
                            pool_from(mx.z, mn.z, sc.z, sh.z), pool_from(mx.w, mn.w, sc.w, sh.w));
     };
     const float4 c = has_empty ? value(V) : make_float4(0.f, 0.f, 0.f, 0.f);
-    const long long total = (long long)ncells * 16;
     const long long nv = vout ? (long long)(V + 1) * 16 : 0;
+    // grid == nullptr: the compact per-voxel outputs only (what the field form of the first Conv3D reads)
+    const long long total = grid ? (long long)ncells * 16 : (nv < (long long)ncells * 16 ? nv : (long long)ncells * 16);
     for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int cell = (int)(i >> 4);
-        const int v = cell_voxel[cell];
-        reinterpret_cast<float4*>(grid)[i] = v < 0 ? c : value(v);
+        if (grid) {
+            const int v = cell_voxel[(int)(i >> 4)];
+            reinterpret_cast<float4*>(grid)[i] = v < 0 ? c : value(v);
+        }
         if (i < nv) {
             const int u = (int)(i >> 4);
             const float4 o = u < V ? value(u) : c;
@@ -503,8 +505,7 @@ extern "C" int lisec_vfe_forward(const lisec_vfe_params* p, const int32_t* info,
                                  const int32_t* row_start, const float* rows, int64_t* row_stats_, int n_points,
                                  int ncells, int T, int cap_voxels, int training, float* saved, void* workspace,
                                  size_t workspace_bytes, float* grid, lisec_stream_t stream_) {
-    LISEC_CHECK_ARG(p && info && cell_voxel && npts && row_start && rows && saved && workspace && grid,
-                    "NULL pointer");
+    LISEC_CHECK_ARG(p && info && cell_voxel && npts && row_start && rows && saved && workspace, "NULL pointer");
     LISEC_CHECK_ARG(ncells > 0 && T >= 1 && T <= 64 && cap_voxels >= 0 && n_points >= 0, "bad sizes");
     for (int i = 0; i < 3; ++i)
         LISEC_CHECK_ARG(p->kernel[i] && p->gamma[i] && p->beta[i] && p->moving_mean[i] && p->moving_var[i],

@@ -55,7 +55,15 @@ class LisecNet:
             self.act[name] = torch.empty(shape, dtype=f32, device=dev)
             return self.act[name]
 
-        buf("grid", D, H, W, 64)
+        # the dense VFE output: only the dense form of the first Conv3D reads it (allocated on first use, 164 MB)
+        self.grid_shape = (D, H, W, 64)
+        # field form of the first Conv3D (csrc/field_conv.hip): sweeps with a voxel capacity (= min(points, cells)) up to
+        # this never form the grid -- beyond ~40 % occupancy the dense contraction is the cheaper one;
+        # LISEC_FIELD_CONV=0 keeps the dense contraction for every sweep
+        self.field_conv = os.environ.get("LISEC_FIELD_CONV", "1") == "1"
+        self.field_max_voxels = int(os.environ.get("LISEC_FIELD_MAX_VOXELS", "262144"))
+        self.field_ws = None
+        self._used_field = False
         # ---- middle layers (model_training.py:236-238) ----------------------------------------
         d_in, prev = D, "grid"
         for i, (stride, pad) in enumerate(MID):
@@ -205,6 +213,15 @@ class LisecNet:
         if c.bn:
             self._bn_after(c, training)
 
+    def dense_grid(self, rewrite=True):
+        """The dense (D,H,W,64) VFE output; rewrite: fill it from the last forward's per-voxel values (the field form
+        of the first Conv3D never writes it)."""
+        if "grid" not in self.act:
+            self.act["grid"] = torch.empty(self.grid_shape, dtype=torch.float32, device=self.device)
+        if rewrite:
+            self.vfe.rewrite_grid(self.act["grid"])
+        return self.act["grid"]
+
     def forward(self, sample, training=False):
         """sample: VoxelSample of one lidar sweep.  Returns (cls (1,Ho,Wo,2), reg (1,Ho,Wo,14)) device views."""
         if sample.grid_shape != (self.D, self.H, self.W) or sample.cfg.sampleSize != self.T:
@@ -223,7 +240,15 @@ class LisecNet:
         if not pending:
             self._pack_all()
         a = self.act
-        self.vfe.forward(sample, training, out=a["grid"])
+        use_field = self._used_field = self.field_conv and sample.cap <= self.field_max_voxels
+        if use_field:
+            first = self.layers[0]["conv"]
+            need = ops.conv_field_forward_workspace_bytes(first.g, sample.cap)
+            if self.field_ws is None or self.field_ws.numel() < need:
+                self.field_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            self.vfe.forward(sample, training, dense=False)
+        else:
+            self.vfe.forward(sample, training, out=self.dense_grid(rewrite=False))
         if pending:
             # the repack of this step's weights was enqueued on the second stream right after the last optimizer step
             # and ran under this sweep's voxeliser and VFE; the first contraction is the first reader
@@ -232,7 +257,14 @@ class LisecNet:
         for L in self.layers:
             if L["kind"] == "mid":
                 n = L["name"]
-                self._run_conv(L["conv"], a[L["src"]], a[n + ".y"], training)
+                if L["src"] == "grid" and use_field:
+                    c = L["conv"]
+                    ops.conv_field_forward(c.g, self.vfe.saved_field("vout"), self.vfe.saved_field("delta"), sample,
+                                           self.packed[c.name], a[n + ".y"], self.field_ws, bias=self.params.view(c.bias),
+                                           sink=self._fwd_sink(c) if training else None)
+                    self._bn_after(c, training)
+                else:
+                    self._run_conv(L["conv"], a[L["src"]], a[n + ".y"], training)
                 self._run_conv(L["dense"], a[n + ".y"], a[n + ".u"], training)
             elif L["kind"] == "conv":
                 if L["src"] == "fold":

@@ -254,6 +254,20 @@ def scale_(x, s):
     _lib.check(_lib.load().lisec_scale(_lib.ptr(x), x.numel(), s, _lib.current_stream()))
 
 
+def conv_field_forward_workspace_bytes(g, row_capacity):
+    return _lib.load().lisec_conv_field_forward_workspace_bytes(ctypes.byref(g), row_capacity)
+
+
+def conv_field_forward(g, vout, delta, sample, wp, out, workspace, bias=None, sink=None):
+    """First Conv3D over the VFE's compact output (constant + voxel rows) instead of the dense grid; sample: the
+    VoxelSample the VFE ran on; workspace: uint8 tensor of conv_field_forward_workspace_bytes(g, sample.cap)."""
+    _lib.check(_lib.load().lisec_conv_field_forward(
+        ctypes.byref(g), _lib.ptr(vout), _lib.ptr(delta), _lib.ptr(sample.info), _lib.ptr(sample.coords),
+        _lib.ptr(sample.cell_voxel), sample.cap, _lib.ptr(wp), _lib.ptr(bias), _lib.ptr(out),
+        sink.ref if sink is not None else None, _lib.ptr(workspace), workspace.numel(), _lib.current_stream()))
+    return out
+
+
 def tap_sums(g, dy, S, workspace):
     _lib.check(_lib.load().lisec_conv_tap_sums(ctypes.byref(g), _lib.ptr(dy), _lib.ptr(S), _lib.ptr(workspace),
                                                workspace.numel() * workspace.element_size(), _lib.current_stream()))

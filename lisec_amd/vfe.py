@@ -37,8 +37,9 @@ class VFEStack:
             s.moving_var[i] = p.ptr(f"{n}.bn.moving_variance").value
         return s
 
-    def forward(self, sample, training, out=None):
-        """sample: VoxelSample.  Returns the dense (D, H, W, 64) grid (device tensor)."""
+    def forward(self, sample, training, out=None, dense=True):
+        """sample: VoxelSample.  Returns the dense (D, H, W, 64) grid (device tensor); dense=False: no grid, only the
+        compact per-voxel outputs (saved_field('vout') / ('delta')) that the field form of the first Conv3D reads."""
         D, H, W = sample.grid_shape
         ncells = D * H * W
         # training with the tiled backward: `saved` also carries the per-row extras (winner slots, layer-2 rows).  The
@@ -50,7 +51,9 @@ class VFEStack:
         if self._saved is None or self._saved.numel() < need:
             self._saved = torch.empty(need, dtype=torch.float32, device=self.device)
         self._saved_rows = rows_cap
-        grid = out if out is not None else torch.empty((D, H, W, 64), dtype=torch.float32, device=self.device)
+        grid = None
+        if dense:
+            grid = out if out is not None else torch.empty((D, H, W, 64), dtype=torch.float32, device=self.device)
         cp = self._cparams()
         _lib.check(self.lib.lisec_vfe_forward(
             ctypes.byref(cp), _lib.ptr(sample.info), _lib.ptr(sample.cell_voxel), _lib.ptr(sample.npts),
