@@ -32,6 +32,9 @@ import torch  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_HBM_GBS = 8000.0            # HBM3E spec (6.3 TB/s achievable per the same guide)
+# PMC passes of the dominant kernel's launch (profiles/r02_pmc_and_experiments.txt); None until collected
+MID2_DGRAD_TRAFFIC_BYTES = None
+MID2_DGRAD_CLOCK_GHZ = None
 
 
 def u20k_cloud(seed, n=20000):
@@ -315,33 +318,51 @@ def main():
     result = None
     if rank == 0:
         # ---- roofline of the dominant kernel, timed live on the launch stream ----------------------
-        mid1 = next(L for L in net.layers if L["name"] == "mid1")
-        c = mid1["conv"]
+        # Since the first Conv3D runs over the VFE's compact output (csrc/field_conv.hip, ~1 GFLOP), the largest launches
+        # of the step are the second middle block's: its data gradient is the longest one on the main chain.
+        mid2 = next(L for L in net.layers if L["name"] == "mid2")
+        c2, dg2 = mid2["conv"], net.dgeom[mid2["conv"].name]
+        dz2, du1 = net.dact["mid2.z"], net.dact["mid1.u"]
 
-        grid = net.dense_grid()
-
-        def run_mid1():
-            # TAG_ROOFLINE: one un-sliced launch under its own symbol (k_igemm<0,false,1>), so the row of that
+        def run_mid2_dgrad():
+            # TAG_ROOFLINE: one un-sliced launch under its own symbol (k_igemm_halo<1,false,1,2>), so the row of that
             # symbol in the rocprofv3 --stats summary of this command is this layer alone
-            ops.conv_forward(c.g, grid, net.packed[c.name], net.act["mid1.y"],
-                             bias=net.params.view(c.bias), stats=net.parts, flags=ops.TAG_ROOFLINE)
-        ms = event_time_ms(run_mid1, 20)
-        # algorithmic FLOPs: 2 * positions * 27 taps * 64 * 64; depth-padding taps included
-        flops = 2.0 * c.M * 27 * 64 * 64
+            ops.conv_forward(dg2, dz2, net.packed_t[c2.name][0], du1, flags=ops.TAG_ROOFLINE)
+        ms = event_time_ms(run_mid2_dgrad, 20)
+        # algorithmic FLOPs: 2 * output positions of the layer * 27 taps * 64 * 64 -- every (position, tap)
+        # pair of the forward contraction is one pair of its transpose; the kernel runs exactly those (depth taps that
+        # fall outside are skipped per tile), so executed == algorithmic here
+        flops = 2.0 * c2.M * 27 * 64 * 64
         tf = flops / (ms * 1e-3) / 1e12
-        # traffic: HBM bytes per launch from rocprofv3 PMC passes of this very launch (profiles/r02_pmc_and_experiments.txt):
-        # FETCH_SIZE 125 952 KiB (x2, the gfx950 correction for wide coalesced reads) + WRITE_SIZE 82 500 KiB
-        # frac_executed: the kernel skips the taps that only read depth padding (kd = 0 of the first of the four output
-        # planes: 9 of 108 plane-taps), so the MFMA pipes execute 11/12 of the algorithmic FLOPs (PMC: 15.79 M of 17.28 M
-        # MFMA instructions, profiles/r02_pmc_and_experiments.txt); clock_ghz: GRBM_GUI_ACTIVE / 8 / duration of this kernel in
-        # the same PMC passes (2.42 GHz on the real, 98 %-constant grid; 2.05-2.11 GHz on random data, where it takes 665 us)
-        executed = sum(sum(1 for kd in range(3) if 0 <= 2 * d - 1 + kd < net.D) for d in range(c.g.Do)) / (3.0 * c.g.Do)
-        roofline = dict(bound="mfma", kernel="k_igemm_halo<0,false,1,2> mid1 Conv3D 64->64 k3 s(2,1,1)", achieved=tf,
+        roofline = dict(bound="mfma", kernel="k_igemm_halo<1,false,1,2> mid2 Conv3D 64->64 k3 s1 data gradient", achieved=tf,
                         peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s", frac=tf / PEAK_F32_MFMA_TFLOPS,
-                        frac_executed=tf * executed / PEAK_F32_MFMA_TFLOPS, executed_share=executed,
-                        clock_ghz=2.42, clock_note="GRBM_GUI_ACTIVE/8/duration, PMC offline (real grid; 2.05-2.11 on random data)",
-                        traffic=(2 * 125952.0 + 82500.0) * 1024, traffic_unit="bytes/launch (PMC, offline)",
+                        frac_executed=tf / PEAK_F32_MFMA_TFLOPS, executed_share=1.0,
+                        clock_ghz=MID2_DGRAD_CLOCK_GHZ, clock_note="GRBM_GUI_ACTIVE/8/duration, PMC offline (gradient data)",
+                        traffic=MID2_DGRAD_TRAFFIC_BYTES, traffic_unit="bytes/launch (PMC, offline)",
                         us_per_launch=ms * 1e3, flops_per_launch=flops)
+        # the other large contractions, same clock: mid2 forward, and the dense form of the first Conv3D (the dominant
+        # kernel of rounds 1-2; sweeps beyond LISEC_FIELD_MAX_VOXELS still take it)
+        grid = net.dense_grid()
+        mid1 = next(L for L in net.layers if L["name"] == "mid1")
+        c1 = mid1["conv"]
+        ms_f2 = event_time_ms(lambda: ops.conv_forward(c2.g, net.act["mid1.u"], net.packed[c2.name], net.act["mid2.y"],
+                                                       bias=net.params.view(c2.bias), stats=net.parts), 20)
+        ms_f1 = event_time_ms(lambda: ops.conv_forward(c1.g, grid, net.packed[c1.name], net.act["mid1.y"],
+                                                       bias=net.params.view(c1.bias), stats=net.parts), 10)
+        vout, delta = net.vfe.saved_field("vout"), net.vfe.saved_field("delta")
+        ms_field = event_time_ms(lambda: ops.conv_field_forward(c1.g, vout, delta, net.vfe._sample, net.packed[c1.name],
+                                                                net.act["mid1.y"], net.field_ws,
+                                                                bias=net.params.view(c1.bias)), 20)
+        f1 = 2.0 * c1.M * 27 * 64 * 64
+        roofline["others"] = {
+            "mid2_forward": dict(us_per_launch=ms_f2 * 1e3, achieved=flops / (ms_f2 * 1e-3) / 1e12,
+                                 frac=flops / (ms_f2 * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, flops_per_launch=flops),
+            "mid1_dense_form": dict(us_per_launch=ms_f1 * 1e3, achieved=f1 / (ms_f1 * 1e-3) / 1e12,
+                                    frac=f1 / (ms_f1 * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, flops_per_launch=f1),
+            "mid1_field_form": dict(us_per_call=ms_field * 1e3, launches=2,
+                                    note="what the step runs: k_field_taps + k_field_combine over the VFE's compact output, "
+                                         "same values as mid1_dense_form"),
+        }
         sample = vox(pts)
 
         def run_vfe():
@@ -349,18 +370,24 @@ def main():
         ms_v = event_time_ms(run_vfe, 20)
         hi = sample.host_info()
         vfe_bytes = 12.0 * len(cloud) + 24.0 * hi["rows"] + 4.0 * 64 * net.D * net.H * net.W
+        ms_vc = event_time_ms(lambda: net.vfe.forward(sample, True, dense=False), 20)
+        vfe_compact_bytes = 12.0 * len(cloud) + 24.0 * hi["rows"] + 2.0 * 256 * (hi["V"] + 1)
         ms_g = event_time_ms(lambda: net.vfe.rewrite_grid(grid), 50)
         grid_bytes = 4.0 * 64 * net.D * net.H * net.W
         gbs = grid_bytes / (ms_g * 1e-3) / 1e9
         # traffic from PMC: WRITE_SIZE 160 000 KiB (= the algorithmic bytes) + FETCH_SIZE 4 875 KiB x2
-        roofline_vfe = dict(bound="hbm", kernel="k_vfe_grid (dense (8,200,400,64) VFE output writer)", achieved=gbs,
+        roofline_vfe = dict(bound="hbm", kernel="k_vfe_grid (dense (8,200,400,64) VFE output writer; lisec_vfe_forward with a grid)", achieved=gbs,
                             peak=PEAK_HBM_GBS, unit="GB/s", frac=gbs / PEAK_HBM_GBS,
                             traffic=(160000.0 + 2 * 4875.125) * 1024, traffic_unit="bytes/launch (PMC, offline)",
                             us_per_launch=ms_g * 1e3, bytes_per_launch=grid_bytes,
                             whole_vfe_forward=dict(us_per_call=ms_v * 1e3, bytes_per_call=vfe_bytes,
                                                    achieved=vfe_bytes / (ms_v * 1e-3) / 1e9,
                                                    frac=vfe_bytes / (ms_v * 1e-3) / 1e9 / PEAK_HBM_GBS,
-                                                   launches=3))
+                                                   launches=3),
+                            in_step=dict(us_per_call=ms_vc * 1e3, bytes_per_call=vfe_compact_bytes, launches=3,
+                                         note="what the training step runs: the same three launches without the dense "
+                                              "grid (per-voxel outputs only, read by the field form of the first Conv3D); "
+                                              "latency-bound, not an HBM roofline case"))
         voxelizer = voxelizer_leg(vox, dev, args.no_cpu_baseline)
         r200k = None
         if args.cloud == "u20k" and world == 1 and not use_graph:

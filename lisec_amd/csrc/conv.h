@@ -37,6 +37,10 @@ struct ConvGeom {
     // up to whole tiles, M = 4 * pc_span.  Every tile then has ONE parity, i.e. one set of taps that divide.
     int pc_span, pc_rows;
     int pointwise;           // 1x1x1 taps, unit strides, no padding, dense rows: row m reads position m
+    // plane_pair: a workgroup of k_igemm_halo runs the tiles of one (h, w) place of depth planes 2q and 2q + 1 (planes are
+    // whole numbers of tiles, plane_tiles each; the grid has half as many workgroups) -- equal work per workgroup when the
+    // planes of a strided / transposed Conv3D run different numbers of taps
+    int plane_tiles, plane_pair;
     // optional BatchNormalization-backward statistics of the stored gradient (see lisec_conv_extras): the per-tile
     // partials become (sum dz, sum dz*yhat) with dz = stored value * (relu ? bn(y) > 0 : 1), yhat = (y - mean)*invstd
     const float* bwd_y;      // (positions, Cout) raw conv output of the layer the gradient belongs to, row stride Cout

@@ -22,6 +22,10 @@
 #include "conv.h"
 
 #include <cstdlib>
+#include <map>
+#include <mutex>
+#include <utility>
+#include <vector>
 
 namespace lisec {
 namespace {
@@ -34,12 +38,23 @@ constexpr int kThreads = 256;
 constexpr int A_FLOATS = BM * LDA;               // 8704
 constexpr int B_FLOATS = BK * BN;                // 4096
 
+// diagnostic (tools/igemm_stamps.py): 100 MHz s_memrealtime stamps of thread 0 of every workgroup of k_igemm_halo at its
+// phase boundaries; nullptr (the default) = no stamp executes
+__device__ unsigned long long* g_igemm_stamps = nullptr;
+#define IGEMM_STAMP(K_)                                                                                    \
+    do {                                                                                                   \
+        if (stamps && threadIdx.x == 0 && stamp_wg < 8192)                                                 \
+            stamps[(size_t)stamp_wg * 8 + (K_)] = __builtin_amdgcn_s_memrealtime();                        \
+    } while (0)
+
 // Epilogue shared by the igemm kernels: raw K-slice slab, or bias (+accumulate, output gate, ReLU) store with the
 // per-tile BatchNormalization partial sums.  C layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+// mw: first of the 32 rows this wave holds; storer: false for a wave whose accumulators were already folded into another
+// wave's (k_igemm_w) -- it only takes part in the statistics reduction, with zeros.
 __device__ __forceinline__ void store_tile(const ConvGeom& g, const f32x16& acc0, const f32x16& acc1, float* smem,
-                                           int m0, int n0, int mb, int mlimit, int tile0, int wave, int lane, int tid,
+                                           int mw, int n0, int mb, int mlimit, int tile0, int wave, int lane, int tid,
                                            const float* __restrict__ bias, int flags, float* __restrict__ out,
-                                           double* __restrict__ stats, float* __restrict__ partial) {
+                                           double* __restrict__ stats, float* __restrict__ partial, bool storer = true) {
     const int col = lane & 31;
     if (partial) {
         // slabs cover the rows of tiles tile0 .. (the tail of the layer, or all of it)
@@ -47,7 +62,7 @@ __device__ __forceinline__ void store_tile(const ConvGeom& g, const f32x16& acc0
         float* pz = partial + (size_t)blockIdx.z * rows_part * g.CoutP;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const int m = mw + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             if (m < mlimit) {
                 const size_t ml = (size_t)(m - tile0 * BM);
                 pz[ml * g.CoutP + n0 + col] = acc0[r];
@@ -64,7 +79,6 @@ __device__ __forceinline__ void store_tile(const ConvGeom& g, const f32x16& acc0
     // parity-class order: decode the wave's first row once
     int pc_c = 0, pc_q = 0, pc_i = 0, pc_j = 0;
     if (g.pc_span) {
-        const int mw = m0 + wave * 32;
         pc_c = mw / g.pc_span;
         pc_q = mw - pc_c * g.pc_span;
         pc_i = pc_q / (g.Wo >> 1);
@@ -83,8 +97,8 @@ __device__ __forceinline__ void store_tile(const ConvGeom& g, const f32x16& acc0
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        const int m = m0 + wave * 32 + row;
-        bool live_row = m < mlimit;
+        const int m = mw + row;
+        bool live_row = storer && m < mlimit;
         size_t orow = (size_t)m;
         if (g.pc_span && live_row) {
             // parity-class order: q = q0 + row with q0 decoded once per wave (row < 32 <= Wo/2: at most one line wrap)
@@ -253,9 +267,12 @@ k_igemm(ConvGeom g, const float* __restrict__ in, const float* __restrict__ wp,
             ra[p] = *reinterpret_cast<const float4*>(in + off);
             valid_mask |= ok ? (1u << p) : 0u;
         }
-        if (XF && in_bn && cok) {
-            tsc = *reinterpret_cast<const float4*>(in_bn + c);
-            tsh = *reinterpret_cast<const float4*>(in_bn + g.Cin + c);
+        if (XF) {
+            // unconditional (in_bn is never NULL here, see lisec_conv_forward_ex): with these two loads under a branch the
+            // compiler sizes its s_waitcnt for the shorter path and every step waits for its first A loads before the MFMAs
+            const int cs = cok ? c : 0;
+            tsc = *reinterpret_cast<const float4*>(in_bn + cs);
+            tsh = *reinterpret_cast<const float4*>(in_bn + g.Cin + cs);
         }
         const float* wb = wp + ((size_t)(tap * KpQ + cc * (BK / 4)) * g.CoutP + n0) * 4;
         const float* wl = wb + (size_t)(tid >> 6) * g.CoutP * 4 + (tid & 63) * 4;
@@ -341,7 +358,7 @@ k_igemm(ConvGeom g, const float* __restrict__ in, const float* __restrict__ wp,
         s = snext;
     }
 
-    store_tile(g, acc0, acc1, smem, m0, n0, mb, mlimit, tile0, wave, lane, tid, bias, flags, out, stats, partial);
+    store_tile(g, acc0, acc1, smem, m0 + wave * 32, n0, mb, mlimit, tile0, wave, lane, tid, bias, flags, out, stats, partial);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -358,19 +375,18 @@ k_igemm(ConvGeom g, const float* __restrict__ in, const float* __restrict__ wp,
 constexpr int halo_rows(int nseg) { return BM + 2 * nseg; }     // segments + two halo columns each
 constexpr size_t halo_lds_bytes(int nseg) { return (size_t)(halo_rows(nseg) * LDA + B_FLOATS) * sizeof(float); }   // <= 52 832 B: 3 per CU
 
-template <int MODE, bool XF, int TAG = 0, int NSEG = 2>
-__global__ void __launch_bounds__(kThreads)
-k_igemm_halo(ConvGeom g, const float* __restrict__ in, const float* __restrict__ wp,
-             const float* __restrict__ bias, const float* __restrict__ in_bn, int flags,
-             float* __restrict__ out, double* __restrict__ stats, int nsplit, float* __restrict__ partial, int tile0) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+template <int MODE, bool XF, int NSEG>
+__device__ __forceinline__ void
+halo_tile(const ConvGeom& g, const float* __restrict__ in, const float* __restrict__ wp,
+          const float* __restrict__ bias, const float* __restrict__ in_bn, int flags,
+          float* __restrict__ out, double* __restrict__ stats, int nsplit, float* __restrict__ partial, int tile0,
+          int mb, float* smem, unsigned long long* stamps, unsigned stamp_wg) {
     constexpr int HALO_MAX_ROWS = halo_rows(NSEG);
     float* sA = smem;
     float* sB = smem + HALO_MAX_ROWS * LDA;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int mb = tile0 + xcd_remap(blockIdx.x, gridDim.x);
     const int m0 = mb * BM;
     const int n0 = blockIdx.y * BN;
     const int mlimit = g.M;
@@ -456,9 +472,10 @@ k_igemm_halo(ConvGeom g, const float* __restrict__ in, const float* __restrict__
                 ra[p] = *reinterpret_cast<const float4*>(in + off);
                 valid_mask |= ok ? (1u << p) : 0u;
             }
-            if (XF && in_bn && cok) {
-                tsc = *reinterpret_cast<const float4*>(in_bn + c);
-                tsh = *reinterpret_cast<const float4*>(in_bn + g.Cin + c);
+            if (XF) {
+                const int cs = cok ? c : 0;                     // unconditional, see k_igemm
+                tsc = *reinterpret_cast<const float4*>(in_bn + cs);
+                tsh = *reinterpret_cast<const float4*>(in_bn + g.Cin + cs);
             }
         }
         const int tap = (kd * g.KH + kh) * 3 + kw;
@@ -511,12 +528,16 @@ k_igemm_halo(ConvGeom g, const float* __restrict__ in, const float* __restrict__
         return s < s_end ? s : nsteps;
     };
     int s = advance_to(s_begin);
+    IGEMM_STAMP(1);
     if (s < nsteps) {
         issue_loads(s);
         store_lds();
     }
     __syncthreads();
+    IGEMM_STAMP(2);
+    int stamp_steps = 0;
     while (s < nsteps) {
+        ++stamp_steps;
         const int snext = advance_to(s + 1);
         if (snext < nsteps) issue_loads(snext);
         const int kw = s % 3;
@@ -549,7 +570,235 @@ k_igemm_halo(ConvGeom g, const float* __restrict__ in, const float* __restrict__
         __syncthreads();
         s = snext;
     }
-    store_tile(g, acc0, acc1, smem, m0, n0, mb, mlimit, tile0, wave, lane, tid, bias, flags, out, stats, partial);
+    IGEMM_STAMP(3);
+    store_tile(g, acc0, acc1, smem, m0 + wave * 32, n0, mb, mlimit, tile0, wave, lane, tid, bias, flags, out, stats, partial);
+    IGEMM_STAMP(4);
+    if (stamps && threadIdx.x == 0 && stamp_wg < 8192) stamps[(size_t)stamp_wg * 8 + 5] = (unsigned long long)stamp_steps;
+}
+
+// TAG only changes the symbol name (see k_igemm).  With g.plane_pair the workgroup runs TWO tiles: the same (h, w) place of
+// depth planes 2q and 2q + 1.  The planes of a strided or transposed Conv3D run different numbers of taps (the data
+// gradient of the second middle block: 9 / 18 / 18 / 9 of 27 per plane); the hardware hands workgroups to the CUs in a
+// fixed rotation and waits for a slot on the CU whose turn it is, so a launch of mixed 9- and 18-step workgroups left
+// 40 % of the slots empty (tools/igemm_stamps.py).  Paired, every workgroup runs 27 steps.
+template <int MODE, bool XF, int TAG = 0, int NSEG = 2>
+__global__ void __launch_bounds__(kThreads)
+k_igemm_halo(ConvGeom g, const float* __restrict__ in, const float* __restrict__ wp,
+             const float* __restrict__ bias, const float* __restrict__ in_bn, int flags,
+             float* __restrict__ out, double* __restrict__ stats, int nsplit, float* __restrict__ partial, int tile0) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    unsigned long long* stamps = g_igemm_stamps;
+    const unsigned stamp_wg = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    IGEMM_STAMP(0);
+    const int v = tile0 + xcd_remap(blockIdx.x, gridDim.x);
+    if (!g.plane_pair) {
+        halo_tile<MODE, XF, NSEG>(g, in, wp, bias, in_bn, flags, out, stats, nsplit, partial, tile0, v, smem, stamps, stamp_wg);
+        return;
+    }
+    const int q = v / g.plane_tiles, i = v - q * g.plane_tiles;
+    halo_tile<MODE, XF, NSEG>(g, in, wp, bias, in_bn, flags, out, stats, nsplit, partial, tile0,
+                              2 * q * g.plane_tiles + i, smem, stamps, stamp_wg);
+    __syncthreads();                                  // the epilogue's statistics scratch is the next tile's staging area
+    halo_tile<MODE, XF, NSEG>(g, in, wp, bias, in_bn, flags, out, stats, nsplit, partial, tile0,
+                              (2 * q + 1) * g.plane_tiles + i, smem, stamps, stamp_wg);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Wave-independent variant for layers with few output tiles (the RPN: 20 000 / 5 000 / 1 250 positions).  There a
+// 128-row workgroup grid cannot fill 1024 SIMDs, and slicing K over workgroups costs a slab round trip through HBM
+// plus a combine launch per layer (17 forward + 19 backward launches, 0.76 ms of a 5.1 ms step).  Here the K slices
+// live INSIDE the workgroup: wave (rg, ks) owns rows rg*32.. of a 32*RT-row tile and the ks-th of KS contiguous
+// slices of the (tap, channel slab) list, RT * KS = 4.  A wave stages its own 32 x 64 A slab in a private LDS
+// region and reads its W fragments straight from L2 in the packed [k/4][n][4] order (a wave-wide 16-byte load IS the
+// MFMA B fragment), so waves never wait for one another until the end, where the slices are summed through LDS in
+// slice order (deterministic) and wave (rg, 0) runs the usual epilogue.  No global partials, no combine launch.
+template <int MODE, bool XF, int KS>
+__global__ void __launch_bounds__(kThreads)
+k_igemm_w(ConvGeom g, const float* __restrict__ in, const float* __restrict__ wp,
+          const float* __restrict__ bias, const float* __restrict__ in_bn, int flags,
+          float* __restrict__ out, double* __restrict__ stats) {
+    constexpr int RT = 4 / KS;                   // 32-row groups per workgroup
+    constexpr int BMW = 32 * RT;                 // rows per workgroup
+    constexpr int WA = 32 * LDA;                 // floats of one wave's A slab
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rg = wave % RT, ks = wave / RT;
+    float* sA = smem + wave * WA;
+    const int mb = xcd_remap(blockIdx.x, gridDim.x);
+    const int mw = mb * BMW + rg * 32;
+    const int n0 = blockIdx.y * BN;
+    const int mlimit = row_limit(g);
+    if (mb * BMW >= mlimit) return;              // (whole workgroup)
+    const int HW = g.Ho * g.Wo;
+
+    // ---- gather descriptors: lane r < 32 owns row mw + r; the 16 lanes that stage a row fetch it by shuffle --------
+    const int piece = lane & 15;
+    RowGather rows[8];
+    int tile_mask = 0;
+    {
+        const RowGather me = row_gather(g, mw + (lane & 31), MODE, 0);
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const int src = p * 4 + (lane >> 4);
+            rows[p].off = __shfl(me.off, src, 64) + piece * 4;
+            rows[p].mask = __shfl(me.mask, src, 64);
+        }
+        if (g.row_coords) {
+            int m = me.mask;
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) m |= __shfl_xor(m, o, 64);
+            tile_mask = m;
+        }
+    }
+    const int mlast = (mw + 31 < g.M ? mw + 31 : g.M - 1);
+    const int d_first = g.pc_span ? 0 : mw / HW, d_last = g.pc_span ? 0 : mlast / HW;
+    int dmask_first;
+    {
+        int tmp;
+        dmask_first = axis_mask(d_first, g.KD, g.ls_d, g.pd, g.Di, MODE, tmp);
+    }
+    const int ncc = (g.Cin + BK - 1) / BK;
+    const int ntaps = g.KD * g.KH * g.KW;
+    const int nsteps = ntaps * ncc;
+    const int KpQ = ncc * (BK / 4);
+    const int pclass = g.pc_span ? mw / g.pc_span : 0;
+    auto live = [&](int s) -> bool {
+        if (g.pc_span) {
+            const int tap = s / ncc, kw = tap % g.KW, kh = (tap / g.KW) % g.KH;
+            return (((pclass >> 1) + g.ph - kh) & 1) == 0 && (((pclass & 1) + g.pw - kw) & 1) == 0;
+        }
+        if (g.row_coords) {
+            const int tap = s / ncc, kw = tap % g.KW, kh = (tap / g.KW) % g.KH, kd = tap / (g.KW * g.KH);
+            const int tb = tap_bits(kd, kh, kw);
+            return (tile_mask & tb) == tb;
+        }
+        if (d_first != d_last) return true;
+        const int kd = (s / ncc) / (g.KH * g.KW);
+        return (dmask_first >> kd) & 1;
+    };
+
+    float4 ra[8];
+    float4 b0[BK / 8], b1[BK / 8];
+    float4 tsc = make_float4(1, 1, 1, 1), tsh = make_float4(0, 0, 0, 0);
+    unsigned valid_mask = 0;
+    auto load_a = [&](int s) {
+        const int tap = s / ncc, cc = s - tap * ncc;
+        const int kw = tap % g.KW, kh = (tap / g.KW) % g.KH, kd = tap / (g.KW * g.KH);
+        const int c = cc * BK + piece * 4;
+        const bool cok = c < g.Cin;
+        const int soff = tap_delta(g, kd, kh, kw, MODE) + cc * BK;
+        const int tbits = cok ? tap_bits(kd, kh, kw) : 0x7fffffff;
+        valid_mask = 0;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const bool ok = (rows[p].mask & tbits) == tbits;
+            const int off = ok ? rows[p].off + soff : 0;
+            ra[p] = *reinterpret_cast<const float4*>(in + off);
+            valid_mask |= ok ? (1u << p) : 0u;
+        }
+        if (XF) {
+            // unconditional (in_bn is never NULL here, see lisec_conv_forward_ex): with these two loads under a branch the
+            // compiler sizes its s_waitcnt for the shorter path and every step waits for its first A loads before the MFMAs
+            const int cs = cok ? c : 0;
+            tsc = *reinterpret_cast<const float4*>(in_bn + cs);
+            tsh = *reinterpret_cast<const float4*>(in_bn + g.Cin + cs);
+        }
+    };
+    const float relu_lo = (flags & LISEC_CONV_IN_RELU) ? 0.f : -INFINITY;
+    auto store_a = [&]() {
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            float4 v = ra[p];
+            const bool ok = (valid_mask >> p) & 1;
+            if (XF) {
+                v.x = ok ? fmaxf(fmaf(v.x, tsc.x, tsh.x), relu_lo) : 0.f;
+                v.y = ok ? fmaxf(fmaf(v.y, tsc.y, tsh.y), relu_lo) : 0.f;
+                v.z = ok ? fmaxf(fmaf(v.z, tsc.z, tsh.z), relu_lo) : 0.f;
+                v.w = ok ? fmaxf(fmaf(v.w, tsc.w, tsh.w), relu_lo) : 0.f;
+            } else {
+                v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+            }
+            *reinterpret_cast<float4*>(sA + (p * 4 + (lane >> 4)) * LDA + piece * 4) = v;
+        }
+    };
+    // W fragments of (step s, k chunk kc): lane (n = lane & 31, k quad = 2 kc + lane / 32) of the packed slab
+    const float* wlane = wp + ((size_t)(lane >> 5) * g.CoutP + n0 + (lane & 31)) * 4;
+    auto wslab = [&](int s) -> const float* {
+        const int tap = s / ncc, cc = s - tap * ncc;
+        return wlane + (size_t)(tap * KpQ + cc * (BK / 4)) * g.CoutP * 4;
+    };
+
+    f32x16 acc0 = {0}, acc1 = {0};
+    const float* aRow = sA + (lane & 31) * LDA + 4 * (lane >> 5);
+    const int s_begin = (int)(((long long)ks * nsteps) / KS), s_end = (int)(((long long)(ks + 1) * nsteps) / KS);
+    auto advance_to = [&](int s) -> int {
+        while (s < s_end && !live(s)) ++s;
+        return s < s_end ? s : nsteps;
+    };
+    int s = mw < mlimit ? advance_to(s_begin) : nsteps;      // a wave whose rows all lie beyond the layer only joins barriers
+    if (s < nsteps) {
+        load_a(s);
+        const float* wb = wslab(s);
+#pragma unroll
+        for (int kc = 0; kc < BK / 8; ++kc) {
+            b0[kc] = *reinterpret_cast<const float4*>(wb + (size_t)kc * 2 * g.CoutP * 4);
+            b1[kc] = *reinterpret_cast<const float4*>(wb + (size_t)kc * 2 * g.CoutP * 4 + 32 * 4);
+        }
+        store_a();
+    }
+    while (s < nsteps) {
+        const int snext = advance_to(s + 1);
+        // every step issues the same loads -- the last one re-reads its own operands -- so that the number of loads in
+        // flight is static: with loads under a branch the compiler has to assume the smaller count and its s_waitcnt
+        // vmcnt(0) at the end of each step also waits for the W chunks that were only just requested
+        const int sl = snext < nsteps ? snext : s;
+        load_a(sl);
+        const float* wb = wslab(sl);
+        float4 a = *reinterpret_cast<const float4*>(aRow);
+#pragma unroll
+        for (int kc = 0; kc < BK / 8; ++kc) {
+            float4 an = a;
+            if (kc + 1 < BK / 8) an = *reinterpret_cast<const float4*>(aRow + (kc + 1) * 8);
+            __builtin_amdgcn_sched_barrier(0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0[kc].x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1[kc].x, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b0[kc].y, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1[kc].y, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b0[kc].z, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b1[kc].z, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b0[kc].w, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b1[kc].w, acc1, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            // the fragment registers of this chunk are free again: the next step's W chunk streams into them while the
+            // remaining chunks run (a whole step of MFMAs, ~4000 cycles, before it is needed)
+            b0[kc] = *reinterpret_cast<const float4*>(wb + (size_t)kc * 2 * g.CoutP * 4);
+            b1[kc] = *reinterpret_cast<const float4*>(wb + (size_t)kc * 2 * g.CoutP * 4 + 32 * 4);
+            a = an;
+        }
+        store_a();                               // LDS is in order per wave: every fragment read above was issued first
+        s = snext;
+    }
+    // ---- fold the K slices (slice order), then the shared epilogue --------------------------------------------------
+    if (KS > 1) {
+        __syncthreads();                         // every wave is done with its A slab
+        if (ks > 0) {
+            float* mine = smem + (size_t)((ks - 1) * RT + rg) * 2048;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { mine[r * 64 + lane] = acc0[r]; mine[(16 + r) * 64 + lane] = acc1[r]; }
+        }
+        __syncthreads();
+        if (ks == 0) {
+#pragma unroll
+            for (int k = 1; k < KS; ++k) {
+                const float* o = smem + (size_t)((k - 1) * RT + rg) * 2048;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { acc0[r] += o[r * 64 + lane]; acc1[r] += o[(16 + r) * 64 + lane]; }
+            }
+        }
+        __syncthreads();                         // store_tile reuses smem for the statistics
+    }
+    store_tile(g, acc0, acc1, smem, mw, n0, mb, mlimit, 0, wave, lane, tid, bias, flags, out, stats, nullptr, ks == 0);
 }
 
 // all layers of the network in ONE launch: table of descriptors in device memory, element index -> layer by
@@ -730,6 +979,7 @@ int conv_geom_check(const lisec_conv_geom* c, ConvGeom* g) {
     g->pc_span = 0; g->pc_rows = 0;
     g->bwd_y = nullptr; g->bwd_bn = nullptr; g->bwd_relu = 0;
     g->sink.acc = nullptr;
+    g->plane_tiles = 0; g->plane_pair = 0;
     g->pointwise = c->KD * c->KH * c->KW == 1 && ld == 0 && lh == 0 && lw == 0 && c->pd == 0 && c->ph == 0 && c->pw == 0 &&
                    c->Di == c->Do && c->Hi == c->Ho && c->Wi == c->Wo;
     return 0;
@@ -819,6 +1069,25 @@ void parity_order(const lisec_conv_geom* c, ConvGeom* g) {
     }
 }
 
+// (scale = 1, shift = 0) for `C` channels, device memory of the current device, made once per size and kept for the life
+// of the process (a few KB): the on-load affine of a call that only asked for LISEC_CONV_IN_RELU
+const float* identity_bnstate(int C) {
+    static std::mutex mu;
+    static std::map<std::pair<int, int>, float*> tables;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = tables.find({dev, C});
+    if (it != tables.end()) return it->second;
+    std::vector<float> host(2 * (size_t)C, 0.f);
+    for (int i = 0; i < C; ++i) host[i] = 1.f;
+    float* d = nullptr;
+    if (hipMalloc(&d, host.size() * sizeof(float)) != hipSuccess) return nullptr;
+    if (hipMemcpy(d, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); return nullptr; }
+    tables[{dev, C}] = d;
+    return d;
+}
+
 ConvPlan make_conv_plan(const ConvGeom& g) {
     ConvPlan p;
     const int ntiles = cdiv(g.M, BM), nnb = g.CoutP / BN;
@@ -839,8 +1108,10 @@ ConvPlan make_conv_plan(const ConvGeom& g) {
     if (tail_blocks == 0 || tail_blocks * 10 > (long long)slots * 7) return p;   // tail round >= 70 % full already
     if (blocks > 2LL * slots) return p;     // >= 3 rounds: the short last round costs less than a sliced launch + combine
     int ns = (int)(slots / tail_blocks);
-    if (ns > nsteps / 3) ns = nsteps / 3;
-    if (ns > 8) ns = 8;
+    static const int max_split = [] { const char* e = getenv("LISEC_MAX_SPLITK"); return e ? atoi(e) : 12; }();
+    static const int min_steps = [] { const char* e = getenv("LISEC_SPLITK_MIN_STEPS"); return e ? atoi(e) : 3; }();
+    if (ns > nsteps / min_steps) ns = nsteps / min_steps;
+    if (ns > max_split) ns = max_split;
     // LISEC_MIN_SPLITK (measurement knob): layers that would only be cut in two run unsplit instead -- the combine pass
     // of a two-way split costs about what the split saves once the second backward stream competes for the CUs
     static const int min_split = [] { const char* e = getenv("LISEC_MIN_SPLITK"); return e ? atoi(e) : 2; }();
@@ -900,6 +1171,7 @@ extern "C" int lisec_conv_forward_ex(const lisec_conv_geom* c, const float* in, 
     g.out_mask = out_mask;
     const bool bwd_stats = extras && extras->bwd_y;
     const lisec_bn_sink* sk = extras ? extras->sink : nullptr;
+    const bool table_stats = stats_partials != nullptr && !sk;     // per-tile partial table (laid out for 128-row tiles)
     if (sk) {
         LISEC_CHECK_ARG(sk->acc && sk->n_rows > 0 && !row_coords && !c->ps, "bn sink: accumulators, row count, dense rows");
         LISEC_CHECK_ARG((sk->kind == LISEC_SINK_FORWARD && !bwd_stats && sk->gamma && sk->beta && sk->bnstate &&
@@ -940,6 +1212,11 @@ extern "C" int lisec_conv_forward_ex(const lisec_conv_geom* c, const float* in, 
     size_t lds = (size_t)(A_FLOATS + B_FLOATS) * sizeof(float);
     hipStream_t st = static_cast<hipStream_t>(stream_);
     const bool xf = in_bnstate != nullptr || (flags & LISEC_CONV_IN_RELU);
+    if (xf && !in_bnstate) {
+        // ReLU on load without a BatchNormalization: the kernels always read a (scale, shift) table -- hand them the identity
+        in_bnstate = identity_bnstate(g.Cin);
+        LISEC_CHECK_ARG(in_bnstate, "could not allocate the identity (scale, shift) table");
+    }
 #define LISEC_IG(M_, X_, GRID_, NS_, PART_, T0_) hipLaunchKernelGGL((k_igemm<M_, X_>), GRID_, dim3(kThreads), lds, st, g, in, \
         packed_w, bias, in_bnstate, flags, out, stats_partials, NS_, PART_, T0_)
 #define LISEC_IG_ALL(GRID_, NS_, PART_, T0_)                                                                   \
@@ -952,14 +1229,60 @@ extern "C" int lisec_conv_forward_ex(const lisec_conv_geom* c, const float* in, 
                            g.Wo >= 64 && g.in_stride % 4 == 0;       // <= 3 lines per 128-row tile
     const bool halo3 = g.Wo < BM - 2;                                // more than two lines per tile possible
     const size_t lds_halo = halo_lds_bytes(halo3 ? 3 : 2);
-    if ((flags & LISEC_CONV_TAG_ROOFLINE) && c->mode == 0 && !xf) {
-        dim3 grid(ntiles, nnb, 1);                   // one launch, every tile, under its own symbol
-        if (halo_geom && !halo3)
-            hipLaunchKernelGGL((k_igemm_halo<0, false, 1, 2>), grid, dim3(kThreads), halo_lds_bytes(2), st, g, in, packed_w,
-                               bias, in_bnstate, flags, out, stats_partials, 1, (float*)nullptr, 0);
-        else
+    // planes that run different numbers of depth taps: one workgroup per PAIR of planes (see k_igemm_halo) when the layer
+    // runs as one launch of the halo kernel and the pairs still fill the chip; LISEC_PLANE_PAIR=0 turns it off
+    static const bool pair_ok = [] { const char* e = getenv("LISEC_PLANE_PAIR"); return !e || atoi(e) != 0; }();
+    if (pair_ok && halo_geom && g.Do % 2 == 0 && (g.Ho * g.Wo) % BM == 0 && !g.pc_span &&
+        (plan.tile0_tail == ntiles || (flags & LISEC_CONV_TAG_ROOFLINE)) && (long long)(ntiles / 2) * nnb >= resident_slots()) {
+        int lo = 1 << 30, hi = 0;
+        for (int d = 0; d < g.Do; ++d) {
+            int live = 0;
+            for (int kd = 0; kd < g.KD; ++kd) {
+                if (c->mode == 0) { const int sd = (d << g.ls_d) - g.pd + kd; live += sd >= 0 && sd < g.Di; }
+                else { const int t = d + g.pd - kd; live += t >= 0 && (t & ((1 << g.ls_d) - 1)) == 0 && (t >> g.ls_d) < g.Di; }
+            }
+            lo = live < lo ? live : lo; hi = live > hi ? live : hi;
+        }
+        if (lo != hi) { g.plane_tiles = g.Ho * g.Wo / BM; g.plane_pair = 1; }
+    }
+    const int launch_tiles = g.plane_pair ? ntiles / 2 : ntiles;     // workgroups along x of an every-tile launch
+    if ((flags & LISEC_CONV_TAG_ROOFLINE) && !xf) {
+        dim3 grid(halo_geom && !halo3 ? launch_tiles : ntiles, nnb, 1);   // one launch, every tile, under its own symbol
+        if (!(halo_geom && !halo3)) g.plane_pair = 0;
+        if (halo_geom && !halo3) {
+            if (c->mode == 0)
+                hipLaunchKernelGGL((k_igemm_halo<0, false, 1, 2>), grid, dim3(kThreads), halo_lds_bytes(2), st, g, in, packed_w,
+                                   bias, in_bnstate, flags, out, stats_partials, 1, (float*)nullptr, 0);
+            else
+                hipLaunchKernelGGL((k_igemm_halo<1, false, 1, 2>), grid, dim3(kThreads), halo_lds_bytes(2), st, g, in, packed_w,
+                                   bias, in_bnstate, flags, out, stats_partials, 1, (float*)nullptr, 0);
+        } else if (c->mode == 0) {
             hipLaunchKernelGGL((k_igemm<0, false, 1>), grid, dim3(kThreads), lds, st, g, in, packed_w, bias, in_bnstate,
                                flags, out, stats_partials, 1, (float*)nullptr, 0);
+        } else {
+            hipLaunchKernelGGL((k_igemm<1, false, 1>), grid, dim3(kThreads), lds, st, g, in, packed_w, bias, in_bnstate,
+                               flags, out, stats_partials, 1, (float*)nullptr, 0);
+        }
+        LISEC_LAUNCH_CHECK();
+        return LISEC_OK;
+    }
+    // a layer that would be K-sliced as a whole: the slices stay inside the workgroups (k_igemm_w) -- no slabs, no combine.
+    // LISEC_WAVE_K = 2 / 4 / 1 (auto): opt-in -- measured slower than the sliced launch + combine on every RPN shape but the
+    // 1250-position one (two waves per SIMD at 219 registers: 2.4 rounds of workgroups where the sliced launch needs one)
+    static const int wave_k = [] { const char* e = getenv("LISEC_WAVE_K"); return e ? atoi(e) : 0; }();
+    if (plan.nsplit >= 2 && plan.tile0_tail == 0 && !table_stats && wave_k != 0) {
+        const int KS = wave_k == 2 || wave_k == 4 ? wave_k : (plan.nsplit == 2 ? 2 : 4);
+        const int bmw = 128 / KS;
+        dim3 grid(cdiv(g.M, bmw), nnb, 1);
+        if (sk) g.sink.total = grid.x * grid.y;
+        const size_t lds_w = (size_t)4 * 32 * LDA * sizeof(float);
+#define LISEC_IW(M_, X_, K_) hipLaunchKernelGGL((k_igemm_w<M_, X_, K_>), grid, dim3(kThreads), lds_w, st, g, in, packed_w, bias, \
+        in_bnstate, flags, out, stats_partials)
+#define LISEC_IW_K(M_, X_) do { if (KS == 2) LISEC_IW(M_, X_, 2); else LISEC_IW(M_, X_, 4); } while (0)
+        if (c->mode == 0) { if (xf) LISEC_IW_K(0, true); else LISEC_IW_K(0, false); }
+        else              { if (xf) LISEC_IW_K(1, true); else LISEC_IW_K(1, false); }
+#undef LISEC_IW_K
+#undef LISEC_IW
         LISEC_LAUNCH_CHECK();
         return LISEC_OK;
     }
@@ -980,8 +1303,9 @@ extern "C" int lisec_conv_forward_ex(const lisec_conv_geom* c, const float* in, 
             else              { if (xf) LISEC_IH(1, true, GRID_, NS_, PART_, T0_); else LISEC_IH(1, false, GRID_, NS_, PART_, T0_); } \
         } else LISEC_IG_ALL(GRID_, NS_, PART_, T0_);                                                           \
     } while (0)
+    if (!halo) g.plane_pair = 0;
     if (plan.tile0_tail > 0) {                       // whole rounds, single pass
-        dim3 grid(plan.tile0_tail, nnb, 1);
+        dim3 grid(g.plane_pair ? launch_tiles : plan.tile0_tail, nnb, 1);
         LISEC_IG_ANY(grid, 1, (float*)nullptr, 0);
     }
     if (plan.tile0_tail < ntiles) {                  // K-sliced tail (or the whole small layer)
@@ -999,5 +1323,11 @@ extern "C" int lisec_conv_forward_ex(const lisec_conv_geom* c, const float* in, 
 #undef LISEC_IG_ALL
 #undef LISEC_IG
     LISEC_LAUNCH_CHECK();
+    return LISEC_OK;
+}
+
+// Diagnostic (not in lisec_hip.h): points k_igemm_halo's stamp buffer at `buf` (device, 8192*8 uint64) or NULL.
+extern "C" int lisec_debug_igemm_stamps(unsigned long long* buf) {
+    LISEC_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_igemm_stamps), &buf, sizeof(buf)));
     return LISEC_OK;
 }

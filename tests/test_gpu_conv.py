@@ -269,8 +269,10 @@ def test_backward_statistics_folded_into_the_store(mode, stride, W, splitk):
         parts = torch.full((nparts, 2, Cg), float("nan"), dtype=torch.float64, device=DEV)
         got = torch.empty(1, H, W, Cg, device=DEV)
         ops.conv_forward(geo, src, wp, got, splitk=splitk, bwd=(y, st, relu), stats=parts)
-        assert torch.equal(got, plain)
-        dz = plain.reshape(M, Cg).double()
+        # same contraction, possibly another K-slice order (a call without a partial table may keep its slices inside
+        # the workgroups): equal to fp32 summation noise
+        _close(got, plain, rtol=1e-5)
+        dz = got.reshape(M, Cg).double()
         if relu:
             dz = dz * ((y.double() * st[:Cg].double() + st[Cg:2 * Cg].double()) > 0)
         yhat = (y.double() - mean.double()) * inv.double()
