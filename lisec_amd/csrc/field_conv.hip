@@ -40,12 +40,12 @@ __device__ __forceinline__ bool feeds(int x, int k, int ls, int pad, int n_out) 
     return t >= 0 && (t & ((1 << ls) - 1)) == 0 && (t >> ls) < n_out;
 }
 
-// One workgroup per (128 voxel rows, (kd, kh) pair): the A tile is staged once and the KW taps of the pair run over it,
-// the next tap's W slab prefetched into registers under the MFMAs of the current one.
+// One workgroup per (128 voxel rows, tpw taps): the A tile is staged once and the taps run over it, the next tap's W slab
+// prefetched into registers under the MFMAs of the current one.
 __global__ void __launch_bounds__(kFieldThreads)
 k_field_taps(ConvGeom g, const float* __restrict__ vout, const float* __restrict__ delta,
              const int* __restrict__ info, const int* __restrict__ coords, int cap,
-             const float* __restrict__ wp, float* __restrict__ Z, long long zstride, float* __restrict__ Zc) {
+             const float* __restrict__ wp, float* __restrict__ Z, long long zstride, float* __restrict__ Zc, int tpw) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __shared__ int any_valid;
     float* sA = smem;
@@ -60,13 +60,17 @@ k_field_taps(ConvGeom g, const float* __restrict__ vout, const float* __restrict
     const int m0 = blockIdx.x * FM;
     if (m0 > V) return;                                   // rows 0 .. V exist (row V = the empty-cell constant)
     FIELD_STAMP(0, wg, 1);
-    const int kh = blockIdx.y % g.KH, kd = blockIdx.y / g.KH;
+    // tpw taps per workgroup: KW (one (kd, kh) pair, the A tile staged once) or 1 (three times the workgroups)
+    const int tap0 = blockIdx.y * tpw;
+    const int kh = (tap0 / g.KW) % g.KH, kd = tap0 / (g.KW * g.KH), kw0 = tap0 % g.KW;
     if (tid == 0) any_valid = 0;
     __syncthreads();
     if (tid < FM) {
         const int m = m0 + tid;
         bool ok = m == V;                                 // the constant is needed for every tap
-        if (m < V) ok = feeds(coords[3 * m], kd, g.ls_d, g.pd, g.Do) && feeds(coords[3 * m + 1], kh, g.ls_h, g.ph, g.Ho);
+        if (m < V)
+            ok = feeds(coords[3 * m], kd, g.ls_d, g.pd, g.Do) && feeds(coords[3 * m + 1], kh, g.ls_h, g.ph, g.Ho) &&
+                 (tpw > 1 || feeds(coords[3 * m + 2], kw0, g.ls_w, g.pw, g.Wo));
         if (ok) any_valid = 1;
     }
     __syncthreads();
@@ -74,7 +78,6 @@ k_field_taps(ConvGeom g, const float* __restrict__ vout, const float* __restrict
     FIELD_STAMP(0, wg, 2);
 
     const int piece = tid & 15;
-    const int tap0 = blockIdx.y * g.KW;
     float4 rb[4];
     auto load_w = [&](int tap) {
         const float* wt = wp + (size_t)tap * FC * FC;     // packed [k/4][n][4] slab of this tap
@@ -92,12 +95,12 @@ k_field_taps(ConvGeom g, const float* __restrict__ vout, const float* __restrict
     const float* aRow = sA + (wave * 32 + (lane & 31)) * FLDA + 4 * (lane >> 5);
     const float* bCol = sB + ((lane >> 5) * FC + (lane & 31)) * 4;
     const int col = lane & 31;
-    for (int kw = 0; kw < g.KW; ++kw) {
+    for (int kw = 0; kw < tpw; ++kw) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(sB + (i * 256 + tid) * 4) = rb[i];
         __syncthreads();
         if (kw == 0) FIELD_STAMP(0, wg, 3);
-        if (kw + 1 < g.KW) load_w(tap0 + kw + 1);
+        if (kw + 1 < tpw) load_w(tap0 + kw + 1);
         f32x16 acc0 = {0}, acc1 = {0};
 #pragma unroll
         for (int kc = 0; kc < FC / 8; ++kc) {
@@ -135,7 +138,7 @@ k_field_taps(ConvGeom g, const float* __restrict__ vout, const float* __restrict
 // One workgroup per segment of an output line (d', h'); 16 lanes x float4 per output position.  Nothing in here depends
 // on the device-side voxel count: the constant's row lives at a fixed place (Zc), ordinals are clamped to the capacity,
 // so the cell lookups, the constant rows and the bias are all requested at once (one round trip before the first store).
-__global__ void __launch_bounds__(kCombineThreads)
+__global__ void __launch_bounds__(kCombineThreads, 8)
 k_field_combine(ConvGeom g, const int* __restrict__ cell_voxel, int cap, const float* __restrict__ Z,
                 long long zstride, const float* __restrict__ Zc, const float* __restrict__ bias,
                 float* __restrict__ out, int nseg, int seg_len, int LW) {
@@ -328,9 +331,13 @@ extern "C" int lisec_conv_field_forward(const lisec_conv_geom* c, const float* v
     const long long zstride = ((long long)row_capacity + 1) * FC;
     const int ntaps = g.KD * g.KH * g.KW;
     float* Zc = Z + (size_t)ntaps * zstride;
-    hipLaunchKernelGGL(k_field_taps, dim3(cdiv((long long)row_capacity + 1, FM), g.KD * g.KH), dim3(kFieldThreads),
+    // small sweeps: one tap per workgroup (9 400 voxels: 25 us against 38 us -- the launch is far from filling the chip);
+    // big ones: the KW taps of a (kd, kh) pair share one staged A tile (84 000 voxels: 268 us against 302 us for the call)
+    static const int tpw_env = [] { const char* e = std::getenv("LISEC_FIELD_TPW"); return e ? std::atoi(e) : 0; }();
+    const int tpw = (tpw_env == 1 || tpw_env == g.KW) ? tpw_env : (row_capacity > 65536 ? g.KW : 1);
+    hipLaunchKernelGGL(k_field_taps, dim3(cdiv((long long)row_capacity + 1, FM), ntaps / tpw), dim3(kFieldThreads),
                        (size_t)(FM * FLDA + FC * FC) * sizeof(float), st, g, vout, delta, info, coords, row_capacity,
-                       packed_w, Z, zstride, Zc);
+                       packed_w, Z, zstride, Zc, tpw);
     const size_t dyn = sizeof(int) * ((size_t)g.KD * g.KH * LW + seg_len);
     hipLaunchKernelGGL(k_field_combine, dim3(nblocks), dim3(kCombineThreads), dyn, st, g, cell_voxel, row_capacity,
                        (const float*)Z, zstride, (const float*)Zc, bias, out, nseg, seg_len, LW);

@@ -832,13 +832,18 @@ __global__ void k_pack_weights_batched(const lisec_pack_desc* __restrict__ tab, 
 
 // split-K combine: out = sum_z partial[z] + bias (+ out) (relu) ; BatchNormalization partial statistics per
 // 128-row tile (same tile index as the single-pass kernel, so lisec_bn_finalize sees the same layout)
-constexpr int kSkThreads = 1024;
-__global__ void __launch_bounds__(kSkThreads)
+// ROWS rows x 64 channels per workgroup of ROWS * 8 threads.  ROWS = 128 (one 128-row tile: the layout of the per-tile
+// statistics table); ROWS = 32 otherwise: four times as many, four times lighter workgroups (256 threads, 8 KB of LDS) --
+// beside the weight-gradient kernels of the second stream the 1024-thread ones waited tens of microseconds for a CU
+// with 16 free wave slots.
+template <int ROWS>
+__global__ void __launch_bounds__(ROWS * 8)
 k_splitk_reduce(const float* __restrict__ partial, int nsplit, int M, int Cout, int CoutP,
                 const float* __restrict__ bias, int flags, float* __restrict__ out, int out_stride,
-                double* __restrict__ stats, int tile0, const int32_t* __restrict__ row_count,
+                double* __restrict__ stats, int tile0, int rows_part, const int32_t* __restrict__ row_count,
                 const float* __restrict__ out_mask, int pc_span, int pc_rows, int Wo,
                 const float* __restrict__ bwd_y, const float* __restrict__ bwd_bn, int bwd_relu, BnSink sink) {
+    constexpr int kSkThreads = ROWS * 8;
     __shared__ float red[2][kSkThreads][4];
     if (row_count && *row_count < M) M = *row_count;          // row list shorter than its capacity
     constexpr int cq = BN / 4;                       // one 64-channel slab per blockIdx.y
@@ -856,11 +861,13 @@ k_splitk_reduce(const float* __restrict__ partial, int nsplit, int M, int Cout, 
     }
     const bool orelu = (flags & LISEC_CONV_OUT_RELU) != 0, accum = (flags & LISEC_CONV_ACCUMULATE) != 0;
     float4 s1 = make_float4(0, 0, 0, 0), s2 = make_float4(0, 0, 0, 0);
-    const int tile = tile0 + blockIdx.x;
-    const int m_begin = tile * BM, m_end = m_begin + BM < M ? m_begin + BM : M;
-    if (m_begin >= M) return;                                  // (never taken with stats: no row list there)
-    const size_t rows_part = (size_t)gridDim.x * BM;
-    const size_t zstride = rows_part * CoutP;
+    const int tile = tile0 + (int)((long long)blockIdx.x * ROWS / BM);     // the 128-row tile these rows belong to
+    const int m_begin = tile0 * BM + blockIdx.x * ROWS, m_end = m_begin + ROWS < M ? m_begin + ROWS : M;
+    if (m_begin >= M) {                                        // rows beyond the layer (or a short row list)
+        if (sink.acc) sink_finish(sink);
+        return;
+    }
+    const size_t zstride = (size_t)rows_part * CoutP;
     for (int m = m_begin + rsub; m < m_end; m += rows_per_iter) {
         float4 v = b;
         const float* src = partial + (size_t)(m - tile0 * BM) * CoutP + c;
@@ -1204,7 +1211,9 @@ extern "C" int lisec_conv_forward_ex(const lisec_conv_geom* c, const float* in, 
     if (sk) {
         g.sink.acc = static_cast<long long*>(sk->acc);
         g.sink.kind = sk->kind; g.sink.C = g.Cout; g.sink.unbiased = sk->unbiased_moving;
-        g.sink.total = (unsigned)ntiles * (unsigned)nnb;          // every (tile, channel slab) stores exactly once
+        // one arrival per storing workgroup: every (tile, channel slab) once; the combine pass of K-sliced tiles runs four
+        // 32-row workgroups per tile
+        g.sink.total = ((unsigned)plan.tile0_tail + (unsigned)(ntiles - plan.tile0_tail) * (BM / 32)) * (unsigned)nnb;
         g.sink.N = sk->n_rows;
         g.sink.gamma = sk->gamma; g.sink.beta = sk->beta; g.sink.mmean = sk->moving_mean; g.sink.mvar = sk->moving_var;
         g.sink.bnstate = sk->bnstate; g.sink.dgamma = sk->dgamma; g.sink.dbeta = sk->dbeta; g.sink.coef = sk->coef;
@@ -1314,9 +1323,15 @@ extern "C" int lisec_conv_forward_ex(const lisec_conv_geom* c, const float* in, 
         const int tail = ntiles - plan.tile0_tail;
         dim3 grid(tail, nnb, plan.nsplit);
         LISEC_IG_ANY(grid, plan.nsplit, partial, plan.tile0_tail);
-        hipLaunchKernelGGL(k_splitk_reduce, dim3(tail, nnb), dim3(kSkThreads), 0, st, partial, plan.nsplit, g.M, g.Cout,
-                           g.CoutP, bias, flags, out, g.out_stride, stats_partials, plan.tile0_tail, g.row_count, g.out_mask,
-                           g.pc_span, g.pc_rows, g.Wo, g.bwd_y, g.bwd_bn, g.bwd_relu, g.sink);
+        if (table_stats) {
+            hipLaunchKernelGGL((k_splitk_reduce<BM>), dim3(tail, nnb), dim3(BM * 8), 0, st, partial, plan.nsplit, g.M, g.Cout,
+                               g.CoutP, bias, flags, out, g.out_stride, stats_partials, plan.tile0_tail, tail * BM, g.row_count,
+                               g.out_mask, g.pc_span, g.pc_rows, g.Wo, g.bwd_y, g.bwd_bn, g.bwd_relu, g.sink);
+        } else {
+            hipLaunchKernelGGL((k_splitk_reduce<32>), dim3(tail * (BM / 32), nnb), dim3(256), 0, st, partial, plan.nsplit, g.M,
+                               g.Cout, g.CoutP, bias, flags, out, g.out_stride, stats_partials, plan.tile0_tail, tail * BM,
+                               g.row_count, g.out_mask, g.pc_span, g.pc_rows, g.Wo, g.bwd_y, g.bwd_bn, g.bwd_relu, g.sink);
+        }
     }
 #undef LISEC_IG_ANY
 #undef LISEC_IH
