@@ -415,28 +415,6 @@ class LisecNet:
             if need > self.wgrad_ws.numel():
                 self.wgrad_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
             self.dout_rows = torch.empty((sample.cap + 1, 64), dtype=torch.float32, device=self.device)
-        kind = {"mse": 0, "smoothl1_ce": 1}[loss]
-        ops.rpn_loss(a["head"], y_cls, y_reg, M, kind, d["head"], self.loss_out, grad_scale=grad_scale)
-        # ---- heads (model_training.py:254-255) ---------------------------------------------------
-        ops.conv_wgrad(self.head_geom, a["concat"], d["head"], self.head_dw, self.wgrad_ws)
-        ops.colsum(d["head"], 16, M, 16, self.head_db)
-        if getattr(self, "_head_split", None) is None:     # merged head gradients -> the Keras-shaped slots of G
-            self._head_split = ops.CopyTable([(self.head_dw[:, :2], p.grad_view(G, "cls.kernel")[0, 0]),
-                                              (self.head_dw[:, 2:], p.grad_view(G, "reg.kernel")[0, 0]),
-                                              (self.head_db[:2], p.grad_view(G, "cls.bias")),
-                                              (self.head_db[2:], p.grad_view(G, "reg.bias"))], self.device)
-        self._head_split.run()
-        ops.conv_forward(self.head_dgeom, d["head"], self.packed_t["head"][0], d["concat"])
-        # the three deconv bias gradients are the column sums of the concat gradient: one pass over it
-        ops.colsum(d["concat"], 768, M, 768, self.up_db)
-        if getattr(self, "_up_bias_split", None) is None:
-            self._up_bias_split = ops.CopyTable(
-                [(self.up_db[256 * L["slot"]:256 * (L["slot"] + 1)], p.grad_view(G, L["conv"].bias))
-                 for L in self.layers if L["kind"] == "deconv"], self.device)
-        self._up_bias_split.run()
-        # ---- RPN blocks, last to first -------------------------------------------------------------
-        layers = self.layers
-        first_write = set()                    # gradient buffers that already hold a contribution
         main = torch.cuda.current_stream()
 
         side_handle = self.side.cuda_stream
@@ -477,6 +455,37 @@ class LisecNet:
             if len(pending) >= fork_every or torch_ops:
                 flush_side()
 
+        kind = {"mse": 0, "smoothl1_ce": 1}[loss]
+        ops.rpn_loss(a["head"], y_cls, y_reg, M, kind, d["head"], self.loss_out, grad_scale=grad_scale)
+        # ---- heads (model_training.py:254-255) ---------------------------------------------------
+        # only the data gradient is on the way to the rest of the backward pass: the heads' weight and bias gradients and
+        # the deconv bias gradients (column sums of the concat gradient) are leaves and go to the second stream
+        if getattr(self, "_head_split", None) is None:     # merged head gradients -> the Keras-shaped slots of G
+            self._head_split = ops.CopyTable([(self.head_dw[:, :2], p.grad_view(G, "cls.kernel")[0, 0]),
+                                              (self.head_dw[:, 2:], p.grad_view(G, "reg.kernel")[0, 0]),
+                                              (self.head_db[:2], p.grad_view(G, "cls.bias")),
+                                              (self.head_db[2:], p.grad_view(G, "reg.bias"))], self.device)
+            self._up_bias_split = ops.CopyTable(
+                [(self.up_db[256 * L["slot"]:256 * (L["slot"] + 1)], p.grad_view(G, L["conv"].bias))
+                 for L in self.layers if L["kind"] == "deconv"], self.device)
+
+        def head_leaves():
+            ops.conv_wgrad(self.head_geom, a["concat"], d["head"], self.head_dw, self.wgrad_ws)
+            ops.colsum(d["head"], 16, M, 16, self.head_db, ws_tag="side")
+            self._head_split.run()
+
+        def concat_leaves():
+            # the three deconv bias gradients are the column sums of the concat gradient: one pass over it
+            ops.colsum(d["concat"], 768, M, 768, self.up_db, ws_tag="side")
+            self._up_bias_split.run()
+
+        on_side(head_leaves)
+        ops.conv_forward(self.head_dgeom, d["head"], self.packed_t["head"][0], d["concat"])
+        on_side(concat_leaves)
+        layers = self.layers
+        first_write = set()                    # gradient buffers that already hold a contribution
+
+        # ---- RPN blocks, last to first -------------------------------------------------------------
         writes = {}                            # gradient buffer -> contributions stored so far
         bwd_ready = {}                         # gradient buffer -> partial rows of its BN-backward statistics
 

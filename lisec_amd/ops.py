@@ -200,8 +200,10 @@ def conv_wgrad(g, x, dy, dW, workspace, in_bn=None, flags=0, transpose_out=False
 _EW = {}
 
 
-def _ew_workspace(device):
-    key = str(device)
+def _ew_workspace(device, tag="main"):
+    """Scratch of the element-wise entry points; launches that may run at the same time on different streams must not
+    share one (tag: one buffer per stream role)."""
+    key = (str(device), tag)
     if key not in _EW:
         _EW[key] = torch.empty(_lib.load().lisec_eltwise_workspace_bytes(), dtype=torch.uint8, device=device)
     return _EW[key]
@@ -218,8 +220,8 @@ def relu_mask(grad, act):
     _lib.check(_lib.load().lisec_relu_mask(_lib.ptr(grad), _lib.ptr(act), grad.numel(), _lib.current_stream()))
 
 
-def colsum(x, stride, M, C, out):
-    ws = _ew_workspace(x.device)
+def colsum(x, stride, M, C, out, ws_tag="main"):
+    ws = _ew_workspace(x.device, ws_tag)
     _lib.check(_lib.load().lisec_colsum(_lib.ptr(x), stride, M, C, _lib.ptr(out), _lib.ptr(ws), ws.numel(),
                                         _lib.current_stream()))
 

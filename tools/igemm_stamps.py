@@ -12,7 +12,7 @@ lib = _lib.load()
 lib.lisec_debug_igemm_stamps.argtypes = [ctypes.c_void_p]
 
 
-def case(name, mode, ind, outd, k, s, p, cin, cout):
+def case(name, mode, ind, outd, k, s, p, cin, cout, extra=0):
     x = torch.randn(*ind, cin, device=dev)
     ntaps = k[0] * k[1] * k[2]
     w = torch.randn(ntaps, cin, cout, device=dev) * 0.05
@@ -20,11 +20,11 @@ def case(name, mode, ind, outd, k, s, p, cin, cout):
     out = torch.empty(*outd, cout, device=dev)
     g = ops.geom(mode, ind, outd, k, s, p, cin, cout)
     for _ in range(3):
-        ops.conv_forward(g, x, wp, out, flags=ops.TAG_ROOFLINE)
+        ops.conv_forward(g, x, wp, out, flags=ops.TAG_ROOFLINE | extra)
     buf = torch.zeros(8192 * 8, dtype=torch.int64, device=dev)
     _lib.check(lib.lisec_debug_igemm_stamps(buf.data_ptr()))
     torch.cuda.synchronize()
-    ops.conv_forward(g, x, wp, out, flags=ops.TAG_ROOFLINE)
+    ops.conv_forward(g, x, wp, out, flags=ops.TAG_ROOFLINE | extra)
     torch.cuda.synchronize()
     _lib.check(lib.lisec_debug_igemm_stamps(None))
     t = buf.cpu().numpy().reshape(8192, 8)
@@ -58,4 +58,4 @@ def case(name, mode, ind, outd, k, s, p, cin, cout):
 if __name__ == "__main__":
     case("mid2 fwd", 0, (4, 200, 400), (2, 200, 400), (3, 3, 3), (1, 1, 1), (0, 1, 1), 64, 64)
     case("mid2 dgrad", 1, (2, 200, 400), (4, 200, 400), (3, 3, 3), (1, 1, 1), (0, 1, 1), 64, 64)
-    case("mid1 fwd", 0, (8, 200, 400), (4, 200, 400), (3, 3, 3), (2, 1, 1), (1, 1, 1), 64, 64)
+    case("mid1 fwd (dense form)", 0, (8, 200, 400), (4, 200, 400), (3, 3, 3), (2, 1, 1), (1, 1, 1), 64, 64)
