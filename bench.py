@@ -32,9 +32,11 @@ import torch  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_HBM_GBS = 8000.0            # HBM3E spec (6.3 TB/s achievable per the same guide)
-# PMC passes of the dominant kernel's launch (profiles/r02_pmc_and_experiments.txt); None until collected
-MID2_DGRAD_TRAFFIC_BYTES = None
-MID2_DGRAD_CLOCK_GHZ = None
+# rocprofv3 --pmc passes of the dominant kernel's own launch (profiles/r02_pmc_and_experiments.txt, "round 2, field form"):
+# FETCH_SIZE 73 360 KiB (x2: the gfx950 correction for wide coalesced reads) + WRITE_SIZE 80 000 KiB per launch (algorithmic:
+# 41 MB read + 82 MB written -- the depth / halo re-reads that miss L2 make up the rest); GRBM_GUI_ACTIVE / 8 / duration
+MID2_DGRAD_TRAFFIC_BYTES = (2 * 73359.6 + 80000.0) * 1024
+MID2_DGRAD_CLOCK_GHZ = 2.30
 
 
 def u20k_cloud(seed, n=20000):

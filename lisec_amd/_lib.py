@@ -243,3 +243,51 @@ def require_gpu():
         from .parallel import select_device
         return select_device()
     return torch.device("cuda", torch.cuda.current_device())
+
+
+# ---- device-scope events ----------------------------------------------------------------------------------------------
+# torch.cuda.Event records with a system-scope release (the host may inspect it): ~6 us of the recording queue per
+# record.  The forks between the two backward streams only order work on ONE device, so they use events created with
+# hipEventDisableTiming | hipEventReleaseToDevice through the HIP runtime the process already has loaded.
+_hip = None
+
+
+def _hiprt():
+    global _hip
+    if _hip is None:
+        _hip = ctypes.CDLL("libamdhip64.so")
+        _hip.hipEventCreateWithFlags.argtypes = [POINTER(c_void_p), ctypes.c_uint]
+        _hip.hipEventRecord.argtypes = [c_void_p, c_void_p]
+        _hip.hipStreamWaitEvent.argtypes = [c_void_p, c_void_p, ctypes.c_uint]
+        _hip.hipEventDestroy.argtypes = [c_void_p]
+    return _hip
+
+
+class DeviceEvent:
+    """hipEvent_t with device-scope release: record(stream_handle) / wait(stream_handle); handles are the integers
+    torch's Stream.cuda_stream gives."""
+    FLAGS = 0x2 | 0x40000000          # hipEventDisableTiming | hipEventReleaseToDevice
+
+    def __init__(self):
+        h = c_void_p()
+        rc = _hiprt().hipEventCreateWithFlags(ctypes.byref(h), self.FLAGS)
+        if rc != 0:
+            raise LisecError(f"hipEventCreateWithFlags failed ({rc})")
+        self.handle = h
+
+    def record(self, stream_handle):
+        rc = _hiprt().hipEventRecord(self.handle, c_void_p(stream_handle))
+        if rc != 0:
+            raise LisecError(f"hipEventRecord failed ({rc})")
+
+    def wait(self, stream_handle):
+        rc = _hiprt().hipStreamWaitEvent(c_void_p(stream_handle), self.handle, 0)
+        if rc != 0:
+            raise LisecError(f"hipStreamWaitEvent failed ({rc})")
+
+    def __del__(self):
+        try:
+            if self.handle:
+                _hiprt().hipEventDestroy(self.handle)
+        except Exception:
+            pass

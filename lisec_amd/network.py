@@ -213,6 +213,23 @@ class LisecNet:
         if c.bn:
             self._bn_after(c, training)
 
+    def _new_event(self):
+        return _lib.DeviceEvent() if getattr(self, "device_events", False) else torch.cuda.Event()
+
+    @staticmethod
+    def _record(ev, stream):
+        if isinstance(ev, _lib.DeviceEvent):
+            ev.record(stream.cuda_stream)
+        else:
+            ev.record(stream)
+
+    @staticmethod
+    def _wait(ev, stream):
+        if isinstance(ev, _lib.DeviceEvent):
+            ev.wait(stream.cuda_stream)
+        else:
+            stream.wait_event(ev)
+
     def dense_grid(self, rewrite=True):
         """The dense (D,H,W,64) VFE output; rewrite: fill it from the last forward's per-voxel values (the field form
         of the first Conv3D never writes it)."""
@@ -235,7 +252,7 @@ class LisecNet:
     def _forward(self, sample, training):
         pending = getattr(self, "_pack_pending", False)
         if pending and (self._packed_version != (self.params_version, self.params.version)):
-            torch.cuda.current_stream().wait_event(self._pack_done)     # variables changed since the early repack
+            self._wait(self._pack_done, torch.cuda.current_stream())     # variables changed since the early repack
             self._pack_pending = pending = False
         if not pending:
             self._pack_all()
@@ -252,7 +269,7 @@ class LisecNet:
         if pending:
             # the repack of this step's weights was enqueued on the second stream right after the last optimizer step
             # and ran under this sweep's voxeliser and VFE; the first contraction is the first reader
-            torch.cuda.current_stream().wait_event(self._pack_done)
+            self._wait(self._pack_done, torch.cuda.current_stream())
             self._pack_pending = False
         for L in self.layers:
             if L["kind"] == "mid":
@@ -333,7 +350,7 @@ class LisecNet:
         self.packed_t["head"] = (torch.empty(ops.packed_floats(1, 16, 768), dtype=f32, device=dev), None)
         self.head_dw = torch.empty(768, 16, dtype=f32, device=dev)
         self.up_db = torch.empty(768, dtype=f32, device=dev)
-        self._fork_events, self._join_event = [], torch.cuda.Event()
+        self._fork_events, self._join_event = [], None
         # conv outputs that sit under a BatchNormalization(+ReLU), and how many layers read each of them
         self.bn_of, self.consumers = {}, {}
         nparts = 1
@@ -353,6 +370,10 @@ class LisecNet:
         # gradient, instead of beside it on the second stream (measurement knob; they need a workspace of their own)
         self.mid_wgrad_main = os.environ.get("LISEC_MID_WGRAD", "side") == "main"
         self.fork_every = max(1, int(os.environ.get("LISEC_FORK_EVERY", "1")))
+        # fork events with a device-scope release (LISEC_DEVICE_EVENTS=0: torch.cuda.Event, system-scope release)
+        self.device_events = os.environ.get("LISEC_DEVICE_EVENTS", "1") == "1"
+        if torch.cuda.is_current_stream_capturing():
+            self.device_events = False
         self.wgrad_ws_main = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if self.mid_wgrad_main else None
         # weight gradients are leaves of the backward graph: they run on a second HIP stream next to the
         # BN-backward / data-gradient chain (the RPN layers are too small to fill 256 CUs on their own)
@@ -429,11 +450,11 @@ class LisecNet:
             if not pending:
                 return
             if nfork[0] == len(events):
-                events.append(torch.cuda.Event())
+                events.append(self._new_event())
             ev = events[nfork[0]]                       # events are reused step after step
             nfork[0] += 1
-            ev.record(main)
-            self.side.wait_event(ev)
+            self._record(ev, main)
+            self._wait(ev, self.side)
             pin = _lib.pin_stream(side_handle)
             try:
                 for fn, torch_ops in pending:
@@ -585,9 +606,10 @@ class LisecNet:
         # ---- VFE -----------------------------------------------------------------------------------
         flush_side()
         self.vfe.backward(None, G, dout_rows=self.dout_rows, g_all=self.g_all)
-        done = self._join_event
-        done.record(self.side)
-        main.wait_event(done)                  # every weight gradient has landed before the optimizer reads G
+        if self._join_event is None:
+            self._join_event = self._new_event()
+        self._record(self._join_event, self.side)
+        self._wait(self._join_event, main)     # every weight gradient has landed before the optimizer reads G
         return self.loss_out
 
     def apply_gradients(self, lr=0.01, decay=1e-6, momentum=0.9):
@@ -600,16 +622,16 @@ class LisecNet:
             # both repacks (forward and transposed layouts, ~75 us) for the NEXT step go to the second stream now: they
             # only depend on this update, and the next sweep's voxeliser + VFE (~105 us) do not read them
             if getattr(self, "_pack_done", None) is None:
-                self._pack_fork, self._pack_done = torch.cuda.Event(), torch.cuda.Event()
-            self._pack_fork.record(torch.cuda.current_stream())
-            self.side.wait_event(self._pack_fork)
+                self._pack_fork, self._pack_done = self._new_event(), self._new_event()
+            self._record(self._pack_fork, torch.cuda.current_stream())
+            self._wait(self._pack_fork, self.side)
             pin = _lib.pin_stream(self.side.cuda_stream)
             try:
                 self._pack_all()
                 self._pack_all_t()
             finally:
                 _lib.pin_stream(pin)
-            self._pack_done.record(self.side)
+            self._record(self._pack_done, self.side)
             self._pack_pending = True
 
     def train_step(self, sample, y_cls, y_reg, loss="mse", allreduce=None):
@@ -655,6 +677,8 @@ class CapturedStep:
         torch.cuda.synchronize(dev)
         net._pack_pending = False
         net._prepare_training()
+        # torch's capture only knows the events torch made: the forks go back to torch.cuda.Event
+        net.device_events, net._fork_events, net._join_event = False, [], None
         p = net.params
         keep = (p.theta.clone(), p.state.clone(), net.velocity.clone(), net._iter_dev.clone(), net._iterations,
                 net.params_version, net.state_version)
