@@ -328,6 +328,13 @@ int lisec_conv_wgrad(const lisec_conv_geom* g, const float* in, const float* in_
 size_t lisec_conv_tap_sums_workspace_bytes(const lisec_conv_geom* g);
 int lisec_conv_tap_sums(const lisec_conv_geom* g, const float* dy, float* S, void* workspace,
                         size_t workspace_bytes, lisec_stream_t stream);
+/* lisec_conv_tap_sums fused with the apply pass of the BatchNormalization backward in front of it (what
+ * lisec_bn_backward_apply_coef(relu = 0) computes): dz is the gradient of the normalised map, y / bnstate / coef as
+ * there; dy = scale * (dz - coef[c] - yhat * coef[C + c]) is stored (dy may alias dz, row stride Cout) and S is
+ * summed over dy -- one pass over the map instead of two. */
+int lisec_conv_tap_sums_bn(const lisec_conv_geom* g, const float* dz, const float* y, const float* bnstate,
+                           const float* coef, float* dy, float* S, void* workspace, size_t workspace_bytes,
+                           lisec_stream_t stream);
 int lisec_const_field_grads(const float* W, const float* S, const float* cvec, const int32_t* cvec_row,
                             int cvec_row_max, int ntaps, int Cin, int Cout, float* dW, float* g_all,
                             lisec_stream_t stream);

@@ -108,6 +108,8 @@ def _declare(lib):
     lib.lisec_conv_tap_sums_workspace_bytes.argtypes = [POINTER(ConvGeom)]
     lib.lisec_conv_tap_sums.restype = c_int
     lib.lisec_conv_tap_sums.argtypes = [POINTER(ConvGeom), P, P, P, c_size_t, P]
+    lib.lisec_conv_tap_sums_bn.restype = c_int
+    lib.lisec_conv_tap_sums_bn.argtypes = [POINTER(ConvGeom), P, P, P, P, P, P, P, c_size_t, P]
     lib.lisec_conv_field_forward_workspace_bytes.restype = c_size_t
     lib.lisec_conv_field_forward_workspace_bytes.argtypes = [POINTER(ConvGeom), c_int]
     lib.lisec_conv_field_forward.restype = c_int

@@ -832,10 +832,10 @@ __global__ void k_pack_weights_batched(const lisec_pack_desc* __restrict__ tab, 
 
 // split-K combine: out = sum_z partial[z] + bias (+ out) (relu) ; BatchNormalization partial statistics per
 // 128-row tile (same tile index as the single-pass kernel, so lisec_bn_finalize sees the same layout)
-// ROWS rows x 64 channels per workgroup of ROWS * 8 threads.  ROWS = 128 (one 128-row tile: the layout of the per-tile
-// statistics table); ROWS = 32 otherwise: four times as many, four times lighter workgroups (256 threads, 8 KB of LDS) --
-// beside the weight-gradient kernels of the second stream the 1024-thread ones waited tens of microseconds for a CU
-// with 16 free wave slots.
+// ROWS rows x 64 channels per workgroup of ROWS * 8 threads.  ROWS = 128: one 128-row tile, the layout of the per-tile
+// statistics table.  (ROWS = 32 -- four times as many 256-thread workgroups -- was measured and dropped: no faster beside
+// the weight-gradient kernels of the second stream, and 17 -> 27 us alone on the 20 000-position layers: four times the
+// sink's atomic adds.)
 template <int ROWS>
 __global__ void __launch_bounds__(ROWS * 8)
 k_splitk_reduce(const float* __restrict__ partial, int nsplit, int M, int Cout, int CoutP,
@@ -1211,9 +1211,7 @@ extern "C" int lisec_conv_forward_ex(const lisec_conv_geom* c, const float* in, 
     if (sk) {
         g.sink.acc = static_cast<long long*>(sk->acc);
         g.sink.kind = sk->kind; g.sink.C = g.Cout; g.sink.unbiased = sk->unbiased_moving;
-        // one arrival per storing workgroup: every (tile, channel slab) once; the combine pass of K-sliced tiles runs four
-        // 32-row workgroups per tile
-        g.sink.total = ((unsigned)plan.tile0_tail + (unsigned)(ntiles - plan.tile0_tail) * (BM / 32)) * (unsigned)nnb;
+        g.sink.total = (unsigned)ntiles * (unsigned)nnb;          // every (tile, channel slab) stores exactly once
         g.sink.N = sk->n_rows;
         g.sink.gamma = sk->gamma; g.sink.beta = sk->beta; g.sink.mmean = sk->moving_mean; g.sink.mvar = sk->moving_var;
         g.sink.bnstate = sk->bnstate; g.sink.dgamma = sk->dgamma; g.sink.dbeta = sk->dbeta; g.sink.coef = sk->coef;
@@ -1323,15 +1321,9 @@ extern "C" int lisec_conv_forward_ex(const lisec_conv_geom* c, const float* in, 
         const int tail = ntiles - plan.tile0_tail;
         dim3 grid(tail, nnb, plan.nsplit);
         LISEC_IG_ANY(grid, plan.nsplit, partial, plan.tile0_tail);
-        if (table_stats) {
-            hipLaunchKernelGGL((k_splitk_reduce<BM>), dim3(tail, nnb), dim3(BM * 8), 0, st, partial, plan.nsplit, g.M, g.Cout,
-                               g.CoutP, bias, flags, out, g.out_stride, stats_partials, plan.tile0_tail, tail * BM, g.row_count,
-                               g.out_mask, g.pc_span, g.pc_rows, g.Wo, g.bwd_y, g.bwd_bn, g.bwd_relu, g.sink);
-        } else {
-            hipLaunchKernelGGL((k_splitk_reduce<32>), dim3(tail * (BM / 32), nnb), dim3(256), 0, st, partial, plan.nsplit, g.M,
-                               g.Cout, g.CoutP, bias, flags, out, g.out_stride, stats_partials, plan.tile0_tail, tail * BM,
-                               g.row_count, g.out_mask, g.pc_span, g.pc_rows, g.Wo, g.bwd_y, g.bwd_bn, g.bwd_relu, g.sink);
-        }
+        hipLaunchKernelGGL((k_splitk_reduce<BM>), dim3(tail, nnb), dim3(BM * 8), 0, st, partial, plan.nsplit, g.M, g.Cout,
+                           g.CoutP, bias, flags, out, g.out_stride, stats_partials, plan.tile0_tail, tail * BM, g.row_count,
+                           g.out_mask, g.pc_span, g.pc_rows, g.Wo, g.bwd_y, g.bwd_bn, g.bwd_relu, g.sink);
     }
 #undef LISEC_IG_ANY
 #undef LISEC_IH

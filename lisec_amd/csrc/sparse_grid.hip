@@ -16,18 +16,40 @@ namespace lisec {
 namespace {
 
 // per output line (d', h'): sums over w' of dy grouped by which kw taps are valid  -> line_s[line][kw][C]
+// APPLY: `dy` is still the gradient in front of the layer's BatchNormalization; the apply pass of its backward
+// (dy = scale * (dz - mean(dz) - yhat * mean(dz * yhat)), the arithmetic of k_bn_bwd_apply) runs on the way, the result is
+// stored to dy_out (may alias dy) and summed: one pass over the 82 MB map instead of two.
+template <bool APPLY>
 __global__ void __launch_bounds__(256)
-k_line_sums(ConvGeom g, const float* __restrict__ dy, float* __restrict__ line_s) {
+k_line_sums(ConvGeom g, const float* dy, float* __restrict__ line_s, const float* __restrict__ y,
+            const float* __restrict__ st, const float* __restrict__ coef, float* dy_out) {
     __shared__ float red[4][256][4];
     const int C = g.Cout, cq = C / 4;
     const int q = threadIdx.x % cq, wsub = threadIdx.x / cq, wlanes = 256 / cq;
     const int line = blockIdx.x;
+    float4 sc, mu, is, m1, m2;
+    if (APPLY) {
+        sc = reinterpret_cast<const float4*>(st)[q];
+        mu = reinterpret_cast<const float4*>(st + 2 * C)[q];
+        is = reinterpret_cast<const float4*>(st + 3 * C)[q];
+        m1 = reinterpret_cast<const float4*>(coef)[q];
+        m2 = reinterpret_cast<const float4*>(coef + C)[q];
+    }
     float4 acc[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) acc[k] = make_float4(0, 0, 0, 0);
-    const float* base = dy + (size_t)line * g.Wo * g.out_stride;
+    const size_t row0 = (size_t)line * g.Wo;
+    const float* base = dy + row0 * g.out_stride;
     for (int w = wsub; w < g.Wo; w += wlanes) {
-        const float4 v = *reinterpret_cast<const float4*>(base + (size_t)w * g.out_stride + q * 4);
+        float4 v = *reinterpret_cast<const float4*>(base + (size_t)w * g.out_stride + q * 4);
+        if (APPLY) {
+            const float4 yv = *reinterpret_cast<const float4*>(y + (row0 + w) * C + q * 4);
+            v.x = sc.x * (v.x - m1.x - (yv.x - mu.x) * is.x * m2.x);
+            v.y = sc.y * (v.y - m1.y - (yv.y - mu.y) * is.y * m2.y);
+            v.z = sc.z * (v.z - m1.z - (yv.z - mu.z) * is.z * m2.z);
+            v.w = sc.w * (v.w - m1.w - (yv.w - mu.w) * is.w * m2.w);
+            *reinterpret_cast<float4*>(dy_out + (row0 + w) * g.out_stride + q * 4) = v;
+        }
         const int b = (w << g.ls_w) - g.pw;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -140,23 +162,37 @@ extern "C" size_t lisec_conv_tap_sums_workspace_bytes(const lisec_conv_geom* c) 
     return align_up(sizeof(float) * (size_t)g.Do * g.Ho * g.KW * g.Cout, 256);
 }
 
-extern "C" int lisec_conv_tap_sums(const lisec_conv_geom* c, const float* dy, float* S, void* workspace,
-                                   size_t workspace_bytes, lisec_stream_t stream_) {
+extern "C" int lisec_conv_tap_sums_bn(const lisec_conv_geom* c, const float* dz, const float* y, const float* bnstate,
+                                      const float* coef, float* dy, float* S, void* workspace, size_t workspace_bytes,
+                                      lisec_stream_t stream_) {
     ConvGeom g;
     if (int rc = conv_geom_check(c, &g)) return rc;
-    LISEC_CHECK_ARG(c->mode == 0 && dy && S && workspace, "tap sums: mode-0 geometry and non-NULL pointers required");
+    LISEC_CHECK_ARG(c->mode == 0 && dz && S && workspace, "tap sums: mode-0 geometry and non-NULL pointers required");
     LISEC_CHECK_ARG(g.Cout % 4 == 0 && g.Cout <= 256 && 256 % (g.Cout / 4) == 0 && g.out_stride % 4 == 0,
                     "tap sums: Cout/4 must divide 256");
+    const bool apply = y != nullptr;
+    LISEC_CHECK_ARG(!apply || (bnstate && coef && dy && g.out_stride == g.Cout &&
+                               (((uintptr_t)y | (uintptr_t)bnstate | (uintptr_t)coef | (uintptr_t)dy) & 15) == 0),
+                    "tap sums with the BatchNormalization apply pass: y, bnstate, coef, dy (16-byte aligned), dense rows");
     if (workspace_bytes < lisec_conv_tap_sums_workspace_bytes(c)) {
         set_error("tap sums workspace too small");
         return LISEC_ENOSPC;
     }
     hipStream_t st = static_cast<hipStream_t>(stream_);
     float* line_s = static_cast<float*>(workspace);
-    hipLaunchKernelGGL(k_line_sums, dim3(g.Do * g.Ho), dim3(256), 0, st, g, dy, line_s);
+    if (apply)
+        hipLaunchKernelGGL(k_line_sums<true>, dim3(g.Do * g.Ho), dim3(256), 0, st, g, dz, line_s, y, bnstate, coef, dy);
+    else
+        hipLaunchKernelGGL(k_line_sums<false>, dim3(g.Do * g.Ho), dim3(256), 0, st, g, dz, line_s, (const float*)nullptr,
+                           (const float*)nullptr, (const float*)nullptr, (float*)nullptr);
     hipLaunchKernelGGL(k_tap_sums, dim3(g.KD * g.KH * g.KW), dim3(1024), 0, st, g, line_s, S);
     LISEC_LAUNCH_CHECK();
     return LISEC_OK;
+}
+
+extern "C" int lisec_conv_tap_sums(const lisec_conv_geom* c, const float* dy, float* S, void* workspace,
+                                   size_t workspace_bytes, lisec_stream_t stream_) {
+    return lisec_conv_tap_sums_bn(c, dy, nullptr, nullptr, nullptr, nullptr, S, workspace, workspace_bytes, stream_);
 }
 
 extern "C" int lisec_const_field_grads(const float* W, const float* S, const float* cvec, const int32_t* cvec_row,

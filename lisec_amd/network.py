@@ -137,6 +137,18 @@ class LisecNet:
         self.parts = torch.empty(max_parts, dtype=torch.float64, device=dev)
         self._sinks, self._bsinks = {}, {}
         self.early_pack = os.environ.get("LISEC_PACK_EARLY", "1") == "1"
+        # The second HIP stream.  Backward: weight gradients are leaves of the graph and run beside the BN-backward /
+        # data-gradient chain (the RPN layers are too small to fill 256 CUs on their own).  Forward and backward: the
+        # Conv2DTranspose branches of RPN blocks 1 and 2 (model_training.py:246,249) only meet the rest of the network at the
+        # concat, so they run beside the next block's small convolutions instead of in front of them.
+        # ROCm multiplexes same-priority streams onto a few hardware queues round-robin, so a plain second stream
+        # can land on the main stream's queue (it does once RCCL has made its own streams) and then nothing
+        # overlaps; a different priority level always gets its own hardware queue.
+        self.side = torch.cuda.Stream(device=dev, priority=int(os.environ.get("LISEC_SIDE_PRIORITY", "-1")))
+        self.branch_overlap = os.environ.get("LISEC_BRANCH_OVERLAP", "1") == "1"
+        # fork / join events with a device-scope release (LISEC_DEVICE_EVENTS=0: torch.cuda.Event, system-scope release)
+        self.device_events = os.environ.get("LISEC_DEVICE_EVENTS", "1") == "1"
+        self._fwd_events = {}
         self._packed_version = -1
         self.params_version = 0
         self.state_version = 0
@@ -204,14 +216,20 @@ class LisecNet:
                         p.view(c.bn + ".moving_variance"), C, self.bnstate[c.bn])
             self._folded[c.bn] = (self.params_version, self.state_version, p.version)
 
-    def _run_conv(self, c, x, out, training):
+    def _run_conv(self, c, x, out, training, ws_tag="main"):
         p = self.params
         flags = (ops.IN_RELU if c.in_relu else 0) | (ops.OUT_RELU if c.out_relu else 0)
         sink = self._fwd_sink(c) if (c.bn and training) else None
         ops.conv_forward(c.g, x, self.packed[c.name], out, bias=p.view(c.bias) if c.bias else None,
-                         in_bn=self.bnstate[c.in_bn] if c.in_bn else None, flags=flags, sink=sink)
+                         in_bn=self.bnstate[c.in_bn] if c.in_bn else None, flags=flags, sink=sink, ws_tag=ws_tag)
         if c.bn:
             self._bn_after(c, training)
+
+    def _event(self, name):
+        ev = self._fwd_events.get(name)
+        if ev is None:
+            ev = self._fwd_events[name] = self._new_event()
+        return ev
 
     def _new_event(self):
         return _lib.DeviceEvent() if getattr(self, "device_events", False) else torch.cuda.Event()
@@ -271,6 +289,7 @@ class LisecNet:
             # and ran under this sweep's voxeliser and VFE; the first contraction is the first reader
             self._wait(self._pack_done, torch.cuda.current_stream())
             self._pack_pending = False
+        side_used = False
         for L in self.layers:
             if L["kind"] == "mid":
                 n = L["name"]
@@ -289,7 +308,24 @@ class LisecNet:
                 self._run_conv(L["conv"], a[L["src"]], a[L["dst"]], training)
             else:
                 b = L["slot"]
-                self._run_conv(L["conv"], a[L["src"]], a["concat"][:, :, 256 * b:], training)
+                if self.branch_overlap and b < len(DECONVS) - 1:
+                    # an upsampling branch that is not the last: beside the next block, on the second stream
+                    main = torch.cuda.current_stream()
+                    fork = self._event("fwd_fork%d" % b)
+                    self._record(fork, main)
+                    self._wait(fork, self.side)
+                    pin = _lib.pin_stream(self.side.cuda_stream)
+                    try:
+                        self._run_conv(L["conv"], a[L["src"]], a["concat"][:, :, 256 * b:], training, ws_tag="side")
+                    finally:
+                        _lib.pin_stream(pin)
+                    side_used = True
+                else:
+                    self._run_conv(L["conv"], a[L["src"]], a["concat"][:, :, 256 * b:], training)
+        if side_used:
+            join = self._event("fwd_join")
+            self._record(join, self.side)
+            self._wait(join, torch.cuda.current_stream())
         ops.conv_forward(self.head_geom, a["concat"], self.packed["head"], a["head"], bias=self.head_b)
         head = a["head"]
         return head[None, :, :, :2], head[None, :, :, 2:]
@@ -370,17 +406,7 @@ class LisecNet:
         # gradient, instead of beside it on the second stream (measurement knob; they need a workspace of their own)
         self.mid_wgrad_main = os.environ.get("LISEC_MID_WGRAD", "side") == "main"
         self.fork_every = max(1, int(os.environ.get("LISEC_FORK_EVERY", "1")))
-        # fork events with a device-scope release (LISEC_DEVICE_EVENTS=0: torch.cuda.Event, system-scope release)
-        self.device_events = os.environ.get("LISEC_DEVICE_EVENTS", "1") == "1"
-        if torch.cuda.is_current_stream_capturing():
-            self.device_events = False
         self.wgrad_ws_main = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if self.mid_wgrad_main else None
-        # weight gradients are leaves of the backward graph: they run on a second HIP stream next to the
-        # BN-backward / data-gradient chain (the RPN layers are too small to fill 256 CUs on their own)
-        # ROCm multiplexes same-priority streams onto a few hardware queues round-robin, so a plain second stream
-        # can land on the main stream's queue (it does once RCCL has made its own streams) and then nothing
-        # overlaps; a different priority level always gets its own hardware queue.
-        self.side = torch.cuda.Stream(device=dev, priority=int(os.environ.get("LISEC_SIDE_PRIORITY", "-1")))
         self._packed_t_version = -1
         self._train_ready = True
 
@@ -510,7 +536,12 @@ class LisecNet:
         writes = {}                            # gradient buffer -> contributions stored so far
         bwd_ready = {}                         # gradient buffer -> partial rows of its BN-backward statistics
 
-        def dgrad_into(c, dy, dst_name):
+        early_dst = {}                         # gradient buffer -> event behind a contribution made on the second stream
+
+        def dgrad_into(c, dy, dst_name, ws_tag="main"):
+            ev = early_dst.pop(dst_name, None) if ws_tag == "main" else None
+            if ev is not None:
+                self._wait(ev, main)           # the branch's contribution is stored before this one accumulates onto it
             flags = ops.ACCUMULATE if dst_name in first_write else 0
             # the output of a middle block went through Dense(relu) (model_training.py:195): its gradient is gated
             # by that activation while the data gradient is stored (single consumer, so no ACCUMULATE there)
@@ -524,23 +555,43 @@ class LisecNet:
                 bwd, sink = (a[dst_name], self.bnstate[bn_name], True), self._bwd_sink(bn_name, C, a[dst_name].numel() // C)
                 bwd_ready[dst_name] = sink
             ops.conv_forward(self.dgeom[c.name], dy, self.packed_t[c.name][0], d[dst_name], flags=flags, out_mask=mask,
-                             bwd=bwd, sink=sink)
+                             bwd=bwd, sink=sink, ws_tag=ws_tag)
             first_write.add(dst_name)
+
+        def deconv_wgrad(L):
+            c = L["conv"]
+            dy = d["concat"][:, :, 256 * L["slot"]:]
+            if "wgeom" in L:
+                ops.conv_wgrad(L["wgeom"], dy, a[L["src"]], p.grad_view(G, c.wname), self.wgrad_ws,
+                               flags=ops.DY_RELU, dy_bn=self.bnstate[c.in_bn])
+            else:
+                ops.conv_wgrad(c.g, a[L["src"]], dy, p.grad_view(G, c.wname), self.wgrad_ws,
+                               in_bn=self.bnstate[c.in_bn], flags=ops.IN_RELU, transpose_out=True)
+
+        # the Conv2DTranspose branches of blocks 1 and 2 hang off the concat gradient, which is complete now: both of
+        # their gradients go to the second stream at once, beside the small layers of blocks 3 and 2, instead of waiting
+        # on the chain for their turn; the chain picks their contribution up where it reaches the block's last conv
+        early_layers = set()
+        if self.branch_overlap:
+            for L in layers:
+                if L["kind"] == "deconv" and L["slot"] < len(DECONVS) - 1:
+                    def branch(L=L):
+                        deconv_wgrad(L)
+                        dgrad_into(L["conv"], d["concat"][:, :, 256 * L["slot"]:], L["src"], ws_tag="side")
+                    on_side(branch)
+                    flush_side()
+                    ev = self._event("bwd_branch%d" % L["slot"])
+                    self._record(ev, self.side)
+                    early_dst[L["src"]] = ev
+                    early_layers.add(L["name"])
 
         for L in reversed(layers):
             c = L["conv"]
             if L["kind"] == "deconv":
-                b = L["slot"]
-                dy = d["concat"][:, :, 256 * b:]
-                if "wgeom" in L:
-                    on_side(lambda L=L, c=c, dy=dy: ops.conv_wgrad(
-                        L["wgeom"], dy, a[L["src"]], p.grad_view(G, c.wname), self.wgrad_ws,
-                        flags=ops.DY_RELU, dy_bn=self.bnstate[c.in_bn]))
-                else:
-                    on_side(lambda L=L, c=c, dy=dy: ops.conv_wgrad(
-                        c.g, a[L["src"]], dy, p.grad_view(G, c.wname), self.wgrad_ws,
-                        in_bn=self.bnstate[c.in_bn], flags=ops.IN_RELU, transpose_out=True))
-                dgrad_into(c, dy, L["src"])
+                if L["name"] in early_layers:
+                    continue
+                on_side(lambda L=L: deconv_wgrad(L))
+                dgrad_into(c, d["concat"][:, :, 256 * L["slot"]:], L["src"])
             elif L["kind"] == "conv":
                 dst = L["dst"]
                 C = c.g.Cout
@@ -577,15 +628,19 @@ class LisecNet:
                 msink = self._bwd_sink(c.bn, 64, c.M)
                 ops.conv_forward(self.dgeom[dn.name], d[n + ".u"], self.packed_t[dn.name][0], d[n + ".z"],
                                  bwd=(a[n + ".y"], self.bnstate[c.bn], False), sink=msink)
-                ops.bn_backward_apply_coef(d[n + ".z"], 64, a[n + ".y"], self.bnstate[c.bn], c.M, 64, False, msink.coef,
-                                           d[n + ".z"])
+                if L["src"] != "grid":
+                    ops.bn_backward_apply_coef(d[n + ".z"], 64, a[n + ".y"], self.bnstate[c.bn], c.M, 64, False, msink.coef,
+                                               d[n + ".z"])
                 if L["src"] == "grid":
                     # the grid is a constant on the empty cells + V voxel rows: both gradients reduce to V-row
                     # contractions plus sums of dy over boundary-trimmed boxes (exact; csrc/sparse_grid.hip)
                     rows = (sample.coords, sample.info, rcap)
                     dg = self.dgeom[c.name]
                     dW = p.grad_view(G, c.wname)
-                    ops.tap_sums(c.g, d[n + ".z"], self.mid1_S, self.tapsum_ws)
+                    # the apply pass of this block's BatchNormalization backward runs inside the line sums (one pass
+                    # over the 82 MB gradient instead of two)
+                    ops.tap_sums_bn(c.g, d[n + ".z"], a[n + ".y"], self.bnstate[c.bn], msink.coef, d[n + ".z"], self.mid1_S,
+                                    self.tapsum_ws)
                     ops.const_field_grads(p.view(c.wname), self.mid1_S, None, 27, 64, 64, g_all=self.g_all)
                     vout, delta = self.vfe.saved_field("vout"), self.vfe.saved_field("delta")
 
@@ -678,7 +733,7 @@ class CapturedStep:
         net._pack_pending = False
         net._prepare_training()
         # torch's capture only knows the events torch made: the forks go back to torch.cuda.Event
-        net.device_events, net._fork_events, net._join_event = False, [], None
+        net.device_events, net._fork_events, net._join_event, net._fwd_events = False, [], None, {}
         p = net.params
         keep = (p.theta.clone(), p.state.clone(), net.velocity.clone(), net._iter_dev.clone(), net._iterations,
                 net.params_version, net.state_version)

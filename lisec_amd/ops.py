@@ -95,14 +95,15 @@ def num_mblocks(g):
 _SPLITK_WS = {}
 
 
-def conv_workspace(g, device, row_capacity=0):
-    """Shared split-K scratch for `g` (None when the layer is large enough to run in one pass)."""
+def conv_workspace(g, device, row_capacity=0, tag="main"):
+    """Shared split-K scratch for `g` (None when the layer is large enough to run in one pass); one buffer per stream
+    role (tag): contractions that may run at the same time on two streams must not share their slabs."""
     lib = _lib.load()
     need = (lib.lisec_conv_forward_rows_workspace_bytes(ctypes.byref(g), row_capacity) if row_capacity > 0
             else lib.lisec_conv_forward_workspace_bytes(ctypes.byref(g)))
     if need == 0:
         return None
-    key = str(device)
+    key = (str(device), tag)
     if key not in _SPLITK_WS or _SPLITK_WS[key].numel() < need:
         _SPLITK_WS[key] = torch.empty(need, dtype=torch.uint8, device=device)
     return _SPLITK_WS[key]
@@ -130,14 +131,14 @@ class BnSink:
 
 
 def conv_forward(g, x, wp, out, bias=None, in_bn=None, flags=0, stats=None, splitk=True, rows=None, out_mask=None,
-                 bwd=None, sink=None):
+                 bwd=None, sink=None, ws_tag="main"):
     """rows: optional (row_coords int32 (cap,3), row_count int32 device scalar, capacity) row list.
     out_mask: optional tensor laid out like `out`; values are stored as 0 where out_mask <= 0.
     bwd: optional (y, bnstate, relu): `out` is a gradient about to cross that BatchNormalization(+ReLU) backwards and
     `stats` (num_mblocks_bwd(g) rows) receives the per-tile (sum dz, sum dz*yhat) -- see bn_backward_apply.
     sink: optional BnSink taking the per-tile sums instead of `stats` (finalised inside the call)."""
     rc, rn, cap = rows if rows is not None else (None, None, 0)
-    ws = conv_workspace(g, out.device, cap) if splitk else None
+    ws = conv_workspace(g, out.device, cap, ws_tag) if splitk else None
     ex = _lib.ConvExtras(_lib.ptr(out_mask), _lib.ptr(bwd[0]) if bwd is not None else None,
                          _lib.ptr(bwd[1]) if bwd is not None else None, 1 if (bwd is not None and bwd[2]) else 0,
                          sink.ref if sink is not None else None)
@@ -273,6 +274,13 @@ def conv_field_forward(g, vout, delta, sample, wp, out, workspace, bias=None, si
 def tap_sums(g, dy, S, workspace):
     _lib.check(_lib.load().lisec_conv_tap_sums(ctypes.byref(g), _lib.ptr(dy), _lib.ptr(S), _lib.ptr(workspace),
                                                workspace.numel() * workspace.element_size(), _lib.current_stream()))
+
+
+def tap_sums_bn(g, dz, y, bnstate, coef, dy, S, workspace):
+    """tap_sums fused with bn_backward_apply_coef(relu=False) in front of it: dy (may be dz) is written, S summed."""
+    _lib.check(_lib.load().lisec_conv_tap_sums_bn(ctypes.byref(g), _lib.ptr(dz), _lib.ptr(y), _lib.ptr(bnstate),
+                                                  _lib.ptr(coef), _lib.ptr(dy), _lib.ptr(S), _lib.ptr(workspace),
+                                                  workspace.numel() * workspace.element_size(), _lib.current_stream()))
 
 
 def tap_sums_workspace_bytes(g):

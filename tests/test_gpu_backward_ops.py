@@ -180,3 +180,45 @@ def test_bn_backward_in_place_without_bias(M, C, relu):
     _close(buf, y.grad, rtol=2e-4)
     _close(dg, gamma.grad, rtol=2e-4)
     _close(db, beta.grad, rtol=2e-4)
+
+
+@pytest.mark.parametrize("dims", [((8, 16, 24), (4, 16, 24), (2, 1, 1), (1, 1, 1)), ((4, 12, 40), (2, 12, 40), (1, 1, 1), (0, 1, 1))])
+def test_tap_sums_alone_and_fused_with_the_bn_backward_apply(dims):
+    """lisec_conv_tap_sums: S[tap][n] = sum of dy over the output positions whose tap reads inside the input map (a
+    torch transposed convolution of dy against ones, summed over space, is the same number); lisec_conv_tap_sums_bn:
+    the same sums over dy = bn_backward_apply_coef(dz) with dy written in place -- equal to the two separate calls."""
+    from lisec_amd import ops
+    ind, outd, stride, pad = dims
+    g = torch.Generator().manual_seed(23)
+    C = 64
+    geo = ops.geom(0, ind, outd, (3, 3, 3), stride, pad, C, C)
+    M = outd[0] * outd[1] * outd[2]
+    dz = torch.randn(M, C, generator=g).to(DEV)
+    y = (torch.randn(M, C, generator=g) * 1.5 + 0.2).to(DEV)
+    mean, var = y.mean(0), y.var(0, unbiased=False)
+    inv = torch.rsqrt(var + 1e-3)
+    gamma, beta = torch.rand(C, generator=g).to(DEV) + 0.5, torch.randn(C, generator=g).to(DEV)
+    st = torch.cat([gamma * inv, beta - mean * gamma * inv, mean, inv]).contiguous()
+    coef = torch.cat([dz.mean(0), (dz * (y - mean) * inv).mean(0)]).contiguous()
+    ws = torch.empty(ops.tap_sums_workspace_bytes(geo), dtype=torch.uint8, device=DEV)
+    want_dy = torch.empty_like(dz)
+    ops.bn_backward_apply_coef(dz, C, y, st, M, C, False, coef, want_dy)
+    S_sep = torch.empty(27, C, device=DEV)
+    ops.tap_sums(geo, want_dy, S_sep, ws)
+    # independent value: does tap (kd,kh,kw) of output position o read inside the map?
+    dyv = want_dy.double().cpu().reshape(*outd, C)
+    ref = torch.zeros(27, C, dtype=torch.float64)
+    for kd in range(3):
+        for kh in range(3):
+            for kw in range(3):
+                ok = [torch.tensor([0 <= o * s - p + k < n for o in range(no)])
+                      for k, s, p, n, no in zip((kd, kh, kw), stride, pad, ind, outd)]
+                m = ok[0][:, None, None] & ok[1][None, :, None] & ok[2][None, None, :]
+                ref[(kd * 3 + kh) * 3 + kw] = dyv[m].sum(0)
+    np.testing.assert_allclose(S_sep.cpu().numpy(), ref.numpy(), rtol=1e-5, atol=1e-4)
+    got = dz.clone()
+    S_fused = torch.empty(27, C, device=DEV)
+    ops.tap_sums_bn(geo, got, y, st, coef, got, S_fused, ws)
+    torch.cuda.synchronize()
+    assert torch.equal(got, want_dy)
+    assert torch.equal(S_fused, S_sep)
