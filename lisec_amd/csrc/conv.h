@@ -69,34 +69,51 @@ __device__ __forceinline__ void sink_finish(const BnSink& s) {
     __syncthreads();
     if (!sink_last) return;
     for (int c = threadIdx.x; c < s.C; c += blockDim.x) {
-        double v[2];
+        // every limb of every replica is requested before the first one is used: one round trip for the lot (read one
+        // after the other the 4 x 2 x 2 loads cost ~1 us per replica at the tail of every call that feeds a sink)
+        long long hi[2][kSinkReplicas], lo[2][kSinkReplicas];
+        float gam = 0.f, bet = 0.f, mm = 0.f, mv = 0.f;    // (and the per-channel parameters the result needs)
+        if (s.kind == 1) {
+            gam = s.gamma[c]; bet = s.beta[c];
+            if (s.mmean) { mm = s.mmean[c]; mv = s.mvar[c]; }
+        }
 #pragma unroll
         for (int which = 0; which < 2; ++which) {
-            long long hi = 0, lo = 0;
 #pragma unroll
             for (int r = 0; r < kSinkReplicas; ++r) {
                 long long* p = s.acc + ((size_t)(r * 2 + which) * s.C + c) * 2;
-                hi += __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                lo += __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                hi[which][r] = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                lo[which][r] = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        double v[2];
+#pragma unroll
+        for (int which = 0; which < 2; ++which) {
+            long long h = 0, l = 0;
+#pragma unroll
+            for (int r = 0; r < kSinkReplicas; ++r) {
+                h += hi[which][r];
+                l += lo[which][r];
+                long long* p = s.acc + ((size_t)(r * 2 + which) * s.C + c) * 2;
                 __hip_atomic_store(p, 0LL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(p + 1, 0LL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            v[which] = fx_join(hi, lo);
+            v[which] = fx_join(h, l);
         }
         if (s.kind == 1) {
             const double mean = v[0] / s.N;
             double var = v[1] / s.N - mean * mean;        // biased; fp64 so the cancellation is harmless
             if (var < 0.0) var = 0.0;
             const double inv = 1.0 / sqrt(var + 1e-3);    // kBnEps
-            const double scale = (double)s.gamma[c] * inv;
+            const double scale = (double)gam * inv;
             s.bnstate[c] = (float)scale;
-            s.bnstate[s.C + c] = (float)((double)s.beta[c] - mean * scale);
+            s.bnstate[s.C + c] = (float)((double)bet - mean * scale);
             s.bnstate[2 * s.C + c] = (float)mean;
             s.bnstate[3 * s.C + c] = (float)inv;
             if (s.mmean) {
                 const double u = s.unbiased && s.N > 1.0 ? var * (s.N / (s.N - 1.0)) : var;
-                s.mmean[c] = (float)((double)s.mmean[c] * 0.99 + mean * (1.0 - 0.99));       // kBnMomentum
-                s.mvar[c] = (float)((double)s.mvar[c] * 0.99 + u * (1.0 - 0.99));
+                s.mmean[c] = (float)((double)mm * 0.99 + mean * (1.0 - 0.99));       // kBnMomentum
+                s.mvar[c] = (float)((double)mv * 0.99 + u * (1.0 - 0.99));
             }
         } else {
             s.dbeta[c] = (float)v[0];
