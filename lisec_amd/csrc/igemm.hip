@@ -801,6 +801,134 @@ k_igemm_w(ConvGeom g, const float* __restrict__ in, const float* __restrict__ wp
     store_tile(g, acc0, acc1, smem, mw, n0, mb, mlimit, 0, wave, lane, tid, bias, flags, out, stats, nullptr, ks == 0);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Dense(64) on the last axis (model_training.py:195) and its data gradient: 1x1x1, 64 -> 64, row m reads position m.
+// One K step per tile, so k_igemm spends its time in phases (2500 workgroups load, then multiply, then store: 2.6 TB/s
+// on a layer that moves 164 / 246 MB).  Here 768 workgroups stay resident and walk the tiles: the weights sit in LDS for
+// the whole launch, the next tile's rows are requested before the current tile's MFMAs and stores, and the
+// BatchNormalization-backward sums of the data gradient stay in registers until the workgroup is done (ONE sink arrival
+// per workgroup instead of one per tile).
+//   XF:  BatchNormalization of the producer applied on load (forward: Dense reads BN(conv)), bias + optional ReLU on store
+//   BWD: (sum dz, sum dz * yhat) of the stored gradient for the BatchNormalization it is about to cross -> g.sink
+template <bool XF, bool BWD>
+__global__ void __launch_bounds__(kThreads)
+k_dense64(ConvGeom g, const float* __restrict__ in, const float* __restrict__ wp, const float* __restrict__ bias,
+          const float* __restrict__ in_bn, int flags, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sA = smem;
+    float* sB = smem + A_FLOATS;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ntiles = (g.M + BM - 1) / BM;
+    const int piece = tid & 15;
+    // the whole 64 x 64 kernel: packed [k/4][n][4], copied once
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        *reinterpret_cast<float4*>(sB + (i * 256 + tid) * 4) = *reinterpret_cast<const float4*>(wp + (i * 256 + tid) * 4);
+    float4 tsc = make_float4(1, 1, 1, 1), tsh = make_float4(0, 0, 0, 0);
+    if (XF) {
+        tsc = *reinterpret_cast<const float4*>(in_bn + piece * 4);
+        tsh = *reinterpret_cast<const float4*>(in_bn + 64 + piece * 4);
+    }
+    const float relu_lo = (flags & LISEC_CONV_IN_RELU) ? 0.f : -INFINITY;
+    const bool orelu = (flags & LISEC_CONV_OUT_RELU) != 0;
+    const int col = lane & 31;
+    const float biasA = bias ? bias[col] : 0.f, biasB = bias ? bias[32 + col] : 0.f;
+    float ysA = 1.f, yhA = 0.f, ymA = 0.f, yiA = 0.f, ysB = 1.f, yhB = 0.f, ymB = 0.f, yiB = 0.f;
+    if (BWD) {
+        ysA = g.bwd_bn[col]; yhA = g.bwd_bn[64 + col]; ymA = g.bwd_bn[128 + col]; yiA = g.bwd_bn[192 + col];
+        ysB = g.bwd_bn[32 + col]; yhB = g.bwd_bn[96 + col]; ymB = g.bwd_bn[160 + col]; yiB = g.bwd_bn[224 + col];
+    }
+    float sumA = 0.f, sqA = 0.f, sumB = 0.f, sqB = 0.f;
+
+    float4 ra[8];
+    auto issue = [&](int tile) {
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const int m = tile * BM + p * 16 + (tid >> 4);
+            const int mm = m < g.M ? m : 0;                       // rows beyond the layer read row 0 and are never stored
+            ra[p] = *reinterpret_cast<const float4*>(in + (size_t)mm * 64 + piece * 4);
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            float4 v = ra[p];
+            if (XF) {
+                v.x = fmaxf(fmaf(v.x, tsc.x, tsh.x), relu_lo); v.y = fmaxf(fmaf(v.y, tsc.y, tsh.y), relu_lo);
+                v.z = fmaxf(fmaf(v.z, tsc.z, tsh.z), relu_lo); v.w = fmaxf(fmaf(v.w, tsc.w, tsh.w), relu_lo);
+            }
+            *reinterpret_cast<float4*>(sA + (p * 16 + (tid >> 4)) * LDA + piece * 4) = v;
+        }
+    };
+    const float* aRow = sA + (wave * 32 + (lane & 31)) * LDA + 4 * (lane >> 5);
+    const float* bCol = sB + ((lane >> 5) * BN + (lane & 31)) * 4;
+
+    int tile = blockIdx.x;
+    if (tile < ntiles) issue(tile);
+    for (; tile < ntiles; tile += gridDim.x) {
+        __syncthreads();                                          // the previous tile's fragments have been read
+        stage();
+        __syncthreads();
+        const int next = tile + gridDim.x;
+        if (next < ntiles) issue(next);
+        f32x16 acc0 = {0}, acc1 = {0};
+#pragma unroll
+        for (int kc = 0; kc < BK / 8; ++kc) {
+            const float4 a = *reinterpret_cast<const float4*>(aRow + kc * 8);
+            const float4 b0 = *reinterpret_cast<const float4*>(bCol + kc * 2 * BN * 4);
+            const float4 b1 = *reinterpret_cast<const float4*>(bCol + kc * 2 * BN * 4 + 32 * 4);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1.x, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b0.y, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1.y, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b0.z, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b1.z, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b0.w, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b1.w, acc1, 0, 0, 0);
+        }
+        const int mw = tile * BM + wave * 32;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = mw + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (m < g.M) {
+                float va = acc0[r] + biasA, vb = acc1[r] + biasB;
+                if (orelu) { va = fmaxf(va, 0.f); vb = fmaxf(vb, 0.f); }
+                float* o = out + (size_t)m * 64;
+                o[col] = va;
+                o[32 + col] = vb;
+                if (BWD) {
+                    const float* yr = g.bwd_y + (size_t)m * 64;
+                    const float ya = yr[col], yb = yr[32 + col];
+                    const float da = (g.bwd_relu && !(fmaf(ya, ysA, yhA) > 0.f)) ? 0.f : va;
+                    const float db = (g.bwd_relu && !(fmaf(yb, ysB, yhB) > 0.f)) ? 0.f : vb;
+                    sumA += da; sqA = fmaf(da, (ya - ymA) * yiA, sqA);
+                    sumB += db; sqB = fmaf(db, (yb - ymB) * yiB, sqB);
+                }
+            }
+        }
+    }
+    if (BWD) {
+        __syncthreads();
+        float* red = smem;                                        // [4 waves][4][32]
+        sumA += __shfl_xor(sumA, 32, 64); sqA += __shfl_xor(sqA, 32, 64);
+        sumB += __shfl_xor(sumB, 32, 64); sqB += __shfl_xor(sqB, 32, 64);
+        if (lane < 32) {
+            red[(wave * 4 + 0) * 32 + lane] = sumA; red[(wave * 4 + 1) * 32 + lane] = sqA;
+            red[(wave * 4 + 2) * 32 + lane] = sumB; red[(wave * 4 + 3) * 32 + lane] = sqB;
+        }
+        __syncthreads();
+        if (tid < 128) {
+            const int q = tid >> 5, c = tid & 31;                // q: 0 sumA, 1 sqA, 2 sumB, 3 sqB
+            double v = 0.0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v += (double)red[(k * 4 + q) * 32 + c];
+            sink_add(g.sink, q & 1, (q >> 1) * 32 + c, v);
+        }
+        sink_finish(g.sink);
+    }
+}
+
 // all layers of the network in ONE launch: table of descriptors in device memory, element index -> layer by
 // a search over the running element offsets
 __global__ void k_pack_weights_batched(const lisec_pack_desc* __restrict__ tab, int n, long long total) {
@@ -1270,6 +1398,22 @@ extern "C" int lisec_conv_forward_ex(const lisec_conv_geom* c, const float* in, 
             hipLaunchKernelGGL((k_igemm<1, false, 1>), grid, dim3(kThreads), lds, st, g, in, packed_w, bias, in_bnstate,
                                flags, out, stats_partials, 1, (float*)nullptr, 0);
         }
+        LISEC_LAUNCH_CHECK();
+        return LISEC_OK;
+    }
+    // Dense(64) and its data gradient: the resident-workgroup kernel (LISEC_DENSE64=0: the generic path)
+    static const bool dense64 = [] { const char* e = getenv("LISEC_DENSE64"); return !e || atoi(e) != 0; }();
+    if (dense64 && g.pointwise && g.Cin == 64 && g.Cout == 64 && g.in_stride == 64 && g.out_stride == 64 && !g.row_coords &&
+        !g.out_mask && !(flags & (LISEC_CONV_ACCUMULATE | LISEC_CONV_TAG_ROOFLINE)) && !table_stats &&
+        (!sk || (sk->kind == LISEC_SINK_BACKWARD && bwd_stats)) && !(bwd_stats && !sk) && ntiles >= resident_slots()) {
+        const int wgs = resident_slots();
+        if (sk) g.sink.total = (unsigned)wgs;
+        const bool xf_bn = in_bnstate != nullptr;
+#define LISEC_D64(X_, B_) hipLaunchKernelGGL((k_dense64<X_, B_>), dim3(wgs), dim3(kThreads), lds, st, g, in, packed_w, bias, \
+        in_bnstate, flags, out)
+        if (bwd_stats) { if (xf_bn) LISEC_D64(true, true); else LISEC_D64(false, true); }
+        else           { if (xf_bn) LISEC_D64(true, false); else LISEC_D64(false, false); }
+#undef LISEC_D64
         LISEC_LAUNCH_CHECK();
         return LISEC_OK;
     }
