@@ -310,11 +310,14 @@ extern "C" int lisec_conv_field_forward(const lisec_conv_geom* c, const float* v
                         (sk->moving_mean == nullptr) == (sk->moving_var == nullptr),
                         "field conv: a forward bn sink needs accumulators, gamma/beta/bnstate");
     }
-    static const int seg_target = [] {
+    // whole lines for small sweeps (800 workgroups feed the sink instead of 3200: 23 -> 6 us of atomics); big sweeps
+    // have crowded lines next to empty ones, there two segments per line balance the pass (84 000 voxels: 328 -> 270 us)
+    static const int seg_env = [] {
         const char* e = std::getenv("LISEC_FIELD_SEG");
         const int v = e ? std::atoi(e) : 0;
-        return v >= 16 && v <= 1024 ? v : 512;      // whole lines: 800 workgroups feed the sink instead of 3200 (23 -> 6 us)
+        return v >= 16 && v <= 1024 ? v : 0;
     }();
+    const int seg_target = seg_env ? seg_env : (row_capacity > 65536 ? 256 : 512);
     const int nseg = cdiv(g.Wo, seg_target), seg_len = cdiv(g.Wo, nseg);
     const int LW = (seg_len - 1) * (1 << g.ls_w) + g.KW;
     const int nblocks = g.Do * g.Ho * nseg;
