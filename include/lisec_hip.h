@@ -282,6 +282,11 @@ typedef struct lisec_conv_extras {
     const float* bwd_bnstate;
     int bwd_relu;
     const lisec_bn_sink* sink;
+    /* optional, row-list calls: int32[2] device words, ZERO before the first use (every call leaves them zero).  With them a
+     * row list whose capacity is large (>= 768 tiles of 128 rows) and whose Cout <= 64 runs as resident workgroups that
+     * draw their tiles from a counter -- the tiles of a row list do very unequal work (rows beyond the device-side count,
+     * depth parity), which one workgroup per tile turns into idle CUs. */
+    int32_t* queue;
 } lisec_conv_extras;
 int lisec_conv_num_mblocks_bwd(const lisec_conv_geom* g);
 int lisec_conv_forward_ex(const lisec_conv_geom* g, const float* in, const float* packed_w, const float* bias,

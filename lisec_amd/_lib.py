@@ -39,7 +39,7 @@ class BnSinkDesc(ctypes.Structure):           # lisec_bn_sink
 
 class ConvExtras(ctypes.Structure):           # lisec_conv_extras
     _fields_ = [("out_mask", ctypes.c_void_p), ("bwd_y", ctypes.c_void_p), ("bwd_bnstate", ctypes.c_void_p),
-                ("bwd_relu", ctypes.c_int), ("sink", POINTER(BnSinkDesc))]
+                ("bwd_relu", ctypes.c_int), ("sink", POINTER(BnSinkDesc)), ("queue", ctypes.c_void_p)]
 
 
 class CopyDesc(Structure):                     # lisec_copy_desc

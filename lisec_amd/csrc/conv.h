@@ -41,6 +41,8 @@ struct ConvGeom {
     // whole numbers of tiles, plane_tiles each; the grid has half as many workgroups) -- equal work per workgroup when the
     // planes of a strided / transposed Conv3D run different numbers of taps
     int plane_tiles, plane_pair;
+    // row lists over a big capacity: k_igemm's resident workgroups draw tiles from queue[0] (see k_igemm); else nullptr
+    int* queue;
     // optional BatchNormalization-backward statistics of the stored gradient (see lisec_conv_extras): the per-tile
     // partials become (sum dz, sum dz*yhat) with dz = stored value * (relu ? bn(y) > 0 : 1), yhat = (y - mean)*invstd
     const float* bwd_y;      // (positions, Cout) raw conv output of the layer the gradient belongs to, row stride Cout

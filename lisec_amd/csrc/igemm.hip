@@ -166,21 +166,17 @@ __device__ __forceinline__ void store_tile(const ConvGeom& g, const f32x16& acc0
     }
 }
 
-// TAG only changes the symbol name: bench.py launches the dominant layer through k_igemm<0,false,1> so that its
-// row in a rocprofv3 --stats summary is that layer alone (same code as TAG 0).
-template <int MODE, bool XF, int TAG = 0>
-__global__ void __launch_bounds__(kThreads)
-k_igemm(ConvGeom g, const float* __restrict__ in, const float* __restrict__ wp,
-        const float* __restrict__ bias, const float* __restrict__ in_bn, int flags,
-        float* __restrict__ out, double* __restrict__ stats, int nsplit, float* __restrict__ partial, int tile0) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+template <int MODE, bool XF>
+__device__ __forceinline__ void
+igemm_tile(const ConvGeom& g, const float* __restrict__ in, const float* __restrict__ wp,
+           const float* __restrict__ bias, const float* __restrict__ in_bn, int flags,
+           float* __restrict__ out, double* __restrict__ stats, int nsplit, float* __restrict__ partial, int tile0,
+           int mb, float* smem, unsigned long long* stamps, unsigned stamp_wg) {
     float* sA = smem;
     float* sB = smem + A_FLOATS;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // XCD-aware tile order: consecutive M tiles (which share halo rows) stay on one XCD's L2
-    const int mb = tile0 + xcd_remap(blockIdx.x, gridDim.x);
     const int m0 = mb * BM;
     const int n0 = blockIdx.y * BN;
     const int mlimit = row_limit(g);
@@ -318,12 +314,16 @@ k_igemm(ConvGeom g, const float* __restrict__ in, const float* __restrict__ wp,
         return s < s_end ? s : nsteps;
     };
     int s = advance_to(s_begin);
+    IGEMM_STAMP(1);
     if (s < nsteps) {
         issue_loads(s);
         store_lds();
     }
     __syncthreads();
+    IGEMM_STAMP(2);
+    int stamp_steps = 0;
     while (s < nsteps) {
+        ++stamp_steps;
         const int snext = advance_to(s + 1);
         if (snext < nsteps) issue_loads(snext);
         // software-pipelined fragment reads: the ds_reads of chunk kc+1 are issued BEFORE the 8 MFMAs of chunk kc
@@ -357,8 +357,59 @@ k_igemm(ConvGeom g, const float* __restrict__ in, const float* __restrict__ wp,
         __syncthreads();
         s = snext;
     }
-
+    IGEMM_STAMP(3);
     store_tile(g, acc0, acc1, smem, m0 + wave * 32, n0, mb, mlimit, tile0, wave, lane, tid, bias, flags, out, stats, partial);
+    IGEMM_STAMP(4);
+    if (stamps && threadIdx.x == 0 && stamp_wg < 8192) stamps[(size_t)stamp_wg * 8 + 5] = (unsigned long long)stamp_steps;
+}
+
+// TAG only changes the symbol name: bench.py launches a layer through k_igemm<.., 1> so that its row in a rocprofv3
+// --stats summary is that layer alone (same code as TAG 0).
+// k_igemm_queue (row lists over a big capacity, g.queue): 768 resident workgroups that DRAW their tiles from a counter
+// instead of owning one each.  The tiles of a row list run 0 / 9 / 18 steps (rows beyond the device-side count, depth
+// parity of the voxels) and the dispatcher waits for the CU whose turn it is, so one workgroup per tile kept 3/4 of the
+// slots empty (84 000 voxels: starts spread over 183 us, 278 us for 82 us of work).  queue[0] = next tile, queue[1] =
+// workgroups that have drawn past the end; the last of those leaves both zero for the next call.
+template <int MODE, bool XF, int TAG = 0>
+__global__ void __launch_bounds__(kThreads)
+k_igemm(ConvGeom g, const float* __restrict__ in, const float* __restrict__ wp,
+        const float* __restrict__ bias, const float* __restrict__ in_bn, int flags,
+        float* __restrict__ out, double* __restrict__ stats, int nsplit, float* __restrict__ partial, int tile0) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    unsigned long long* stamps = g_igemm_stamps;
+    const unsigned stamp_wg = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    IGEMM_STAMP(0);
+    // XCD-aware tile order: consecutive M tiles (which share halo rows) stay on one XCD's L2
+    igemm_tile<MODE, XF>(g, in, wp, bias, in_bn, flags, out, stats, nsplit, partial, tile0,
+                         tile0 + xcd_remap(blockIdx.x, gridDim.x), smem, stamps, stamp_wg);
+}
+
+// The same tiles DRAWN from a counter by 768 resident workgroups (a kernel of its own: wrapped in the loop the tile code
+// needs 60 more registers and drops to two waves per SIMD, which the one-tile-per-workgroup launches must not pay).
+template <int MODE, bool XF>
+__global__ void __launch_bounds__(kThreads)
+k_igemm_queue(ConvGeom g, const float* __restrict__ in, const float* __restrict__ wp,
+              const float* __restrict__ bias, const float* __restrict__ in_bn, int flags, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ int drawn;
+    unsigned long long* stamps = g_igemm_stamps;
+    const unsigned stamp_wg = blockIdx.x;
+    IGEMM_STAMP(0);
+    const int ntiles = (row_limit(g) + BM - 1) / BM;              // tiles that hold rows (device-side count)
+    for (;;) {
+        if (threadIdx.x == 0) drawn = atomicAdd(g.queue, 1);
+        __syncthreads();
+        const int tile = drawn;
+        __syncthreads();                                           // (`drawn` is rewritten by the next draw)
+        if (tile >= ntiles) break;
+        igemm_tile<MODE, XF>(g, in, wp, bias, in_bn, flags, out, nullptr, 1, nullptr, 0, tile, smem, stamps, stamp_wg);
+        __syncthreads();                                           // the epilogue's scratch is the next tile's staging area
+    }
+    if (threadIdx.x == 0 && atomicAdd(g.queue + 1, 1) == (int)gridDim.x - 1) {
+        // every workgroup has drawn its last (out-of-range) index: nobody draws again
+        __hip_atomic_store(g.queue, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(g.queue + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1114,7 +1165,7 @@ int conv_geom_check(const lisec_conv_geom* c, ConvGeom* g) {
     g->pc_span = 0; g->pc_rows = 0;
     g->bwd_y = nullptr; g->bwd_bn = nullptr; g->bwd_relu = 0;
     g->sink.acc = nullptr;
-    g->plane_tiles = 0; g->plane_pair = 0;
+    g->plane_tiles = 0; g->plane_pair = 0; g->queue = nullptr;
     g->pointwise = c->KD * c->KH * c->KW == 1 && ld == 0 && lh == 0 && lw == 0 && c->pd == 0 && c->ph == 0 && c->pw == 0 &&
                    c->Di == c->Do && c->Hi == c->Ho && c->Wi == c->Wo;
     return 0;
@@ -1288,7 +1339,7 @@ extern "C" int lisec_conv_forward_masked(const lisec_conv_geom* c, const float* 
                                          const float* out_mask, double* stats_partials, void* workspace,
                                          size_t workspace_bytes, const int32_t* row_coords,
                                          const int32_t* row_count, int row_capacity, lisec_stream_t stream_) {
-    lisec_conv_extras ex = {out_mask, nullptr, nullptr, 0, nullptr};
+    lisec_conv_extras ex = {out_mask, nullptr, nullptr, 0, nullptr, nullptr};
     return lisec_conv_forward_ex(c, in, packed_w, bias, in_bnstate, flags, out, &ex, stats_partials, workspace,
                                  workspace_bytes, row_coords, row_count, row_capacity, stream_);
 }
@@ -1336,6 +1387,11 @@ extern "C" int lisec_conv_forward_ex(const lisec_conv_geom* c, const float* in, 
     ConvPlan plan = make_conv_plan(g);
     if (!workspace || workspace_bytes < plan.ws_bytes) { plan.tile0_tail = cdiv(g.M, BM); plan.nsplit = 1; }
     const int ntiles = cdiv(g.M, BM), nnb = g.CoutP / BN;
+    if (row_coords && extras && extras->queue && nnb == 1 && ntiles >= resident_slots() && !stats_partials && !g.out_mask &&
+        !(flags & LISEC_CONV_TAG_ROOFLINE)) {
+        g.queue = extras->queue;                     // one un-sliced launch of resident workgroups drawing tiles
+        plan.tile0_tail = ntiles; plan.nsplit = 1;
+    }
     if (sk) {
         g.sink.acc = static_cast<long long*>(sk->acc);
         g.sink.kind = sk->kind; g.sink.C = g.Cout; g.sink.unbiased = sk->unbiased_moving;
@@ -1455,6 +1511,16 @@ extern "C" int lisec_conv_forward_ex(const lisec_conv_geom* c, const float* in, 
         } else LISEC_IG_ALL(GRID_, NS_, PART_, T0_);                                                           \
     } while (0)
     if (!halo) g.plane_pair = 0;
+    if (g.queue) {
+        dim3 grid(resident_slots(), 1, 1);
+#define LISEC_IQ(M_, X_) hipLaunchKernelGGL((k_igemm_queue<M_, X_>), grid, dim3(kThreads), lds, st, g, in, packed_w, bias, \
+        in_bnstate, flags, out)
+        if (c->mode == 0) { if (xf) LISEC_IQ(0, true); else LISEC_IQ(0, false); }
+        else              { if (xf) LISEC_IQ(1, true); else LISEC_IQ(1, false); }
+#undef LISEC_IQ
+        LISEC_LAUNCH_CHECK();
+        return LISEC_OK;
+    }
     if (plan.tile0_tail > 0) {                       // whole rounds, single pass
         dim3 grid(g.plane_pair ? launch_tiles : plan.tile0_tail, nnb, 1);
         LISEC_IG_ANY(grid, 1, (float*)nullptr, 0);

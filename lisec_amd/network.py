@@ -382,6 +382,7 @@ class LisecNet:
         self.g_all = torch.empty(64, dtype=f32, device=dev)
         self.tapsum_ws = torch.empty(ops.tap_sums_workspace_bytes(first.g), dtype=torch.uint8, device=dev)
         self.dout_rows = None
+        self.rows_queue = torch.zeros(2, dtype=torch.int32, device=dev)      # tile counter of the row-list data gradient
         self.head_dgeom = ops.geom(0, (1, Ho, Wo), (1, Ho, Wo), (1, 1, 1), (1, 1, 1), (0, 0, 0), 16, 768)
         self.packed_t["head"] = (torch.empty(ops.packed_floats(1, 16, 768), dtype=f32, device=dev), None)
         self.head_dw = torch.empty(768, 16, dtype=f32, device=dev)
@@ -649,7 +650,8 @@ class LisecNet:
                         ops.const_field_grads(None, self.mid1_S, vout, 27, 64, 64, dW=dW, cvec_row=sample.info,
                                               cvec_row_max=sample.cap)
                     on_side(sparse_wgrad)
-                    ops.conv_forward(dg, d[n + ".z"], self.packed_t[c.name][0], self.dout_rows, rows=rows)
+                    ops.conv_forward(dg, d[n + ".z"], self.packed_t[c.name][0], self.dout_rows, rows=rows,
+                                     queue=self.rows_queue)
                 else:
                     if self.mid_wgrad_main:
                         dgrad_into(c, d[n + ".z"], L["src"])

@@ -131,17 +131,19 @@ class BnSink:
 
 
 def conv_forward(g, x, wp, out, bias=None, in_bn=None, flags=0, stats=None, splitk=True, rows=None, out_mask=None,
-                 bwd=None, sink=None, ws_tag="main"):
+                 bwd=None, sink=None, ws_tag="main", queue=None):
     """rows: optional (row_coords int32 (cap,3), row_count int32 device scalar, capacity) row list.
     out_mask: optional tensor laid out like `out`; values are stored as 0 where out_mask <= 0.
     bwd: optional (y, bnstate, relu): `out` is a gradient about to cross that BatchNormalization(+ReLU) backwards and
     `stats` (num_mblocks_bwd(g) rows) receives the per-tile (sum dz, sum dz*yhat) -- see bn_backward_apply.
-    sink: optional BnSink taking the per-tile sums instead of `stats` (finalised inside the call)."""
+    sink: optional BnSink taking the per-tile sums instead of `stats` (finalised inside the call).
+    queue: optional int32[2] device tensor, zero before its first use: lets a big row list run as resident workgroups
+    that draw their tiles from a counter (lisec_conv_extras.queue)."""
     rc, rn, cap = rows if rows is not None else (None, None, 0)
     ws = conv_workspace(g, out.device, cap, ws_tag) if splitk else None
     ex = _lib.ConvExtras(_lib.ptr(out_mask), _lib.ptr(bwd[0]) if bwd is not None else None,
                          _lib.ptr(bwd[1]) if bwd is not None else None, 1 if (bwd is not None and bwd[2]) else 0,
-                         sink.ref if sink is not None else None)
+                         sink.ref if sink is not None else None, _lib.ptr(queue))
     _lib.check(_lib.load().lisec_conv_forward_ex(ctypes.byref(g), _lib.ptr(x), _lib.ptr(wp), _lib.ptr(bias),
                                                  _lib.ptr(in_bn), flags, _lib.ptr(out), ctypes.byref(ex),
                                                  _lib.ptr(stats), _lib.ptr(ws),

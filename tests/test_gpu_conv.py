@@ -284,3 +284,41 @@ def test_backward_statistics_folded_into_the_store(mode, stride, W, splitk):
         _close(got.reshape(M, Cg), want, rtol=1e-5)
         _close(dg1, dg0, rtol=1e-5)
         _close(db1, db0, rtol=1e-5)
+
+
+@pytest.mark.parametrize("count,capacity", [(700, 1000), (60000, 100000)])
+def test_row_list_data_gradient_and_the_tile_queue(count, capacity):
+    """lisec_conv_forward over a ROW LIST (the data gradient of the first Conv3D at the occupied cells only): rows of the
+    dense data gradient picked at the listed positions; rows beyond the device-side count stay untouched.  The big list
+    (>= 768 tiles of capacity) also runs with lisec_conv_extras.queue -- resident workgroups drawing tiles from a
+    counter -- which must give the same bits and leave the counter words zero."""
+    from lisec_amd import ops
+    g = torch.Generator().manual_seed(29)
+    C = 64
+    ind, outd, k, s, p = (8, 12, 20), (4, 12, 20), (3, 3, 3), (2, 1, 1), (1, 1, 1)
+    dg = ops.geom(1, outd, ind, k, s, p, C, C)                      # gradient wrt the conv's input: gathers from dz
+    dz = torch.randn(*outd, C, generator=g).to(DEV)
+    w = (torch.randn(27, C, C, generator=g) * 0.1).to(DEV)          # (tap, Cin, Cout) of the forward layer
+    wt = ops.pack_weights(w, 27, C, C, C * C, 1, C)                 # transposed: K = Cout, N = Cin
+    dense = torch.empty(*ind, C, device=DEV)
+    ops.conv_forward(dg, dz, wt, dense)
+    cells = torch.randint(0, ind[0] * ind[1] * ind[2], (count,), generator=g).sort().values
+    coords = torch.stack([cells // (ind[1] * ind[2]), (cells // ind[2]) % ind[1], cells % ind[2]], 1).int()
+    coords_dev = torch.zeros(capacity, 3, dtype=torch.int32, device=DEV)
+    coords_dev[:count] = coords.to(DEV)
+    n = torch.tensor([count], dtype=torch.int32, device=DEV)
+    want = dense.reshape(-1, C)[cells.to(DEV)]
+    out = torch.full((capacity, C), 7.0, device=DEV)
+    ops.conv_forward(dg, dz, wt, out, rows=(coords_dev, n, capacity))
+    _close(out[:count], want, rtol=1e-5)
+    assert (out[count:] == 7.0).all()
+    queue = torch.zeros(2, dtype=torch.int32, device=DEV)
+    for _ in range(2):                                              # twice: the first call must leave the counter zero
+        out_q = torch.full((capacity, C), 7.0, device=DEV)
+        ops.conv_forward(dg, dz, wt, out_q, rows=(coords_dev, n, capacity), queue=queue)
+        torch.cuda.synchronize()
+        assert (queue == 0).all()
+        if capacity >= 768 * 128:
+            assert torch.equal(out_q, out)                          # same tiles, same arithmetic
+        else:
+            _close(out_q[:count], want, rtol=1e-5)
