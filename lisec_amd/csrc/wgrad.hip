@@ -42,8 +42,13 @@ k_wgrad(ConvGeom g, const float* __restrict__ in, const float* __restrict__ in_b
     const int HW = g.Ho * g.Wo;
     const int mlimit = row_limit(g);
     const int ntiles = (mlimit + BMW - 1) / BMW;
-    const int t_begin = split * tiles_per_split;
-    const int t_end = t_begin + tiles_per_split < ntiles ? t_begin + tiles_per_split : ntiles;
+    // dense rows: split s owns the tiles [s * tiles_per_split, ...).  Row lists: the launch is sized for the CAPACITY but
+    // only the tiles below the device-side count hold rows, so split s takes tiles s, s + nsplit, s + 2 nsplit, ... --
+    // every split gets its share of the live tiles whatever their number (84 000 of 200 000 rows: contiguous ranges left
+    // 58 % of the workgroups without a row and 14 tiles to each of the others)
+    const int ts = RL ? nsplit : 1;
+    const int t_begin = RL ? split : split * tiles_per_split;
+    const int t_end = RL ? ntiles : (t_begin + tiles_per_split < ntiles ? t_begin + tiles_per_split : ntiles);
     const int kd = tap0 / (g.KH * g.KW), kh = (tap0 / g.KW) % g.KH, kw0 = tap0 % g.KW;
 
     const int piece = tid & 15;
@@ -147,7 +152,7 @@ k_wgrad(ConvGeom g, const float* __restrict__ in, const float* __restrict__ in_b
             if (tile < t_end) decode_rows(tile);
             return tile;
         }
-        for (; tile < t_end; ++tile) {
+        for (; tile < t_end; tile += ts) {
             decode_rows(tile);
             int pred = 0;
 #pragma unroll
@@ -170,7 +175,7 @@ k_wgrad(ConvGeom g, const float* __restrict__ in, const float* __restrict__ in_b
         int ntile = tile, nt = t + 1;
         if (nt == TG) {
             nt = 0;
-            ntile = first_live(ntile + 1);
+            ntile = first_live(ntile + ts);
         }
         const bool more = ntile < t_end;
         if (more) {
