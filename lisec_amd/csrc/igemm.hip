@@ -54,7 +54,9 @@ __device__ unsigned long long* g_igemm_stamps = nullptr;
 __device__ __forceinline__ void store_tile(const ConvGeom& g, const f32x16& acc0, const f32x16& acc1, float* smem,
                                            int mw, int n0, int mb, int mlimit, int tile0, int wave, int lane, int tid,
                                            const float* __restrict__ bias, int flags, float* __restrict__ out,
-                                           double* __restrict__ stats, float* __restrict__ partial, bool storer = true) {
+                                           double* __restrict__ stats, float* __restrict__ partial, bool storer = true,
+                                           bool half = false) {
+    // half: the workgroup computed a 32-column slab (acc1 is unused): the second 32 columns are treated as outside Cout
     const int col = lane & 31;
     if (partial) {
         // slabs cover the rows of tiles tile0 .. (the tail of the layer, or all of it)
@@ -71,7 +73,7 @@ __device__ __forceinline__ void store_tile(const ConvGeom& g, const f32x16& acc0
         }
         return;
     }
-    const int nA = n0 + col, nB = n0 + 32 + col;
+    const int nA = n0 + col, nB = half ? g.Cout : n0 + 32 + col;
     // pixel-shuffle store (kernel == stride transposed conv): the 64-column slab lies inside one tap
     const int ps_tap = g.ps ? n0 / g.ps_channels : 0;
     const int ps_kh = g.ps ? ps_tap / g.ps : 0, ps_kw = g.ps ? ps_tap - ps_kh * g.ps : 0;
@@ -156,7 +158,7 @@ __device__ __forceinline__ void store_tile(const ConvGeom& g, const f32x16& acc0
             double v = 0.0;
 #pragma unroll
             for (int k = 0; k < 4; ++k) v += (double)red[(k * 4 + q) * 32 + c];
-            const int n = n0 + (q >> 1) * 32 + c;
+            const int n = (half && q >= 2) ? g.Cout : n0 + (q >> 1) * 32 + c;
             if (n < g.Cout) {
                 if (g.sink.acc) sink_add(g.sink, q & 1, n, v);
                 else stats[((size_t)mb * 2 + (q & 1)) * g.Cout + n] = v;
@@ -166,7 +168,9 @@ __device__ __forceinline__ void store_tile(const ConvGeom& g, const f32x16& acc0
     }
 }
 
-template <int MODE, bool XF>
+// NW: columns per workgroup, 64 or 32.  32 (one accumulator per wave, half a W slab) is what a layer of 160-380 tiles
+// runs instead of two K slices + a combine launch: twice the workgroups, every one over the whole K.
+template <int MODE, bool XF, int NW = 64>
 __device__ __forceinline__ void
 igemm_tile(const ConvGeom& g, const float* __restrict__ in, const float* __restrict__ wp,
            const float* __restrict__ bias, const float* __restrict__ in_bn, int flags,
@@ -178,7 +182,7 @@ igemm_tile(const ConvGeom& g, const float* __restrict__ in, const float* __restr
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m0 = mb * BM;
-    const int n0 = blockIdx.y * BN;
+    const int n0 = blockIdx.y * NW;
     const int mlimit = row_limit(g);
     if (m0 >= mlimit) return;                     // row list shorter than its capacity (whole workgroup)
     const int HW = g.Ho * g.Wo;
@@ -271,12 +275,18 @@ igemm_tile(const ConvGeom& g, const float* __restrict__ in, const float* __restr
             tsh = *reinterpret_cast<const float4*>(in_bn + g.Cin + cs);
         }
         const float* wb = wp + ((size_t)(tap * KpQ + cc * (BK / 4)) * g.CoutP + n0) * 4;
-        const float* wl = wb + (size_t)(tid >> 6) * g.CoutP * 4 + (tid & 63) * 4;
-        const size_t wstep = (size_t)4 * g.CoutP * 4;
-        rb0 = *reinterpret_cast<const float4*>(wl);
-        rb1 = *reinterpret_cast<const float4*>(wl + wstep);
-        rb2 = *reinterpret_cast<const float4*>(wl + 2 * wstep);
-        rb3 = *reinterpret_cast<const float4*>(wl + 3 * wstep);
+        if (NW == 64) {
+            const float* wl = wb + (size_t)(tid >> 6) * g.CoutP * 4 + (tid & 63) * 4;
+            const size_t wstep = (size_t)4 * g.CoutP * 4;
+            rb0 = *reinterpret_cast<const float4*>(wl);
+            rb1 = *reinterpret_cast<const float4*>(wl + wstep);
+            rb2 = *reinterpret_cast<const float4*>(wl + 2 * wstep);
+            rb3 = *reinterpret_cast<const float4*>(wl + 3 * wstep);
+        } else {                                                     // 16 k-quads x 32 columns: two float4 per thread
+            const float* wl = wb + (size_t)(tid >> 5) * g.CoutP * 4 + (tid & 31) * 4;
+            rb0 = *reinterpret_cast<const float4*>(wl);
+            rb1 = *reinterpret_cast<const float4*>(wl + (size_t)8 * g.CoutP * 4);
+        }
     };
     const float relu_lo = (flags & LISEC_CONV_IN_RELU) ? 0.f : -INFINITY;
     auto store_lds = [&]() {
@@ -295,16 +305,22 @@ igemm_tile(const ConvGeom& g, const float* __restrict__ in, const float* __restr
             }
             *reinterpret_cast<float4*>(sA + (p * 16 + (tid >> 4)) * LDA + piece * 4) = v;
         }
-        float* bl = sB + ((tid >> 6) * BN + (tid & 63)) * 4;
-        *reinterpret_cast<float4*>(bl) = rb0;
-        *reinterpret_cast<float4*>(bl + 4 * BN * 4) = rb1;
-        *reinterpret_cast<float4*>(bl + 8 * BN * 4) = rb2;
-        *reinterpret_cast<float4*>(bl + 12 * BN * 4) = rb3;
+        if (NW == 64) {
+            float* bl = sB + ((tid >> 6) * BN + (tid & 63)) * 4;
+            *reinterpret_cast<float4*>(bl) = rb0;
+            *reinterpret_cast<float4*>(bl + 4 * BN * 4) = rb1;
+            *reinterpret_cast<float4*>(bl + 8 * BN * 4) = rb2;
+            *reinterpret_cast<float4*>(bl + 12 * BN * 4) = rb3;
+        } else {
+            float* bl = sB + ((tid >> 5) * 32 + (tid & 31)) * 4;
+            *reinterpret_cast<float4*>(bl) = rb0;
+            *reinterpret_cast<float4*>(bl + 8 * 32 * 4) = rb1;
+        }
     };
 
     f32x16 acc0 = {0}, acc1 = {0};
     const float* aRow = sA + (wave * 32 + (lane & 31)) * LDA + 4 * (lane >> 5);
-    const float* bCol = sB + ((lane >> 5) * BN + (lane & 31)) * 4;
+    const float* bCol = sB + ((lane >> 5) * NW + (lane & 31)) * 4;
 
     // split-K: slice z of the (tap, channel-slab) step list; slices write raw partial tiles
     const int s_end = nsplit > 1 ? (int)(((long long)(blockIdx.z + 1) * nsteps) / nsplit) : nsteps;
@@ -331,24 +347,24 @@ igemm_tile(const ConvGeom& g, const float* __restrict__ in, const float* __restr
         // after the MFMAs, exposing ~100 cycles of LDS latency per 512 MFMA cycles)
         float4 a = *reinterpret_cast<const float4*>(aRow);
         float4 b0 = *reinterpret_cast<const float4*>(bCol);
-        float4 b1 = *reinterpret_cast<const float4*>(bCol + 32 * 4);
+        float4 b1 = NW == 64 ? *reinterpret_cast<const float4*>(bCol + 32 * 4) : b0;
 #pragma unroll
         for (int kc = 0; kc < BK / 8; ++kc) {
             float4 an = a, b0n = b0, b1n = b1;
             if (kc + 1 < BK / 8) {
                 an = *reinterpret_cast<const float4*>(aRow + (kc + 1) * 8);
-                b0n = *reinterpret_cast<const float4*>(bCol + (kc + 1) * 2 * BN * 4);
-                b1n = *reinterpret_cast<const float4*>(bCol + (kc + 1) * 2 * BN * 4 + 32 * 4);
+                b0n = *reinterpret_cast<const float4*>(bCol + (kc + 1) * 2 * NW * 4);
+                if (NW == 64) b1n = *reinterpret_cast<const float4*>(bCol + (kc + 1) * 2 * NW * 4 + 32 * 4);
             }
             __builtin_amdgcn_sched_barrier(0);                        // reads of chunk kc+1 stay above ...
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1.x, acc1, 0, 0, 0);
+            if (NW == 64) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1.x, acc1, 0, 0, 0);
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b0.y, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1.y, acc1, 0, 0, 0);
+            if (NW == 64) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1.y, acc1, 0, 0, 0);
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b0.z, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b1.z, acc1, 0, 0, 0);
+            if (NW == 64) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b1.z, acc1, 0, 0, 0);
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b0.w, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b1.w, acc1, 0, 0, 0);
+            if (NW == 64) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b1.w, acc1, 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);                        // ... the 8 MFMAs of chunk kc
             a = an; b0 = b0n; b1 = b1n;
         }
@@ -358,7 +374,8 @@ igemm_tile(const ConvGeom& g, const float* __restrict__ in, const float* __restr
         s = snext;
     }
     IGEMM_STAMP(3);
-    store_tile(g, acc0, acc1, smem, m0 + wave * 32, n0, mb, mlimit, tile0, wave, lane, tid, bias, flags, out, stats, partial);
+    store_tile(g, acc0, acc1, smem, m0 + wave * 32, n0, mb, mlimit, tile0, wave, lane, tid, bias, flags, out, stats, partial,
+               true, NW == 32);
     IGEMM_STAMP(4);
     if (stamps && threadIdx.x == 0 && stamp_wg < 8192) stamps[(size_t)stamp_wg * 8 + 5] = (unsigned long long)stamp_steps;
 }
@@ -370,7 +387,7 @@ igemm_tile(const ConvGeom& g, const float* __restrict__ in, const float* __restr
 // parity of the voxels) and the dispatcher waits for the CU whose turn it is, so one workgroup per tile kept 3/4 of the
 // slots empty (84 000 voxels: starts spread over 183 us, 278 us for 82 us of work).  queue[0] = next tile, queue[1] =
 // workgroups that have drawn past the end; the last of those leaves both zero for the next call.
-template <int MODE, bool XF, int TAG = 0>
+template <int MODE, bool XF, int TAG = 0, int NW = 64>
 __global__ void __launch_bounds__(kThreads)
 k_igemm(ConvGeom g, const float* __restrict__ in, const float* __restrict__ wp,
         const float* __restrict__ bias, const float* __restrict__ in_bn, int flags,
@@ -380,8 +397,8 @@ k_igemm(ConvGeom g, const float* __restrict__ in, const float* __restrict__ wp,
     const unsigned stamp_wg = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
     IGEMM_STAMP(0);
     // XCD-aware tile order: consecutive M tiles (which share halo rows) stay on one XCD's L2
-    igemm_tile<MODE, XF>(g, in, wp, bias, in_bn, flags, out, stats, nsplit, partial, tile0,
-                         tile0 + xcd_remap(blockIdx.x, gridDim.x), smem, stamps, stamp_wg);
+    igemm_tile<MODE, XF, NW>(g, in, wp, bias, in_bn, flags, out, stats, nsplit, partial, tile0,
+                             tile0 + xcd_remap(blockIdx.x, gridDim.x), smem, stamps, stamp_wg);
 }
 
 // The same tiles DRAWN from a counter by 768 resident workgroups (a kernel of its own: wrapped in the loop the tile code
@@ -426,7 +443,7 @@ k_igemm_queue(ConvGeom g, const float* __restrict__ in, const float* __restrict_
 constexpr int halo_rows(int nseg) { return BM + 2 * nseg; }     // segments + two halo columns each
 constexpr size_t halo_lds_bytes(int nseg) { return (size_t)(halo_rows(nseg) * LDA + B_FLOATS) * sizeof(float); }   // <= 52 832 B: 3 per CU
 
-template <int MODE, bool XF, int NSEG>
+template <int MODE, bool XF, int NSEG, int NW = 64>
 __device__ __forceinline__ void
 halo_tile(const ConvGeom& g, const float* __restrict__ in, const float* __restrict__ wp,
           const float* __restrict__ bias, const float* __restrict__ in_bn, int flags,
@@ -439,7 +456,7 @@ halo_tile(const ConvGeom& g, const float* __restrict__ in, const float* __restri
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m0 = mb * BM;
-    const int n0 = blockIdx.y * BN;
+    const int n0 = blockIdx.y * NW;
     const int mlimit = g.M;
 
     // ---- the (at most NSEG) output lines of this tile ----------------------------------------------
@@ -531,12 +548,18 @@ halo_tile(const ConvGeom& g, const float* __restrict__ in, const float* __restri
         }
         const int tap = (kd * g.KH + kh) * 3 + kw;
         const float* wb = wp + ((size_t)(tap * KpQ + cc * (BK / 4)) * g.CoutP + n0) * 4;
-        const float* wl = wb + (size_t)(tid >> 6) * g.CoutP * 4 + (tid & 63) * 4;
-        const size_t wstep = (size_t)4 * g.CoutP * 4;
-        rb0 = *reinterpret_cast<const float4*>(wl);
-        rb1 = *reinterpret_cast<const float4*>(wl + wstep);
-        rb2 = *reinterpret_cast<const float4*>(wl + 2 * wstep);
-        rb3 = *reinterpret_cast<const float4*>(wl + 3 * wstep);
+        if (NW == 64) {
+            const float* wl = wb + (size_t)(tid >> 6) * g.CoutP * 4 + (tid & 63) * 4;
+            const size_t wstep = (size_t)4 * g.CoutP * 4;
+            rb0 = *reinterpret_cast<const float4*>(wl);
+            rb1 = *reinterpret_cast<const float4*>(wl + wstep);
+            rb2 = *reinterpret_cast<const float4*>(wl + 2 * wstep);
+            rb3 = *reinterpret_cast<const float4*>(wl + 3 * wstep);
+        } else {                                                     // 16 k-quads x 32 columns: two float4 per thread
+            const float* wl = wb + (size_t)(tid >> 5) * g.CoutP * 4 + (tid & 31) * 4;
+            rb0 = *reinterpret_cast<const float4*>(wl);
+            rb1 = *reinterpret_cast<const float4*>(wl + (size_t)8 * g.CoutP * 4);
+        }
     };
     const float relu_lo = (flags & LISEC_CONV_IN_RELU) ? 0.f : -INFINITY;
     auto store_lds = [&]() {
@@ -557,18 +580,24 @@ halo_tile(const ConvGeom& g, const float* __restrict__ in, const float* __restri
                 if (j < HALO_MAX_ROWS) *reinterpret_cast<float4*>(sA + j * LDA + piece * 4) = v;
             }
         }
-        float* bl = sB + ((tid >> 6) * BN + (tid & 63)) * 4;
-        *reinterpret_cast<float4*>(bl) = rb0;
-        *reinterpret_cast<float4*>(bl + 4 * BN * 4) = rb1;
-        *reinterpret_cast<float4*>(bl + 8 * BN * 4) = rb2;
-        *reinterpret_cast<float4*>(bl + 12 * BN * 4) = rb3;
+        if (NW == 64) {
+            float* bl = sB + ((tid >> 6) * BN + (tid & 63)) * 4;
+            *reinterpret_cast<float4*>(bl) = rb0;
+            *reinterpret_cast<float4*>(bl + 4 * BN * 4) = rb1;
+            *reinterpret_cast<float4*>(bl + 8 * BN * 4) = rb2;
+            *reinterpret_cast<float4*>(bl + 12 * BN * 4) = rb3;
+        } else {
+            float* bl = sB + ((tid >> 5) * 32 + (tid & 31)) * 4;
+            *reinterpret_cast<float4*>(bl) = rb0;
+            *reinterpret_cast<float4*>(bl + 8 * 32 * 4) = rb1;
+        }
     };
 
     f32x16 acc0 = {0}, acc1 = {0};
     const int r_lane = wave * 32 + (lane & 31);
     const int seg_lane = r_lane < a ? 0 : 1 + (r_lane - a) / g.Wo;
     const float* aLane = sA + (r_lane + 2 * seg_lane) * LDA + 4 * (lane >> 5);
-    const float* bCol = sB + ((lane >> 5) * BN + (lane & 31)) * 4;
+    const float* bCol = sB + ((lane >> 5) * NW + (lane & 31)) * 4;
 
     // split-K: slice z of the (kd, kh, channel slab) list -- whole A tiles, three taps each
     const int nstage = ngroups * ncc;
@@ -595,24 +624,24 @@ halo_tile(const ConvGeom& g, const float* __restrict__ in, const float* __restri
         const float* aRow = aLane + (MODE == 0 ? kw : 2 - kw) * LDA;
         float4 av = *reinterpret_cast<const float4*>(aRow);
         float4 b0 = *reinterpret_cast<const float4*>(bCol);
-        float4 b1 = *reinterpret_cast<const float4*>(bCol + 32 * 4);
+        float4 b1 = NW == 64 ? *reinterpret_cast<const float4*>(bCol + 32 * 4) : b0;
 #pragma unroll
         for (int kc = 0; kc < BK / 8; ++kc) {
             float4 an = av, b0n = b0, b1n = b1;
             if (kc + 1 < BK / 8) {
                 an = *reinterpret_cast<const float4*>(aRow + (kc + 1) * 8);
-                b0n = *reinterpret_cast<const float4*>(bCol + (kc + 1) * 2 * BN * 4);
-                b1n = *reinterpret_cast<const float4*>(bCol + (kc + 1) * 2 * BN * 4 + 32 * 4);
+                b0n = *reinterpret_cast<const float4*>(bCol + (kc + 1) * 2 * NW * 4);
+                if (NW == 64) b1n = *reinterpret_cast<const float4*>(bCol + (kc + 1) * 2 * NW * 4 + 32 * 4);
             }
             __builtin_amdgcn_sched_barrier(0);
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b0.x, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b1.x, acc1, 0, 0, 0);
+            if (NW == 64) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b1.x, acc1, 0, 0, 0);
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b0.y, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b1.y, acc1, 0, 0, 0);
+            if (NW == 64) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b1.y, acc1, 0, 0, 0);
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b0.z, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b1.z, acc1, 0, 0, 0);
+            if (NW == 64) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b1.z, acc1, 0, 0, 0);
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b0.w, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b1.w, acc1, 0, 0, 0);
+            if (NW == 64) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b1.w, acc1, 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             av = an; b0 = b0n; b1 = b1n;
         }
@@ -622,7 +651,8 @@ halo_tile(const ConvGeom& g, const float* __restrict__ in, const float* __restri
         s = snext;
     }
     IGEMM_STAMP(3);
-    store_tile(g, acc0, acc1, smem, m0 + wave * 32, n0, mb, mlimit, tile0, wave, lane, tid, bias, flags, out, stats, partial);
+    store_tile(g, acc0, acc1, smem, m0 + wave * 32, n0, mb, mlimit, tile0, wave, lane, tid, bias, flags, out, stats, partial,
+               true, NW == 32);
     IGEMM_STAMP(4);
     if (stamps && threadIdx.x == 0 && stamp_wg < 8192) stamps[(size_t)stamp_wg * 8 + 5] = (unsigned long long)stamp_steps;
 }
@@ -632,7 +662,7 @@ halo_tile(const ConvGeom& g, const float* __restrict__ in, const float* __restri
 // gradient of the second middle block: 9 / 18 / 18 / 9 of 27 per plane); the hardware hands workgroups to the CUs in a
 // fixed rotation and waits for a slot on the CU whose turn it is, so a launch of mixed 9- and 18-step workgroups left
 // 40 % of the slots empty (tools/igemm_stamps.py).  Paired, every workgroup runs 27 steps.
-template <int MODE, bool XF, int TAG = 0, int NSEG = 2>
+template <int MODE, bool XF, int TAG = 0, int NSEG = 2, int NW = 64>
 __global__ void __launch_bounds__(kThreads)
 k_igemm_halo(ConvGeom g, const float* __restrict__ in, const float* __restrict__ wp,
              const float* __restrict__ bias, const float* __restrict__ in_bn, int flags,
@@ -643,14 +673,14 @@ k_igemm_halo(ConvGeom g, const float* __restrict__ in, const float* __restrict__
     IGEMM_STAMP(0);
     const int v = tile0 + xcd_remap(blockIdx.x, gridDim.x);
     if (!g.plane_pair) {
-        halo_tile<MODE, XF, NSEG>(g, in, wp, bias, in_bn, flags, out, stats, nsplit, partial, tile0, v, smem, stamps, stamp_wg);
+        halo_tile<MODE, XF, NSEG, NW>(g, in, wp, bias, in_bn, flags, out, stats, nsplit, partial, tile0, v, smem, stamps, stamp_wg);
         return;
     }
     const int q = v / g.plane_tiles, i = v - q * g.plane_tiles;
-    halo_tile<MODE, XF, NSEG>(g, in, wp, bias, in_bn, flags, out, stats, nsplit, partial, tile0,
+    halo_tile<MODE, XF, NSEG, NW>(g, in, wp, bias, in_bn, flags, out, stats, nsplit, partial, tile0,
                               2 * q * g.plane_tiles + i, smem, stamps, stamp_wg);
     __syncthreads();                                  // the epilogue's statistics scratch is the next tile's staging area
-    halo_tile<MODE, XF, NSEG>(g, in, wp, bias, in_bn, flags, out, stats, nsplit, partial, tile0,
+    halo_tile<MODE, XF, NSEG, NW>(g, in, wp, bias, in_bn, flags, out, stats, nsplit, partial, tile0,
                               (2 * q + 1) * g.plane_tiles + i, smem, stamps, stamp_wg);
 }
 
@@ -1511,6 +1541,27 @@ extern "C" int lisec_conv_forward_ex(const lisec_conv_geom* c, const float* in, 
         } else LISEC_IG_ALL(GRID_, NS_, PART_, T0_);                                                           \
     } while (0)
     if (!halo) g.plane_pair = 0;
+    // a layer that would run as two K slices + a combine launch (160-380 tiles): 32-column workgroups over the whole K
+    // instead -- as many workgroups, no slabs, no combine.  LISEC_HALF_N=0: the two slices.
+    static const bool half_n = [] { const char* e = getenv("LISEC_HALF_N"); return !e || atoi(e) != 0; }();
+    if (half_n && plan.nsplit == 2 && plan.tile0_tail == 0 && !g.queue) {
+        dim3 grid(ntiles, g.CoutP / 32, 1);
+        if (sk) g.sink.total = grid.x * grid.y;
+#define LISEC_HN(KERNEL_, LDS_) hipLaunchKernelGGL(KERNEL_, grid, dim3(kThreads), LDS_, st, g, in, packed_w, bias, in_bnstate, \
+        flags, out, stats_partials, 1, (float*)nullptr, 0)
+#define LISEC_HN_MX(M_, X_)                                                                            \
+        do {                                                                                           \
+            if (!halo) LISEC_HN((k_igemm<M_, X_, 0, 32>), lds);                                        \
+            else if (halo3) LISEC_HN((k_igemm_halo<M_, X_, 0, 3, 32>), lds_halo);                      \
+            else LISEC_HN((k_igemm_halo<M_, X_, 0, 2, 32>), lds_halo);                                 \
+        } while (0)
+        if (c->mode == 0) { if (xf) LISEC_HN_MX(0, true); else LISEC_HN_MX(0, false); }
+        else              { if (xf) LISEC_HN_MX(1, true); else LISEC_HN_MX(1, false); }
+#undef LISEC_HN_MX
+#undef LISEC_HN
+        LISEC_LAUNCH_CHECK();
+        return LISEC_OK;
+    }
     if (g.queue) {
         dim3 grid(resident_slots(), 1, 1);
 #define LISEC_IQ(M_, X_) hipLaunchKernelGGL((k_igemm_queue<M_, X_>), grid, dim3(kThreads), lds, st, g, in, packed_w, bias, \
