@@ -49,8 +49,8 @@ __device__ unsigned long long* g_igemm_stamps = nullptr;
 
 // Epilogue shared by the igemm kernels: raw K-slice slab, or bias (+accumulate, output gate, ReLU) store with the
 // per-tile BatchNormalization partial sums.  C layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
-// mw: first of the 32 rows this wave holds; storer: false for a wave whose accumulators were already folded into another
-// wave's (k_igemm_w) -- it only takes part in the statistics reduction, with zeros.
+// mw: first of the 32 rows this wave holds; storer: false for a wave that holds no rows of its own -- it only takes part
+// in the statistics reduction, with zeros.
 __device__ __forceinline__ void store_tile(const ConvGeom& g, const f32x16& acc0, const f32x16& acc1, float* smem,
                                            int mw, int n0, int mb, int mlimit, int tile0, int wave, int lane, int tid,
                                            const float* __restrict__ bias, int flags, float* __restrict__ out,
@@ -685,204 +685,6 @@ k_igemm_halo(ConvGeom g, const float* __restrict__ in, const float* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Wave-independent variant for layers with few output tiles (the RPN: 20 000 / 5 000 / 1 250 positions).  There a
-// 128-row workgroup grid cannot fill 1024 SIMDs, and slicing K over workgroups costs a slab round trip through HBM
-// plus a combine launch per layer (17 forward + 19 backward launches, 0.76 ms of a 5.1 ms step).  Here the K slices
-// live INSIDE the workgroup: wave (rg, ks) owns rows rg*32.. of a 32*RT-row tile and the ks-th of KS contiguous
-// slices of the (tap, channel slab) list, RT * KS = 4.  A wave stages its own 32 x 64 A slab in a private LDS
-// region and reads its W fragments straight from L2 in the packed [k/4][n][4] order (a wave-wide 16-byte load IS the
-// MFMA B fragment), so waves never wait for one another until the end, where the slices are summed through LDS in
-// slice order (deterministic) and wave (rg, 0) runs the usual epilogue.  No global partials, no combine launch.
-template <int MODE, bool XF, int KS>
-__global__ void __launch_bounds__(kThreads)
-k_igemm_w(ConvGeom g, const float* __restrict__ in, const float* __restrict__ wp,
-          const float* __restrict__ bias, const float* __restrict__ in_bn, int flags,
-          float* __restrict__ out, double* __restrict__ stats) {
-    constexpr int RT = 4 / KS;                   // 32-row groups per workgroup
-    constexpr int BMW = 32 * RT;                 // rows per workgroup
-    constexpr int WA = 32 * LDA;                 // floats of one wave's A slab
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int rg = wave % RT, ks = wave / RT;
-    float* sA = smem + wave * WA;
-    const int mb = xcd_remap(blockIdx.x, gridDim.x);
-    const int mw = mb * BMW + rg * 32;
-    const int n0 = blockIdx.y * BN;
-    const int mlimit = row_limit(g);
-    if (mb * BMW >= mlimit) return;              // (whole workgroup)
-    const int HW = g.Ho * g.Wo;
-
-    // ---- gather descriptors: lane r < 32 owns row mw + r; the 16 lanes that stage a row fetch it by shuffle --------
-    const int piece = lane & 15;
-    RowGather rows[8];
-    int tile_mask = 0;
-    {
-        const RowGather me = row_gather(g, mw + (lane & 31), MODE, 0);
-#pragma unroll
-        for (int p = 0; p < 8; ++p) {
-            const int src = p * 4 + (lane >> 4);
-            rows[p].off = __shfl(me.off, src, 64) + piece * 4;
-            rows[p].mask = __shfl(me.mask, src, 64);
-        }
-        if (g.row_coords) {
-            int m = me.mask;
-#pragma unroll
-            for (int o = 16; o > 0; o >>= 1) m |= __shfl_xor(m, o, 64);
-            tile_mask = m;
-        }
-    }
-    const int mlast = (mw + 31 < g.M ? mw + 31 : g.M - 1);
-    const int d_first = g.pc_span ? 0 : mw / HW, d_last = g.pc_span ? 0 : mlast / HW;
-    int dmask_first;
-    {
-        int tmp;
-        dmask_first = axis_mask(d_first, g.KD, g.ls_d, g.pd, g.Di, MODE, tmp);
-    }
-    const int ncc = (g.Cin + BK - 1) / BK;
-    const int ntaps = g.KD * g.KH * g.KW;
-    const int nsteps = ntaps * ncc;
-    const int KpQ = ncc * (BK / 4);
-    const int pclass = g.pc_span ? mw / g.pc_span : 0;
-    auto live = [&](int s) -> bool {
-        if (g.pc_span) {
-            const int tap = s / ncc, kw = tap % g.KW, kh = (tap / g.KW) % g.KH;
-            return (((pclass >> 1) + g.ph - kh) & 1) == 0 && (((pclass & 1) + g.pw - kw) & 1) == 0;
-        }
-        if (g.row_coords) {
-            const int tap = s / ncc, kw = tap % g.KW, kh = (tap / g.KW) % g.KH, kd = tap / (g.KW * g.KH);
-            const int tb = tap_bits(kd, kh, kw);
-            return (tile_mask & tb) == tb;
-        }
-        if (d_first != d_last) return true;
-        const int kd = (s / ncc) / (g.KH * g.KW);
-        return (dmask_first >> kd) & 1;
-    };
-
-    float4 ra[8];
-    float4 b0[BK / 8], b1[BK / 8];
-    float4 tsc = make_float4(1, 1, 1, 1), tsh = make_float4(0, 0, 0, 0);
-    unsigned valid_mask = 0;
-    auto load_a = [&](int s) {
-        const int tap = s / ncc, cc = s - tap * ncc;
-        const int kw = tap % g.KW, kh = (tap / g.KW) % g.KH, kd = tap / (g.KW * g.KH);
-        const int c = cc * BK + piece * 4;
-        const bool cok = c < g.Cin;
-        const int soff = tap_delta(g, kd, kh, kw, MODE) + cc * BK;
-        const int tbits = cok ? tap_bits(kd, kh, kw) : 0x7fffffff;
-        valid_mask = 0;
-#pragma unroll
-        for (int p = 0; p < 8; ++p) {
-            const bool ok = (rows[p].mask & tbits) == tbits;
-            const int off = ok ? rows[p].off + soff : 0;
-            ra[p] = *reinterpret_cast<const float4*>(in + off);
-            valid_mask |= ok ? (1u << p) : 0u;
-        }
-        if (XF) {
-            // unconditional (in_bn is never NULL here, see lisec_conv_forward_ex): with these two loads under a branch the
-            // compiler sizes its s_waitcnt for the shorter path and every step waits for its first A loads before the MFMAs
-            const int cs = cok ? c : 0;
-            tsc = *reinterpret_cast<const float4*>(in_bn + cs);
-            tsh = *reinterpret_cast<const float4*>(in_bn + g.Cin + cs);
-        }
-    };
-    const float relu_lo = (flags & LISEC_CONV_IN_RELU) ? 0.f : -INFINITY;
-    auto store_a = [&]() {
-#pragma unroll
-        for (int p = 0; p < 8; ++p) {
-            float4 v = ra[p];
-            const bool ok = (valid_mask >> p) & 1;
-            if (XF) {
-                v.x = ok ? fmaxf(fmaf(v.x, tsc.x, tsh.x), relu_lo) : 0.f;
-                v.y = ok ? fmaxf(fmaf(v.y, tsc.y, tsh.y), relu_lo) : 0.f;
-                v.z = ok ? fmaxf(fmaf(v.z, tsc.z, tsh.z), relu_lo) : 0.f;
-                v.w = ok ? fmaxf(fmaf(v.w, tsc.w, tsh.w), relu_lo) : 0.f;
-            } else {
-                v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
-            }
-            *reinterpret_cast<float4*>(sA + (p * 4 + (lane >> 4)) * LDA + piece * 4) = v;
-        }
-    };
-    // W fragments of (step s, k chunk kc): lane (n = lane & 31, k quad = 2 kc + lane / 32) of the packed slab
-    const float* wlane = wp + ((size_t)(lane >> 5) * g.CoutP + n0 + (lane & 31)) * 4;
-    auto wslab = [&](int s) -> const float* {
-        const int tap = s / ncc, cc = s - tap * ncc;
-        return wlane + (size_t)(tap * KpQ + cc * (BK / 4)) * g.CoutP * 4;
-    };
-
-    f32x16 acc0 = {0}, acc1 = {0};
-    const float* aRow = sA + (lane & 31) * LDA + 4 * (lane >> 5);
-    const int s_begin = (int)(((long long)ks * nsteps) / KS), s_end = (int)(((long long)(ks + 1) * nsteps) / KS);
-    auto advance_to = [&](int s) -> int {
-        while (s < s_end && !live(s)) ++s;
-        return s < s_end ? s : nsteps;
-    };
-    int s = mw < mlimit ? advance_to(s_begin) : nsteps;      // a wave whose rows all lie beyond the layer only joins barriers
-    if (s < nsteps) {
-        load_a(s);
-        const float* wb = wslab(s);
-#pragma unroll
-        for (int kc = 0; kc < BK / 8; ++kc) {
-            b0[kc] = *reinterpret_cast<const float4*>(wb + (size_t)kc * 2 * g.CoutP * 4);
-            b1[kc] = *reinterpret_cast<const float4*>(wb + (size_t)kc * 2 * g.CoutP * 4 + 32 * 4);
-        }
-        store_a();
-    }
-    while (s < nsteps) {
-        const int snext = advance_to(s + 1);
-        // every step issues the same loads -- the last one re-reads its own operands -- so that the number of loads in
-        // flight is static: with loads under a branch the compiler has to assume the smaller count and its s_waitcnt
-        // vmcnt(0) at the end of each step also waits for the W chunks that were only just requested
-        const int sl = snext < nsteps ? snext : s;
-        load_a(sl);
-        const float* wb = wslab(sl);
-        float4 a = *reinterpret_cast<const float4*>(aRow);
-#pragma unroll
-        for (int kc = 0; kc < BK / 8; ++kc) {
-            float4 an = a;
-            if (kc + 1 < BK / 8) an = *reinterpret_cast<const float4*>(aRow + (kc + 1) * 8);
-            __builtin_amdgcn_sched_barrier(0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0[kc].x, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1[kc].x, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b0[kc].y, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1[kc].y, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b0[kc].z, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b1[kc].z, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b0[kc].w, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b1[kc].w, acc1, 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            // the fragment registers of this chunk are free again: the next step's W chunk streams into them while the
-            // remaining chunks run (a whole step of MFMAs, ~4000 cycles, before it is needed)
-            b0[kc] = *reinterpret_cast<const float4*>(wb + (size_t)kc * 2 * g.CoutP * 4);
-            b1[kc] = *reinterpret_cast<const float4*>(wb + (size_t)kc * 2 * g.CoutP * 4 + 32 * 4);
-            a = an;
-        }
-        store_a();                               // LDS is in order per wave: every fragment read above was issued first
-        s = snext;
-    }
-    // ---- fold the K slices (slice order), then the shared epilogue --------------------------------------------------
-    if (KS > 1) {
-        __syncthreads();                         // every wave is done with its A slab
-        if (ks > 0) {
-            float* mine = smem + (size_t)((ks - 1) * RT + rg) * 2048;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { mine[r * 64 + lane] = acc0[r]; mine[(16 + r) * 64 + lane] = acc1[r]; }
-        }
-        __syncthreads();
-        if (ks == 0) {
-#pragma unroll
-            for (int k = 1; k < KS; ++k) {
-                const float* o = smem + (size_t)((k - 1) * RT + rg) * 2048;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { acc0[r] += o[r * 64 + lane]; acc1[r] += o[(16 + r) * 64 + lane]; }
-            }
-        }
-        __syncthreads();                         // store_tile reuses smem for the statistics
-    }
-    store_tile(g, acc0, acc1, smem, mw, n0, mb, mlimit, 0, wave, lane, tid, bias, flags, out, stats, nullptr, ks == 0);
-}
-
-// ---------------------------------------------------------------------------------------------------------------
 // Dense(64) on the last axis (model_training.py:195) and its data gradient: 1x1x1, 64 -> 64, row m reads position m.
 // One K step per tile, so k_igemm spends its time in phases (2500 workgroups load, then multiply, then store: 2.6 TB/s
 // on a layer that moves 164 / 246 MB).  Here 768 workgroups stay resident and walk the tiles: the weights sit in LDS for
@@ -1500,26 +1302,6 @@ extern "C" int lisec_conv_forward_ex(const lisec_conv_geom* c, const float* in, 
         if (bwd_stats) { if (xf_bn) LISEC_D64(true, true); else LISEC_D64(false, true); }
         else           { if (xf_bn) LISEC_D64(true, false); else LISEC_D64(false, false); }
 #undef LISEC_D64
-        LISEC_LAUNCH_CHECK();
-        return LISEC_OK;
-    }
-    // a layer that would be K-sliced as a whole: the slices stay inside the workgroups (k_igemm_w) -- no slabs, no combine.
-    // LISEC_WAVE_K = 2 / 4 / 1 (auto): opt-in -- measured slower than the sliced launch + combine on every RPN shape but the
-    // 1250-position one (two waves per SIMD at 219 registers: 2.4 rounds of workgroups where the sliced launch needs one)
-    static const int wave_k = [] { const char* e = getenv("LISEC_WAVE_K"); return e ? atoi(e) : 0; }();
-    if (plan.nsplit >= 2 && plan.tile0_tail == 0 && !table_stats && wave_k != 0) {
-        const int KS = wave_k == 2 || wave_k == 4 ? wave_k : (plan.nsplit == 2 ? 2 : 4);
-        const int bmw = 128 / KS;
-        dim3 grid(cdiv(g.M, bmw), nnb, 1);
-        if (sk) g.sink.total = grid.x * grid.y;
-        const size_t lds_w = (size_t)4 * 32 * LDA * sizeof(float);
-#define LISEC_IW(M_, X_, K_) hipLaunchKernelGGL((k_igemm_w<M_, X_, K_>), grid, dim3(kThreads), lds_w, st, g, in, packed_w, bias, \
-        in_bnstate, flags, out, stats_partials)
-#define LISEC_IW_K(M_, X_) do { if (KS == 2) LISEC_IW(M_, X_, 2); else LISEC_IW(M_, X_, 4); } while (0)
-        if (c->mode == 0) { if (xf) LISEC_IW_K(0, true); else LISEC_IW_K(0, false); }
-        else              { if (xf) LISEC_IW_K(1, true); else LISEC_IW_K(1, false); }
-#undef LISEC_IW_K
-#undef LISEC_IW
         LISEC_LAUNCH_CHECK();
         return LISEC_OK;
     }

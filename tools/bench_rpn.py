@@ -1,5 +1,5 @@
 """The RPN-shaped contractions alone (no statistics table, so the K slices may stay inside the workgroups).
-usage: [LISEC_WAVE_K=0|2|4] python tools/bench_rpn.py"""
+usage: [LISEC_HALF_N=0] [LISEC_MAX_SPLITK=n] python tools/bench_rpn.py"""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -30,7 +30,7 @@ def run(name, mode, ind, outd, k, s, p, cin, cout, iters=30, in_bn=True):
     ms = e0.elapsed_time(e1) / iters
     M = outd[0] * outd[1] * outd[2]
     fl = 2.0 * M * ntaps * cin * cout
-    print(f"WAVE_K={os.environ.get('LISEC_WAVE_K', 'auto'):4s} {name:30s} {ms*1e3:8.1f} us {fl/ms/1e9:7.1f} TF/s", flush=True)
+    print(f"{name:30s} {ms*1e3:8.1f} us {fl/ms/1e9:7.1f} TF/s", flush=True)
 
 
 if __name__ == "__main__":
