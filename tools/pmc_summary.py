@@ -6,7 +6,7 @@ import os
 import sys
 from collections import defaultdict
 
-KEYS = {"k_igemm_halo<1, false, 1, 2>": "mid2 Conv3D data gradient (roofline launch)", "k_field_taps": "field conv: taps",
+KEYS = {"k_igemm_halo<1, false, 1, 2": "mid2 Conv3D data gradient (roofline launch)", "k_field_taps": "field conv: taps",
         "k_field_combine": "field conv: combine", "k_igemm_halo<0, false, 1, 2>": "mid1 Conv3D fwd (roofline launch)", "k_vfe_grid": "VFE grid writer",
         "k_vfe_stage<2": "VFE layers 1+2", "k_vfe_stage<3": "VFE layer 3", "k_wgrad_halo<false>": "mid wgrad (halo)"}
 for d in sys.argv[1:]:
