@@ -322,3 +322,46 @@ def test_row_list_data_gradient_and_the_tile_queue(count, capacity):
             assert torch.equal(out_q, out)                          # same tiles, same arithmetic
         else:
             _close(out_q[:count], want, rtol=1e-5)
+
+
+def test_dense64_resident_workgroups_forward_and_data_gradient():
+    """Dense(64) over enough rows (>= 768 tiles) for the resident-workgroup kernel (k_dense64): forward with the
+    BatchNormalization of the producer applied on load, bias and ReLU (model_training.py:195), against a plain fp32
+    PyTorch evaluation; data gradient with the BatchNormalization-backward sums in a lisec_bn_sink against their
+    definitions ((sum dz, sum dz*yhat) -> dgamma, dbeta, coef), twice (the sink must be left ready for the next call)."""
+    from lisec_amd import ops
+    g = torch.Generator().manual_seed(31)
+    dims, C = (4, 161, 153), 64                       # 98 532 rows: 770 tiles, a ragged last one
+    M = dims[0] * dims[1] * dims[2]
+    geo = ops.geom(0, dims, dims, (1, 1, 1), (1, 1, 1), (0, 0, 0), C, C)
+    x = torch.randn(M, C, generator=g)
+    w = torch.randn(C, C, generator=g) * 0.1
+    b = torch.randn(C, generator=g)
+    sc, sh = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    wp = ops.pack_weights(w.to(DEV), 1, C, C, 0, C, 1)
+    out = torch.full((M, C), float("nan"), device=DEV)
+    ops.conv_forward(geo, x.to(DEV), wp, out, bias=b.to(DEV), in_bn=torch.cat([sc, sh, torch.zeros(2 * C)]).to(DEV),
+                     flags=ops.OUT_RELU)
+    _close(out, F.relu((x * sc + sh) @ w + b))
+    # data gradient dz = du @ W^T with the statistics of the BatchNormalization it is about to cross
+    du = torch.randn(M, C, generator=g)
+    y = torch.randn(M, C, generator=g) * 1.5 + 0.3
+    mean, var = y.mean(0), y.var(0, unbiased=False)
+    inv = torch.rsqrt(var + 1e-3)
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    st = torch.cat([gamma * inv, beta - mean * gamma * inv, mean, inv]).to(DEV)
+    wt = ops.pack_weights(w.to(DEV), 1, C, C, 0, 1, C)                 # transposed: K = out channel, N = in channel
+    dgamma, dbeta = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    sink = ops.BnSink(C, M, DEV, dgamma=dgamma, dbeta=dbeta)
+    want = du.double() @ w.double().t()
+    yhat = (y.double() - mean.double()) * inv.double()
+    for _ in range(2):
+        dz = torch.full((M, C), float("nan"), device=DEV)
+        ops.conv_forward(geo, du.to(DEV), wt, dz, bwd=(y.to(DEV), st, False), sink=sink)
+        torch.cuda.synchronize()
+        _close(dz, want.float())
+        _close(dbeta, want.sum(0), rtol=1e-5)
+        _close(dgamma, (want * yhat).sum(0), rtol=1e-5)
+        _close(sink.coef[:C], want.mean(0), rtol=1e-5)
+        _close(sink.coef[C:], (want * yhat).mean(0), rtol=1e-5)
+        assert (sink.acc == 0).all()
