@@ -24,10 +24,10 @@ sparse = net.params.grad_view(net.grad, c.wname).clone().reshape(27, 64, 64)
 dz = net.dact["mid1.z"]
 ws = torch.empty(ops.wgrad_workspace_bytes(c.g), dtype=torch.uint8, device=dev)
 dense = torch.empty(27, 64, 64, device=dev)
-ops.conv_wgrad(c.g, net.act["grid"], dz, dense, ws)
+ops.conv_wgrad(c.g, net.dense_grid(), dz, dense, ws)
 torch.cuda.synchronize()
 # fp64 reference for a few taps on CPU
-grid = net.act["grid"].double().cpu(); dzc = dz.double().cpu()
+grid = net.dense_grid().double().cpu(); dzc = dz.double().cpu()
 err = (sparse - dense).abs().reshape(27, -1).max(1).values.cpu().numpy()
 print("max |dense|", dense.abs().max().item(), "max err sparse-dense per tap:", np.round(err / dense.abs().max().item(), 5))
 import torch.nn.functional as F
