@@ -37,6 +37,18 @@ struct GridDims {
     int mx, my, mz;
 };
 
+// cell_count[ncells] = 0 and info[8] = 0 in ONE launch (two hipMemsetAsync calls are two fill kernels: ~11 us + a gap)
+__global__ void __launch_bounds__(256)
+k_zero_counts(int* __restrict__ cell_count, int ncells, int* __restrict__ info) {
+    const int n4 = ncells >> 2;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n4; i += gridDim.x * 256)
+        reinterpret_cast<int4*>(cell_count)[i] = make_int4(0, 0, 0, 0);
+    if (blockIdx.x == 0) {
+        if (threadIdx.x < 8) info[threadIdx.x] = 0;
+        if ((int)threadIdx.x < (ncells & 3)) cell_count[(n4 << 2) + threadIdx.x] = 0;
+    }
+}
+
 template <typename T>
 __global__ void k_key_count(const T* __restrict__ pts, int n, int stride, GridDims g,
                             int* __restrict__ cell_count, int* __restrict__ key,
@@ -392,8 +404,11 @@ extern "C" int lisec_voxelize(const lisec_voxel_cfg* cfg, const void* points, in
         return LISEC_ENOSPC;
     }
     hipStream_t st = static_cast<hipStream_t>(stream_);
-    LISEC_HIP_TRY(hipMemsetAsync(w.cell_count, 0, sizeof(int) * (size_t)g.ncells, st));
-    LISEC_HIP_TRY(hipMemsetAsync(info, 0, sizeof(int) * 8, st));
+    {
+        int zb = cdiv(g.ncells >> 2, 256);
+        if (zb > 1024) zb = 1024;
+        hipLaunchKernelGGL(k_zero_counts, dim3(zb < 1 ? 1 : zb), dim3(256), 0, st, w.cell_count, g.ncells, info);
+    }
     const int nblk = cdiv(g.ncells, kCellsPerBlock);
     if (n_points > 0) {
         int gb = cdiv(n_points, 256);
