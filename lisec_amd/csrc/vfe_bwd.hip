@@ -113,6 +113,8 @@ k_rows_colsum(const int* __restrict__ info, int cap, const float* __restrict__ d
     if (V > cap) V = cap;
     const int c = threadIdx.x & 63, ry = threadIdx.x >> 6;
     double a = 0.0;
+    // (unrolled: the loads of eight voxels in flight at once -- one round trip per voxel made this 42 us at 84 000 voxels)
+#pragma unroll 8
     for (int v = blockIdx.x * 4 + ry; v < V; v += gridDim.x * 4) a += (double)dout[(size_t)v * 64 + c];
     red[ry][c] = a;
     __syncthreads();
@@ -159,6 +161,7 @@ k_l3_stats(VfeIn in, const float* __restrict__ bn3, const float* __restrict__ ym
     const int nvox = V + (in.ncells - V > 0 ? 1 : 0);
     const float sc = bn3[lane], sh = bn3[64 + lane], mu = bn3[128 + lane], is = bn3[192 + lane];
     double s1 = 0.0, s2 = 0.0;
+#pragma unroll 4
     for (int v = blockIdx.x * 4 + w; v < nvox; v += gridDim.x * 4) {
         const float ys = sc >= 0.f ? ymm3[(size_t)v * 128 + lane] : ymm3[(size_t)v * 128 + 64 + lane];
         const float gz = fmaf(ys, sc, sh) > 0.f ? dout[(size_t)v * 64 + lane] : 0.f;
