@@ -1327,7 +1327,7 @@ extern "C" int lisec_conv_forward_ex(const lisec_conv_geom* c, const float* in, 
     // instead -- as many workgroups, no slabs, no combine.  LISEC_HALF_N=0: the two slices.
     static const bool half_n = [] { const char* e = getenv("LISEC_HALF_N"); return !e || atoi(e) != 0; }();
     if (half_n && plan.nsplit == 2 && plan.tile0_tail == 0 && !g.queue) {
-        dim3 grid(ntiles, g.CoutP / 32, 1);
+        dim3 grid(ntiles, cdiv(g.Cout, 32), 1);       // (no workgroups for column blocks beyond Cout: the 16-column heads)
         if (sk) g.sink.total = grid.x * grid.y;
 #define LISEC_HN(KERNEL_, LDS_) hipLaunchKernelGGL(KERNEL_, grid, dim3(kThreads), LDS_, st, g, in, packed_w, bias, in_bnstate, \
         flags, out, stats_partials, 1, (float*)nullptr, 0)
