@@ -27,6 +27,8 @@ namespace lisec {
 namespace {
 
 constexpr int kBwdBlocks = 512;
+constexpr int kL3Blocks = 256;      // k_l3 alone is faster with half the workgroups (49 -> 42 us at 9 400 voxels: its 64x64 partial per
+                                    // workgroup dominates); k_l2 / k_l1 / the statistics pass are faster with 512
 constexpr int kMaxRows = 64;            // rows of one voxel (<= T <= 64)
 
 struct Vox {
@@ -878,12 +880,12 @@ extern "C" int lisec_vfe_backward(const lisec_vfe_params* p, const int32_t* info
         if (int rc = launch_bn_bwd_finalize(ws.parts_a, vblocks, 16, N, g->gamma[0], g->beta[0], ws.coef, st)) return rc;
     } else {
         size_t lds3 = (size_t)(4 * 2 * kMaxRows * 32 + 64 * 64) * sizeof(float);
-        hipLaunchKernelGGL(k_l3, dim3(kBwdBlocks), dim3(256), lds3, st, in, p->kernel[0], p->kernel[1], p->kernel[2],
+        hipLaunchKernelGGL(k_l3, dim3(kL3Blocks), dim3(256), lds3, st, in, p->kernel[0], p->kernel[1], p->kernel[2],
                            sv.bn1, sv.bn2, sv.bn3, ws.coef, sv.ymm1, sv.ymm2, sv.ymm3, ws.dout, ws.gz2, ws.parts_dw,
                            ws.parts_a);
         LISEC_LAUNCH_CHECK();
-        if (int rc = launch_reduce_parts(ws.parts_dw, kBwdBlocks, 64 * 64, 1.0, g->kernel[2], nullptr, st)) return rc;
-        if (int rc = launch_bn_bwd_finalize(ws.parts_a, kBwdBlocks, 32, N, g->gamma[1], g->beta[1], ws.coef, st)) return rc;
+        if (int rc = launch_reduce_parts(ws.parts_dw, kL3Blocks, 64 * 64, 1.0, g->kernel[2], nullptr, st)) return rc;
+        if (int rc = launch_bn_bwd_finalize(ws.parts_a, kL3Blocks, 32, N, g->gamma[1], g->beta[1], ws.coef, st)) return rc;
         // 3. layer 2
         size_t lds2 = (size_t)(4 * 2 * kMaxRows * 16 + 32 * 32) * sizeof(float);
         hipLaunchKernelGGL(k_l2, dim3(kBwdBlocks), dim3(256), lds2, st, in, p->kernel[0], p->kernel[1], sv.bn1, sv.bn2,
