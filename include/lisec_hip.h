@@ -242,6 +242,10 @@ int lisec_conv_num_mblocks(const lisec_conv_geom* g);
  */
 size_t lisec_conv_forward_workspace_bytes(const lisec_conv_geom* g);
 size_t lisec_conv_forward_rows_workspace_bytes(const lisec_conv_geom* g, int row_capacity);
+/* The workspace of the contraction entry points must be ZERO-FILLED once, before its first use: it starts with the
+ * arrival counters of the K slices (the slices of a tile are combined inside the kernel by the last one to arrive, in
+ * slice order -- deterministic, no combine launch), which every call leaves at zero.  One workspace serves any number of
+ * layers on ONE stream; calls that may overlap on two streams need a workspace each. */
 /* lisec_conv_forward with optional extras (NULL fields = off):
  *   out_mask     the output gate of lisec_conv_forward_masked
  *   bwd_y, bwd_bnstate, bwd_relu
@@ -289,6 +293,28 @@ typedef struct lisec_conv_extras {
     int32_t* queue;
 } lisec_conv_extras;
 int lisec_conv_num_mblocks_bwd(const lisec_conv_geom* g);
+
+/* The launch plan lisec_conv_forward_ex WILL run for these arguments (pointers only matter as NULL / non-NULL, so the
+ * query takes flags for them): which kernel, the workgroup shape, the K slicing, the row order.  Tests pin the plans of
+ * the Lyft layer geometries with it; nothing is launched. */
+enum { LISEC_KERNEL_IGEMM = 0,   /* generic gather, 128 x 64 tile                                             */
+       LISEC_KERNEL_HALO2 = 1,   /* w-halo staging, at most two output lines per tile (Wo >= 126)             */
+       LISEC_KERNEL_HALO3 = 2,   /* w-halo staging, three lines per tile (64 <= Wo < 126)                     */
+       LISEC_KERNEL_DENSE64 = 3, /* resident workgroups, 1x1 64 -> 64                                         */
+       LISEC_KERNEL_QUEUE = 4 }; /* resident workgroups drawing row-list tiles from a counter                 */
+typedef struct lisec_conv_plan {
+    int kernel;          /* LISEC_KERNEL_*                                                                    */
+    int cols;            /* output columns per workgroup: 64, or 32 (instead of two K slices)                 */
+    int tiles;           /* 128-row tiles of the call (parity-class order pads every class to whole tiles)    */
+    int tail_tile0;      /* first tile of the K-sliced tail (0: the whole layer is sliced, == tiles: none)    */
+    int k_slices;        /* K slices of the tail, combined in-kernel by the last slice to arrive              */
+    int plane_pair;      /* one workgroup per pair of depth planes                                            */
+    int parity_classes;  /* rows visited in (h & 1, w & 1) classes (data gradient of a stride-2 Conv2D)       */
+    int workgroups, launches;
+} lisec_conv_plan;
+int lisec_conv_plan_query(const lisec_conv_geom* g, int has_in_bnstate, int flags, const lisec_conv_extras* extras,
+                          int has_stats_table, size_t workspace_bytes, int has_row_list, int row_capacity,
+                          lisec_conv_plan* plan);
 int lisec_conv_forward_ex(const lisec_conv_geom* g, const float* in, const float* packed_w, const float* bias,
                           const float* in_bnstate, int flags, float* out, const lisec_conv_extras* extras,
                           double* stats_partials, void* workspace, size_t workspace_bytes,
@@ -361,6 +387,33 @@ int lisec_conv_field_forward(const lisec_conv_geom* g, const float* vout, const 
                              const int32_t* coords, const int32_t* cell_voxel, int row_capacity,
                              const float* packed_w, const float* bias, float* out, const lisec_bn_sink* sink,
                              void* workspace, size_t workspace_bytes, lisec_stream_t stream);
+
+/* Upsampling branches + heads collapsed into 16-channel contractions (csrc/head_fused.hip).  The three
+ * Conv2DTranspose layers (model_training.py:246,249,252) carry a bias but no BatchNormalization and no activation, and the
+ * two 1x1 heads (:254-255) read their Concatenate (:253) linearly, so
+ *     head[m][j] = b'_j + sum_b sum_{tap,c} x_b[src_b(m,tap)][c] * Wc_b[tap][c][j],
+ *     Wc_b[tap][c][j] = sum_n W_b[tap][n][c] * H[256 b + n][j],   b'_j = b_j + sum_b sum_n bias_b[n] * H[256 b + n][j]
+ * (W_b: the Keras Conv2DTranspose kernel (kh,kw,out,in); H = [W_cls | W_reg], (768,16)): transposed convolutions to 16
+ * channels through lisec_conv_forward instead of three to 256 channels and a 768 -> 16 contraction; the (100,200,768)
+ * concat tensor and its gradient are never formed.  Same values up to fp32 summation order.
+ *   lisec_head_compose: Wc[tap*out_tap_stride + c*out_c_stride + j] (j < 16) for ONE branch; head_w = the 256 rows of H
+ *     that branch feeds ((Cup,16), row stride 16); bias_out[j] = (bias_in ? bias_in[j] : 0) + sum_n up_bias[n]*H[n][j]
+ *     (bias_out NULL: skipped; chain the branches through bias_in, starting from the heads' own bias).
+ *   lisec_head_compose_backward: from G = dL/dWc (same indexing as Wc; the lisec_conv_wgrad of the 16-channel contraction)
+ *     and S[j] = sum_m dhead[m][j]:  d_up_kernel (taps,Cup,Cin), d_up_bias (Cup), d_head_w (Cup,16) of that branch
+     (d_head_w includes up_bias[n]*S[j]: the branch carries its bias into the heads).
+ *   lisec_head_shuffle: the kernel == stride branches run as 1x1 contractions with columns (tap, j):
+ *     T_b[pos][tap*16 + j], pos = (h/ps_b)*(Wo/ps_b) + w/ps_b, tap = (h%ps_b)*ps_b + w%ps_b, over the (Ho,Wo,16) head map.
+ *     backward == 0: head[m][j] += sum_b T_b[...];  backward != 0: T_b[...] = head[m][j] (head = dL/dhead, T_b = dL/dT_b).
+ *     T, ps: HOST arrays of n_branches (<= 4) device pointers / strides. */
+int lisec_head_compose(const float* up_kernel, const float* up_bias, const float* head_w, int taps, int Cin, int Cup,
+                       long long out_tap_stride, long long out_c_stride, float* Wc, const float* bias_in, float* bias_out,
+                       lisec_stream_t stream);
+int lisec_head_compose_backward(const float* G, long long g_tap_stride, long long g_c_stride, const float* up_kernel,
+                                const float* up_bias, const float* head_w, const float* S, int taps, int Cin, int Cup,
+                                float* d_up_kernel, float* d_up_bias, float* d_head_w, lisec_stream_t stream);
+int lisec_head_shuffle(float* head, int Ho, int Wo, int n_branches, float* const* T, const int* ps, int backward,
+                       lisec_stream_t stream);
 
 /* BatchNormalization statistics (Keras: axis -1, eps 1e-3, momentum 0.99, biased batch variance).
  * bnstate: float[4*C] {scale = gamma*rsqrt(var+eps), shift = beta - mean*scale, mean, invstd}.
@@ -465,6 +518,13 @@ typedef void* lisec_comm_t; /* ncclComm_t */
 int lisec_comm_unique_id(void* id /* LISEC_COMM_ID_BYTES, host */);
 int lisec_comm_init(int rank, int world, const void* id, lisec_comm_t* comm);
 int lisec_comm_destroy(lisec_comm_t comm);
+/* LISEC_OK when RCCL can be loaded in this process.  No collective, no device work: every rank calls it BEFORE the
+ * collective lisec_comm_init, so that a rank without RCCL is found while the others can still be told. */
+int lisec_comm_probe(void);
+/* Number of ranks of the communicator (ncclCommCount). */
+int lisec_comm_count(lisec_comm_t comm, int* count);
+/* world: 0 = divide by the communicator's own size; > 0 must EQUAL it (a mismatch would mis-scale every gradient and is
+ * refused with LISEC_EINVAL); < 0 = an explicit divisor -world. */
 int lisec_allreduce_grads(lisec_comm_t comm, float* grad, long long n, int world, lisec_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
@@ -496,6 +556,37 @@ size_t lisec_rpn_labels_workspace_bytes(int n_boxes);
 int lisec_rpn_labels(const lisec_rpn_cfg* cfg, const double* fixed_boxes, int n_boxes, double iou_lo, double iou_hi,
                      void* workspace, size_t workspace_bytes, double* valid, double* overlap, double* out_regress,
                      lisec_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * 6. Launch-plan tuning and diagnostics.  Not needed by a caller of the hot path: the defaults are the measured
+ *    optimum on MI355X; tools/ and bench.py use them to measure the alternatives.
+ *    The tuning record is process-wide and read when a call is planned: change it only while no call is in flight.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct lisec_tuning {
+    int struct_bytes;       /* sizeof(lisec_tuning) of the caller (ABI evolution)                              */
+    int max_splitk;         /* most K slices per tile                                              (12)        */
+    int splitk_min_steps;   /* least 64-deep K steps per slice                                     (3)         */
+    int min_splitk;         /* layers that would get fewer slices run unsliced                     (2)         */
+    int plane_pair;         /* pair depth planes that run different numbers of taps                (1)         */
+    int dense64;            /* resident-workgroup kernel for Dense(64)                             (1)         */
+    int half_n;             /* 32-column workgroups instead of two K slices                        (1)         */
+    int vfe_shape;          /* launch shape of the VFE stage kernels, -1 = by capacity             (-1)        */
+    int field_seg;          /* segment length of the field combine pass, 0 = by capacity           (0)         */
+    int field_tpw;          /* taps per workgroup of the field contraction, 0 = by capacity        (0)         */
+    int wgrad_blocks;       /* workgroups a weight-gradient launch aims for                        (1024)      */
+    int debug_sync;         /* lisec_vfe_backward synchronises and reports after every launch      (0)         */
+    int force_splitk;       /* > 0: every sliceable layer gets exactly this many K slices          (0)         */
+} lisec_tuning;
+int lisec_tuning_get(lisec_tuning* t);        /* fills *t with the current record (t->struct_bytes set)          */
+int lisec_tuning_set(const lisec_tuning* t);  /* t->struct_bytes must be sizeof(lisec_tuning)                    */
+
+/* 100 MHz s_memrealtime stamps of thread 0 of every workgroup at the kernels' phase boundaries (tools: igemm_stamps.py, wgrad_stamps.py, vfe_stamps.py, field_stamps.py).
+ * buf: device uint64[8192 x 8] (igemm); see the tools for the others; NULL (the default) turns them off -- no stamp
+ * instruction executes then.  The pointer is a __device__ variable of the code object: set it from one thread. */
+int lisec_debug_igemm_stamps(unsigned long long* buf);
+int lisec_debug_wgrad_stamps(unsigned long long* buf);
+int lisec_debug_vfe_stamps(unsigned long long* buf);
+int lisec_debug_field_stamps(unsigned long long* buf);
 
 #ifdef __cplusplus
 }

@@ -42,6 +42,20 @@ class ConvExtras(ctypes.Structure):           # lisec_conv_extras
                 ("bwd_relu", ctypes.c_int), ("sink", POINTER(BnSinkDesc)), ("queue", ctypes.c_void_p)]
 
 
+class ConvPlan(Structure):                     # lisec_conv_plan
+    _fields_ = [(n, c_int) for n in ("kernel", "cols", "tiles", "tail_tile0", "k_slices", "plane_pair", "parity_classes",
+                                     "workgroups", "launches")]
+
+
+class Tuning(Structure):                       # lisec_tuning
+    _fields_ = [(n, c_int) for n in ("struct_bytes", "max_splitk", "splitk_min_steps", "min_splitk", "plane_pair", "dense64",
+                                     "half_n", "vfe_shape", "field_seg", "field_tpw", "wgrad_blocks", "debug_sync",
+                                     "force_splitk")]
+
+
+KERNEL_NAMES = {0: "igemm", 1: "halo2", 2: "halo3", 3: "dense64", 4: "queue"}
+
+
 class CopyDesc(Structure):                     # lisec_copy_desc
     _fields_ = [("src", c_void_p), ("dst", c_void_p), ("rows", c_int), ("cols", c_int),
                 ("src_stride", ctypes.c_longlong), ("dst_stride", ctypes.c_longlong)]
@@ -176,6 +190,26 @@ def _declare(lib):
     lib.lisec_comm_destroy.argtypes = [P]
     lib.lisec_allreduce_grads.restype = c_int
     lib.lisec_allreduce_grads.argtypes = [P, P, LL, c_int, P]
+    lib.lisec_head_compose.restype = c_int
+    lib.lisec_head_compose.argtypes = [P, P, P, c_int, c_int, c_int, LL, LL, P, P, P, P]
+    lib.lisec_head_compose_backward.restype = c_int
+    lib.lisec_head_compose_backward.argtypes = [P, LL, LL, P, P, P, P, c_int, c_int, c_int, P, P, P, P]
+    lib.lisec_head_shuffle.restype = c_int
+    lib.lisec_head_shuffle.argtypes = [P, c_int, c_int, c_int, POINTER(c_void_p), POINTER(c_int), c_int, P]
+    lib.lisec_comm_probe.restype = c_int
+    lib.lisec_comm_probe.argtypes = []
+    lib.lisec_comm_count.restype = c_int
+    lib.lisec_comm_count.argtypes = [P, POINTER(c_int)]
+    lib.lisec_conv_plan_query.restype = c_int
+    lib.lisec_conv_plan_query.argtypes = [POINTER(ConvGeom), c_int, c_int, POINTER(ConvExtras), c_int, c_size_t, c_int, c_int,
+                                          POINTER(ConvPlan)]
+    lib.lisec_tuning_get.restype = c_int
+    lib.lisec_tuning_get.argtypes = [POINTER(Tuning)]
+    lib.lisec_tuning_set.restype = c_int
+    lib.lisec_tuning_set.argtypes = [POINTER(Tuning)]
+    for name in ("lisec_debug_igemm_stamps", "lisec_debug_wgrad_stamps", "lisec_debug_vfe_stamps", "lisec_debug_field_stamps"):
+        getattr(lib, name).restype = c_int
+        getattr(lib, name).argtypes = [P]
     lib.lisec_bn_finalize.restype = c_int
     lib.lisec_bn_finalize.argtypes = [P, c_int, c_int, c_double, P, P, P, P, c_int, P, P]
     lib.lisec_bn_fold.restype = c_int
@@ -198,7 +232,33 @@ def load():
         lib = ctypes.CDLL(LIB_PATH)
         _declare(lib)
         _lib = lib
+        spec = os.environ.get("LISEC_TUNING")       # measurement aid: "max_splitk=8,half_n=0" (see set_tuning)
+        if spec:
+            set_tuning(**{k.strip(): int(v) for k, v in (kv.split("=") for kv in spec.split(",") if kv.strip())
+                          if k.strip() in dict(Tuning._fields_)})
     return _lib
+
+
+def get_tuning():
+    """The library's launch-plan knobs (lisec_tuning) as a dict."""
+    t = Tuning()
+    check(load().lisec_tuning_get(ctypes.byref(t)))
+    return {n: getattr(t, n) for n, _ in Tuning._fields_ if n != "struct_bytes"}
+
+
+def set_tuning(**kw):
+    """Changes launch-plan knobs of the library (defaults = the measured optimum; tools/ measure the alternatives).
+    Only between calls: the record is process-wide.  Returns the previous values of the changed knobs."""
+    t = Tuning()
+    check(load().lisec_tuning_get(ctypes.byref(t)))
+    prev = {}
+    for k, v in kw.items():
+        if k not in dict(Tuning._fields_) or k == "struct_bytes":
+            raise KeyError(f"unknown tuning knob {k!r}")
+        prev[k] = getattr(t, k)
+        setattr(t, k, int(v))
+    check(load().lisec_tuning_set(ctypes.byref(t)))
+    return prev
 
 
 def check(rc):

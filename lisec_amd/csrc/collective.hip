@@ -24,6 +24,7 @@ struct Rccl {
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     bool ok = false;
+    char why[256] = "symbols missing";      // the loader's message, taken when dlopen failed (dlerror() clears itself)
 };
 
 const Rccl& rccl() {
@@ -32,9 +33,12 @@ const Rccl& rccl() {
         const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
         for (const char* n : names)                                   // the copy already in the process first
             if ((x.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;
-        if (!x.handle)
-            for (const char* n : names)
+        if (!x.handle) {
+            for (const char* n : names) {
                 if ((x.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
+                if (const char* e = dlerror()) std::snprintf(x.why, sizeof(x.why), "%s", e);
+            }
+        }
         if (!x.handle) return x;
         x.GetUniqueId = reinterpret_cast<decltype(x.GetUniqueId)>(dlsym(x.handle, "ncclGetUniqueId"));
         x.CommInitRank = reinterpret_cast<decltype(x.CommInitRank)>(dlsym(x.handle, "ncclCommInitRank"));
@@ -59,7 +63,7 @@ const Rccl& rccl() {
 
 int need_rccl() {
     if (!rccl().ok) {
-        set_error("RCCL (librccl.so.1) could not be loaded: %s", dlerror() ? dlerror() : "symbols missing");
+        set_error("RCCL (librccl.so.1) could not be loaded: %s", rccl().why);
         return LISEC_EHIP;
     }
     return LISEC_OK;
@@ -78,6 +82,15 @@ extern "C" int lisec_comm_unique_id(void* id) {
     ncclUniqueId u;
     LISEC_RCCL_TRY(rccl().GetUniqueId(&u));
     std::memcpy(id, &u, sizeof(u));
+    return LISEC_OK;
+}
+
+extern "C" int lisec_comm_probe(void) { return need_rccl(); }
+
+extern "C" int lisec_comm_count(lisec_comm_t comm, int* count) {
+    LISEC_CHECK_ARG(comm && count, "NULL communicator / count");
+    if (int rc = need_rccl()) return rc;
+    LISEC_RCCL_TRY(rccl().CommCount(static_cast<ncclComm_t>(comm), count));
     return LISEC_OK;
 }
 
@@ -100,11 +113,16 @@ extern "C" int lisec_comm_destroy(lisec_comm_t comm) {
 }
 
 extern "C" int lisec_allreduce_grads(lisec_comm_t comm, float* grad, long long n, int world, lisec_stream_t stream) {
-    LISEC_CHECK_ARG(comm && grad && n >= 0 && n % 4 == 0 && world >= 1, "bad all-reduce arguments (n must be a multiple of 4)");
-    if (n == 0) return LISEC_OK;
+    LISEC_CHECK_ARG(comm && grad && n >= 0 && n % 4 == 0, "bad all-reduce arguments (n must be a multiple of 4)");
     if (int rc = need_rccl()) return rc;
+    // the divisor: the communicator's own size; a caller-supplied world that disagrees with it would silently mis-scale
+    // every gradient, so it is refused -- a deliberate other divisor is passed as -divisor
     int count = 0;
     LISEC_RCCL_TRY(rccl().CommCount(static_cast<ncclComm_t>(comm), &count));
+    LISEC_CHECK_ARG(world <= 0 || world == count, "world = %d but the communicator has %d ranks (0 = use the communicator's "
+                    "size, -d = explicit divisor d)", world, count);
+    world = world < 0 ? -world : count;
+    if (n == 0) return LISEC_OK;
     LISEC_RCCL_TRY(rccl().AllReduce(grad, grad, (size_t)n, ncclFloat, ncclSum, static_cast<ncclComm_t>(comm),
                                     static_cast<hipStream_t>(stream)));
     if (world > 1) return lisec_scale(grad, n, 1.0f / (float)world, stream);

@@ -12,6 +12,7 @@ namespace lisec {
 constexpr int kWave = 64;  // CDNA4 wavefront
 
 void set_error(const char* fmt, ...);
+const lisec_tuning& tuning();      // the process-wide launch-plan knobs (core.hip; lisec_tuning_set)
 
 #define LISEC_CHECK_ARG(cond, ...)                 \
     do {                                           \

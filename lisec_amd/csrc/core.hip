@@ -12,11 +12,28 @@ void set_error(const char* fmt, ...) {
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
 }
+
+static lisec_tuning g_tuning = {(int)sizeof(lisec_tuning), 12, 3, 2, 1, 1, 1, -1, 0, 0, 1024, 0, 0};
+const lisec_tuning& tuning() { return g_tuning; }
 }  // namespace lisec
+
+extern "C" int lisec_tuning_get(lisec_tuning* t) {
+    LISEC_CHECK_ARG(t, "NULL tuning record");
+    *t = lisec::g_tuning;
+    return LISEC_OK;
+}
+
+extern "C" int lisec_tuning_set(const lisec_tuning* t) {
+    LISEC_CHECK_ARG(t && t->struct_bytes == (int)sizeof(lisec_tuning), "tuning record of another ABI version");
+    LISEC_CHECK_ARG(t->max_splitk >= 1 && t->splitk_min_steps >= 1 && t->min_splitk >= 2 && t->wgrad_blocks >= 1,
+                    "tuning: max_splitk, splitk_min_steps, wgrad_blocks >= 1, min_splitk >= 2");
+    lisec::g_tuning = *t;
+    return LISEC_OK;
+}
 
 extern "C" const char* lisec_last_error(void) { return lisec::g_err; }
 
-extern "C" int lisec_abi_version(void) { return 9; }
+extern "C" int lisec_abi_version(void) { return 10; }
 
 extern "C" int lisec_device_info(char* name, int cap) {
     int dev = 0;

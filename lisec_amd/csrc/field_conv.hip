@@ -15,7 +15,6 @@
 // grid is never formed: with the sparse backward of sparse_grid.hip neither direction of the training step needs it.
 #include "conv.h"
 
-#include <cstdlib>
 
 namespace lisec {
 namespace {
@@ -312,11 +311,7 @@ extern "C" int lisec_conv_field_forward(const lisec_conv_geom* c, const float* v
     }
     // whole lines for small sweeps (800 workgroups feed the sink instead of 3200: 23 -> 6 us of atomics); big sweeps
     // have crowded lines next to empty ones, there two segments per line balance the pass (84 000 voxels: 328 -> 270 us)
-    static const int seg_env = [] {
-        const char* e = std::getenv("LISEC_FIELD_SEG");
-        const int v = e ? std::atoi(e) : 0;
-        return v >= 16 && v <= 1024 ? v : 0;
-    }();
+    const int seg_env = tuning().field_seg >= 16 && tuning().field_seg <= 1024 ? tuning().field_seg : 0;
     const int seg_target = seg_env ? seg_env : (row_capacity > 65536 ? 256 : 512);
     const int nseg = cdiv(g.Wo, seg_target), seg_len = cdiv(g.Wo, nseg);
     const int LW = (seg_len - 1) * (1 << g.ls_w) + g.KW;
@@ -336,7 +331,7 @@ extern "C" int lisec_conv_field_forward(const lisec_conv_geom* c, const float* v
     float* Zc = Z + (size_t)ntaps * zstride;
     // small sweeps: one tap per workgroup (9 400 voxels: 25 us against 38 us -- the launch is far from filling the chip);
     // big ones: the KW taps of a (kd, kh) pair share one staged A tile (84 000 voxels: 268 us against 302 us for the call)
-    static const int tpw_env = [] { const char* e = std::getenv("LISEC_FIELD_TPW"); return e ? std::atoi(e) : 0; }();
+    const int tpw_env = tuning().field_tpw;
     const int tpw = (tpw_env == 1 || tpw_env == g.KW) ? tpw_env : (row_capacity > 65536 ? g.KW : 1);
     hipLaunchKernelGGL(k_field_taps, dim3(cdiv((long long)row_capacity + 1, FM), ntaps / tpw), dim3(kFieldThreads),
                        (size_t)(FM * FLDA + FC * FC) * sizeof(float), st, g, vout, delta, info, coords, row_capacity,

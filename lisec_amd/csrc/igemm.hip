@@ -21,11 +21,6 @@
 // summation-order noise (no reduced precision anywhere).
 #include "conv.h"
 
-#include <cstdlib>
-#include <map>
-#include <mutex>
-#include <utility>
-#include <vector>
 
 namespace lisec {
 namespace {
@@ -43,36 +38,80 @@ constexpr int B_FLOATS = BK * BN;                // 4096
 __device__ unsigned long long* g_igemm_stamps = nullptr;
 #define IGEMM_STAMP(K_)                                                                                    \
     do {                                                                                                   \
-        if (stamps && threadIdx.x == 0 && stamp_wg < 8192)                                                 \
+        if (stamps && threadIdx.x == 0 && stamp_wg < 8192) {                                               \
             stamps[(size_t)stamp_wg * 8 + (K_)] = __builtin_amdgcn_s_memrealtime();                        \
+            if ((K_) == 0)   /* where the workgroup runs: HW_ID (wave, simd, cu, sh, se) | XCC_ID << 32 */  \
+                stamps[(size_t)stamp_wg * 8 + 6] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | \
+                                                   ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32); \
+        }                                                                                                  \
     } while (0)
 
-// Epilogue shared by the igemm kernels: raw K-slice slab, or bias (+accumulate, output gate, ReLU) store with the
-// per-tile BatchNormalization partial sums.  C layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+// K slices of one tile meet here (nsplit > 1).  Every slice stores its two accumulators to its slab IN THE REGISTER LAYOUT
+// (slab[z][slot][wave][q][lane] float4: one 1 KB line per store instruction, nothing to transpose), takes a ticket on the
+// tile's arrival counter, and all but the LAST slice to arrive are done.  The last one adds the slabs in slice order
+// z = 0 .. nsplit-1 (so the sum does not depend on who arrived last: deterministic), leaves the counter at zero for the
+// next call and goes on to the ordinary epilogue with the complete accumulators -- bias, gate, BatchNormalization sums and
+// the sink ticket exactly as an un-sliced tile.  No combine launch, no second pass over the output.
+// Hand-off (MI355X guide, inter-workgroup visibility): write-through (sc1) slab stores, every storing wave waits for its
+// stores, workgroup barrier, ONE lane's agent-scope add; the last arriver's waves load (sc1, past their L1) only after the
+// barrier behind the add that told them they are last.
+constexpr int kSplitCounters = 4096;             // arrival counters at the head of the workspace (ints)
+constexpr int kSlabF4 = 4 * 8 * 64;              // float4 per (slice, tile, column block): 128 x 64 floats
+
+__device__ __forceinline__ bool splitk_arrive(f32x16& acc0, f32x16& acc1, float* partial, int nsplit, int slot, int nslots,
+                                              int wave, int lane) {
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    __shared__ int splitk_last;
+    int* counters = reinterpret_cast<int*>(partial);
+    float* slabs = partial + kSplitCounters;
+    const size_t bytes = (size_t)nsplit * nslots * kSlabF4 * 16;
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(slabs, 0, (int)bytes, 0x00020000);
+    const unsigned lane_off = (unsigned)((wave * 8) * 64 + lane) * 16u;
+    const unsigned mine = (unsigned)(((size_t)blockIdx.z * nslots + slot) * kSlabF4 * 16) + lane_off;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const f32x16& a = q < 4 ? acc0 : acc1;
+        const int r = (q & 3) * 4;
+        u32x4 v;
+        v.x = __float_as_uint(a[r]); v.y = __float_as_uint(a[r + 1]); v.z = __float_as_uint(a[r + 2]); v.w = __float_as_uint(a[r + 3]);
+        __builtin_amdgcn_raw_buffer_store_b128(v, rs, mine + q * 64 * 16, 0, 16);          // aux 16 = sc1
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0)
+        splitk_last = __hip_atomic_fetch_add(counters + slot, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nsplit - 1;
+    __syncthreads();
+    if (!splitk_last) return false;
+    if (threadIdx.x == 0) __hip_atomic_store(counters + slot, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    f32x16 s0 = {0}, s1 = {0};
+    const unsigned zstride = (unsigned)((size_t)nslots * kSlabF4 * 16);
+    unsigned off = (unsigned)((size_t)slot * kSlabF4 * 16) + lane_off;
+    for (int z = 0; z < nsplit; ++z, off += zstride) {
+        u32x4 v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, off + q * 64 * 16, 0, 16);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            f32x16& a = q < 4 ? s0 : s1;
+            const int r = (q & 3) * 4;
+            a[r] += __uint_as_float(v[q].x); a[r + 1] += __uint_as_float(v[q].y);
+            a[r + 2] += __uint_as_float(v[q].z); a[r + 3] += __uint_as_float(v[q].w);
+        }
+    }
+    acc0 = s0; acc1 = s1;
+    return true;
+}
+
+// Epilogue shared by the igemm kernels: bias (+accumulate, output gate, ReLU) store with the per-tile BatchNormalization
+// partial sums.  C layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
 // mw: first of the 32 rows this wave holds; storer: false for a wave that holds no rows of its own -- it only takes part
 // in the statistics reduction, with zeros.
 __device__ __forceinline__ void store_tile(const ConvGeom& g, const f32x16& acc0, const f32x16& acc1, float* smem,
-                                           int mw, int n0, int mb, int mlimit, int tile0, int wave, int lane, int tid,
+                                           int mw, int n0, int mb, int mlimit, int wave, int lane, int tid,
                                            const float* __restrict__ bias, int flags, float* __restrict__ out,
-                                           double* __restrict__ stats, float* __restrict__ partial, bool storer = true,
-                                           bool half = false) {
+                                           double* __restrict__ stats, bool storer = true, bool half = false) {
     // half: the workgroup computed a 32-column slab (acc1 is unused): the second 32 columns are treated as outside Cout
     const int col = lane & 31;
-    if (partial) {
-        // slabs cover the rows of tiles tile0 .. (the tail of the layer, or all of it)
-        const size_t rows_part = (size_t)gridDim.x * BM;
-        float* pz = partial + (size_t)blockIdx.z * rows_part * g.CoutP;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = mw + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            if (m < mlimit) {
-                const size_t ml = (size_t)(m - tile0 * BM);
-                pz[ml * g.CoutP + n0 + col] = acc0[r];
-                pz[ml * g.CoutP + n0 + 32 + col] = acc1[r];
-            }
-        }
-        return;
-    }
     const int nA = n0 + col, nB = half ? g.Cout : n0 + 32 + col;
     // pixel-shuffle store (kernel == stride transposed conv): the 64-column slab lies inside one tap
     const int ps_tap = g.ps ? n0 / g.ps_channels : 0;
@@ -374,10 +413,15 @@ igemm_tile(const ConvGeom& g, const float* __restrict__ in, const float* __restr
         s = snext;
     }
     IGEMM_STAMP(3);
-    store_tile(g, acc0, acc1, smem, m0 + wave * 32, n0, mb, mlimit, tile0, wave, lane, tid, bias, flags, out, stats, partial,
-               true, NW == 32);
-    IGEMM_STAMP(4);
     if (stamps && threadIdx.x == 0 && stamp_wg < 8192) stamps[(size_t)stamp_wg * 8 + 5] = (unsigned long long)stamp_steps;
+    if (nsplit > 1) {
+        const bool last = splitk_arrive(acc0, acc1, partial, nsplit, (mb - tile0) * gridDim.y + blockIdx.y,
+                                        gridDim.x * gridDim.y, wave, lane);
+        IGEMM_STAMP(7);
+        if (!last) { IGEMM_STAMP(4); return; }
+    }
+    store_tile(g, acc0, acc1, smem, m0 + wave * 32, n0, mb, mlimit, wave, lane, tid, bias, flags, out, stats, true, NW == 32);
+    IGEMM_STAMP(4);
 }
 
 // TAG only changes the symbol name: bench.py launches a layer through k_igemm<.., 1> so that its row in a rocprofv3
@@ -651,10 +695,15 @@ halo_tile(const ConvGeom& g, const float* __restrict__ in, const float* __restri
         s = snext;
     }
     IGEMM_STAMP(3);
-    store_tile(g, acc0, acc1, smem, m0 + wave * 32, n0, mb, mlimit, tile0, wave, lane, tid, bias, flags, out, stats, partial,
-               true, NW == 32);
-    IGEMM_STAMP(4);
     if (stamps && threadIdx.x == 0 && stamp_wg < 8192) stamps[(size_t)stamp_wg * 8 + 5] = (unsigned long long)stamp_steps;
+    if (nsplit > 1) {
+        const bool last = splitk_arrive(acc0, acc1, partial, nsplit, (mb - tile0) * gridDim.y + blockIdx.y,
+                                        gridDim.x * gridDim.y, wave, lane);
+        IGEMM_STAMP(7);
+        if (!last) { IGEMM_STAMP(4); return; }
+    }
+    store_tile(g, acc0, acc1, smem, m0 + wave * 32, n0, mb, mlimit, wave, lane, tid, bias, flags, out, stats, true, NW == 32);
+    IGEMM_STAMP(4);
 }
 
 // TAG only changes the symbol name (see k_igemm).  With g.plane_pair the workgroup runs TWO tiles: the same (h, w) place of
@@ -841,110 +890,6 @@ __global__ void k_pack_weights_batched(const lisec_pack_desc* __restrict__ tab, 
     }
 }
 
-// split-K combine: out = sum_z partial[z] + bias (+ out) (relu) ; BatchNormalization partial statistics per
-// 128-row tile (same tile index as the single-pass kernel, so lisec_bn_finalize sees the same layout)
-// ROWS rows x 64 channels per workgroup of ROWS * 8 threads.  ROWS = 128: one 128-row tile, the layout of the per-tile
-// statistics table.  (ROWS = 32 -- four times as many 256-thread workgroups -- was measured and dropped: no faster beside
-// the weight-gradient kernels of the second stream, and 17 -> 27 us alone on the 20 000-position layers: four times the
-// sink's atomic adds.)
-template <int ROWS>
-__global__ void __launch_bounds__(ROWS * 8)
-k_splitk_reduce(const float* __restrict__ partial, int nsplit, int M, int Cout, int CoutP,
-                const float* __restrict__ bias, int flags, float* __restrict__ out, int out_stride,
-                double* __restrict__ stats, int tile0, int rows_part, const int32_t* __restrict__ row_count,
-                const float* __restrict__ out_mask, int pc_span, int pc_rows, int Wo,
-                const float* __restrict__ bwd_y, const float* __restrict__ bwd_bn, int bwd_relu, BnSink sink) {
-    constexpr int kSkThreads = ROWS * 8;
-    __shared__ float red[2][kSkThreads][4];
-    if (row_count && *row_count < M) M = *row_count;          // row list shorter than its capacity
-    constexpr int cq = BN / 4;                       // one 64-channel slab per blockIdx.y
-    const int q = threadIdx.x % cq, rsub = threadIdx.x / cq, rows_per_iter = kSkThreads / cq;
-    const int c = blockIdx.y * BN + q * 4;
-    const bool cok = c < Cout;
-    float4 b = make_float4(0, 0, 0, 0);
-    if (bias && cok) b = *reinterpret_cast<const float4*>(bias + c);
-    float4 ysc = make_float4(1, 1, 1, 1), ysh = make_float4(0, 0, 0, 0), ymu = ysh, yis = ysh;
-    if (bwd_y && cok) {
-        ysc = *reinterpret_cast<const float4*>(bwd_bn + c);
-        ysh = *reinterpret_cast<const float4*>(bwd_bn + Cout + c);
-        ymu = *reinterpret_cast<const float4*>(bwd_bn + 2 * Cout + c);
-        yis = *reinterpret_cast<const float4*>(bwd_bn + 3 * Cout + c);
-    }
-    const bool orelu = (flags & LISEC_CONV_OUT_RELU) != 0, accum = (flags & LISEC_CONV_ACCUMULATE) != 0;
-    float4 s1 = make_float4(0, 0, 0, 0), s2 = make_float4(0, 0, 0, 0);
-    const int tile = tile0 + (int)((long long)blockIdx.x * ROWS / BM);     // the 128-row tile these rows belong to
-    const int m_begin = tile0 * BM + blockIdx.x * ROWS, m_end = m_begin + ROWS < M ? m_begin + ROWS : M;
-    if (m_begin >= M) {                                        // rows beyond the layer (or a short row list)
-        if (sink.acc) sink_finish(sink);
-        return;
-    }
-    const size_t zstride = (size_t)rows_part * CoutP;
-    for (int m = m_begin + rsub; m < m_end; m += rows_per_iter) {
-        float4 v = b;
-        const float* src = partial + (size_t)(m - tile0 * BM) * CoutP + c;
-        int z = 0;
-        for (; z + 4 <= nsplit; z += 4) {            // slab loads batched 4 deep, added in slab order
-            float4 p[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) p[u] = *reinterpret_cast<const float4*>(src + (size_t)(z + u) * zstride);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) { v.x += p[u].x; v.y += p[u].y; v.z += p[u].z; v.w += p[u].w; }
-        }
-        for (; z < nsplit; ++z) {
-            const float4 p = *reinterpret_cast<const float4*>(src + (size_t)z * zstride);
-            v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
-        }
-        size_t orow = (size_t)m;
-        bool live_row = true;
-        if (pc_span) {                                           // parity-class row order (see conv.h)
-            const int pc = m / pc_span, q = m - pc * pc_span, Wh = Wo >> 1;
-            const int i = q / Wh, j = q - i * Wh;
-            live_row = q < pc_rows;
-            orow = (size_t)(2 * i + (pc >> 1)) * Wo + 2 * j + (pc & 1);
-        }
-        if (cok && live_row) {
-            float* o = out + orow * out_stride + c;
-            if (accum) { const float4 e = *reinterpret_cast<const float4*>(o); v.x += e.x; v.y += e.y; v.z += e.z; v.w += e.w; }
-            if (out_mask) {
-                const float4 mk = *reinterpret_cast<const float4*>(out_mask + orow * out_stride + c);
-                v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f;
-                v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
-            }
-            if (orelu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-            *reinterpret_cast<float4*>(o) = v;
-            if (bwd_y) {
-                const float4 yv = *reinterpret_cast<const float4*>(bwd_y + orow * Cout + c);
-#define LISEC_BWD(f)                                                                     \
-                {                                                                        \
-                    const float dz = (bwd_relu && !(fmaf(yv.f, ysc.f, ysh.f) > 0.f)) ? 0.f : v.f; \
-                    s1.f += dz;                                                          \
-                    s2.f = fmaf(dz, (yv.f - ymu.f) * yis.f, s2.f);                       \
-                }
-                LISEC_BWD(x) LISEC_BWD(y) LISEC_BWD(z) LISEC_BWD(w)
-#undef LISEC_BWD
-            } else {
-                s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
-                s2.x = fmaf(v.x, v.x, s2.x); s2.y = fmaf(v.y, v.y, s2.y); s2.z = fmaf(v.z, v.z, s2.z); s2.w = fmaf(v.w, v.w, s2.w);
-            }
-        }
-    }
-    if (stats || sink.acc) {
-        red[0][threadIdx.x][0] = s1.x; red[0][threadIdx.x][1] = s1.y; red[0][threadIdx.x][2] = s1.z; red[0][threadIdx.x][3] = s1.w;
-        red[1][threadIdx.x][0] = s2.x; red[1][threadIdx.x][1] = s2.y; red[1][threadIdx.x][2] = s2.z; red[1][threadIdx.x][3] = s2.w;
-        __syncthreads();
-        if (threadIdx.x < 2 * BN) {
-            const int which = threadIdx.x / BN, cl = threadIdx.x % BN, ch = blockIdx.y * BN + cl;
-            double a = 0.0;
-            for (int k = 0; k < rows_per_iter; ++k) a += (double)red[which][k * cq + cl / 4][cl % 4];
-            if (ch < Cout) {
-                if (sink.acc) sink_add(sink, which, ch, a);
-                else stats[((size_t)tile * 2 + which) * Cout + ch] = a;
-            }
-        }
-        if (sink.acc) sink_finish(sink);
-    }
-}
-
 // dst[tap][k/4][n][k%4] (K padded to 64, N padded to 64, zero filled) from an arbitrary strided source
 __global__ void k_pack_weights(const float* __restrict__ src, int ntaps, int K, int N, long long tap_stride,
                                long long k_stride, long long n_stride, int Kp, int Np, float* __restrict__ dst) {
@@ -1054,15 +999,6 @@ extern "C" int lisec_conv_num_mblocks_bwd(const lisec_conv_geom* c) {
 }
 
 namespace {
-// Launch plan: layers with few tiles are cut into K slices so that they fill the 256 CUs; layers with
-// many tiles run whole rounds unsplit and only the LAST, partially filled round is K-sliced (otherwise e.g.
-// mid1's 2500 tiles take 4 rounds of 768 resident workgroups for 3.25 rounds of work).
-struct ConvPlan {
-    int tile0_tail;      // first tile of the K-sliced tail (== ntiles: no tail)
-    int nsplit;          // slices of the tail (or of the whole layer when tile0_tail == 0)
-    size_t ws_bytes;
-};
-
 int resident_slots() {
     static int slots = 0;
     if (!slots) {
@@ -1087,31 +1023,54 @@ void parity_order(const lisec_conv_geom* c, ConvGeom* g) {
     }
 }
 
-// (scale = 1, shift = 0) for `C` channels, device memory of the current device, made once per size and kept for the life
-// of the process (a few KB): the on-load affine of a call that only asked for LISEC_CONV_IN_RELU
+// (scale = 1, shift = 0) for any channel count up to kIdentityMax, part of the code object (no allocation, never written):
+// the on-load affine of a call that only asked for LISEC_CONV_IN_RELU.  The kernels read scale at in_bn[c] and shift at
+// in_bn[Cin + c]: the table is kIdentityMax ones followed by kIdentityMax zeros, entered Cin floats before the zeros.
+constexpr int kIdentityMax = 4096;
+__device__ const float4 g_identity_bn[2 * kIdentityMax / 4] = {
+#define LISEC_ONE4 {1.f, 1.f, 1.f, 1.f}
+#define LISEC_ONE64 LISEC_ONE4, LISEC_ONE4, LISEC_ONE4, LISEC_ONE4, LISEC_ONE4, LISEC_ONE4, LISEC_ONE4, LISEC_ONE4, \
+                    LISEC_ONE4, LISEC_ONE4, LISEC_ONE4, LISEC_ONE4, LISEC_ONE4, LISEC_ONE4, LISEC_ONE4, LISEC_ONE4
+#define LISEC_ONE1024 LISEC_ONE64, LISEC_ONE64, LISEC_ONE64, LISEC_ONE64, LISEC_ONE64, LISEC_ONE64, LISEC_ONE64, LISEC_ONE64, \
+                      LISEC_ONE64, LISEC_ONE64, LISEC_ONE64, LISEC_ONE64, LISEC_ONE64, LISEC_ONE64, LISEC_ONE64, LISEC_ONE64
+    LISEC_ONE1024, LISEC_ONE1024, LISEC_ONE1024, LISEC_ONE1024          // the zeros follow (rest of the initialiser)
+#undef LISEC_ONE1024
+#undef LISEC_ONE64
+#undef LISEC_ONE4
+};
 const float* identity_bnstate(int C) {
-    static std::mutex mu;
-    static std::map<std::pair<int, int>, float*> tables;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    std::lock_guard<std::mutex> lock(mu);
-    auto it = tables.find({dev, C});
-    if (it != tables.end()) return it->second;
-    std::vector<float> host(2 * (size_t)C, 0.f);
-    for (int i = 0; i < C; ++i) host[i] = 1.f;
-    float* d = nullptr;
-    if (hipMalloc(&d, host.size() * sizeof(float)) != hipSuccess) return nullptr;
-    if (hipMemcpy(d, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); return nullptr; }
-    tables[{dev, C}] = d;
-    return d;
+    if (C > kIdentityMax || C % 4) return nullptr;
+    void* base = nullptr;
+    if (hipGetSymbolAddress(&base, HIP_SYMBOL(g_identity_bn)) != hipSuccess) return nullptr;
+    return static_cast<const float*>(base) + (kIdentityMax - C);
 }
 
-ConvPlan make_conv_plan(const ConvGeom& g) {
-    ConvPlan p;
+// Everything lisec_conv_forward_ex decides before it launches, in one place -- so that lisec_conv_plan_query reports the
+// plan a call WILL run, not a restatement of it.
+//
+// K slicing: layers with few tiles are cut into K slices so that they fill the 256 CUs; layers with many tiles run whole
+// rounds unsplit and only the LAST, partially filled round is K-sliced (otherwise e.g. mid1's 2500 tiles take 4 rounds of
+// 768 resident workgroups for 3.25 rounds of work).  The slices of a tile are combined inside the kernel by the last one
+// to arrive (splitk_arrive): the workspace holds kSplitCounters arrival counters (zero between calls) and the slabs.
+enum { KERN_IGEMM = 0, KERN_HALO2 = 1, KERN_HALO3 = 2, KERN_DENSE64 = 3, KERN_QUEUE = 4 };
+struct ConvCall {
+    ConvGeom g;
+    int ntiles, nnb;
+    int tile0_tail, nsplit;      // first tile of the K-sliced tail (== ntiles: none); slices
+    size_t ws_bytes;
+    bool xf, halo, halo3, dense64, half_n, roofline;
+    int kernel;                  // KERN_*
+    int launch_tiles;            // workgroups along x of an every-tile launch (half the tiles with plane_pair)
+    double* stats;               // per-tile table (or the dummy that keeps the statistics paths on under a sink)
+    const float* in_bn;
+};
+
+void plan_slices(const ConvGeom& g, ConvCall* p) {
+    const lisec_tuning& tn = tuning();
     const int ntiles = cdiv(g.M, BM), nnb = g.CoutP / BN;
-    p.tile0_tail = ntiles; p.nsplit = 1; p.ws_bytes = 0;
+    p->tile0_tail = ntiles; p->nsplit = 1; p->ws_bytes = 0;
     const int nsteps = g.KD * g.KH * g.KW * cdiv(g.Cin, BK);
-    if (g.ps || g.Cout % 4 != 0 || g.out_stride % 4 != 0 || nsteps < 6) return p;
+    if (g.ps || g.Cout % 4 != 0 || g.out_stride % 4 != 0 || nsteps < 6) return;
     const int slots = resident_slots();
     const long long blocks = (long long)ntiles * nnb;
     int tail_tiles;
@@ -1123,38 +1082,178 @@ ConvPlan make_conv_plan(const ConvGeom& g) {
         if (ntiles < tiles_per_round) tail_tiles = ntiles;
     }
     const long long tail_blocks = (long long)tail_tiles * nnb;
-    if (tail_blocks == 0 || tail_blocks * 10 > (long long)slots * 7) return p;   // tail round >= 70 % full already
-    if (blocks > 2LL * slots) return p;     // >= 3 rounds: the short last round costs less than a sliced launch + combine
+    if (tail_blocks == 0 || tail_blocks * 10 > (long long)slots * 7) return;   // tail round >= 70 % full already
+    if (blocks > 2LL * slots) return;       // >= 3 rounds: the short last round costs less than a sliced launch
+    if (tail_blocks > kSplitCounters) return;
     int ns = (int)(slots / tail_blocks);
-    static const int max_split = [] { const char* e = getenv("LISEC_MAX_SPLITK"); return e ? atoi(e) : 12; }();
-    static const int min_steps = [] { const char* e = getenv("LISEC_SPLITK_MIN_STEPS"); return e ? atoi(e) : 3; }();
-    if (ns > nsteps / min_steps) ns = nsteps / min_steps;
-    if (ns > max_split) ns = max_split;
-    // LISEC_MIN_SPLITK (measurement knob): layers that would only be cut in two run unsplit instead -- the combine pass
-    // of a two-way split costs about what the split saves once the second backward stream competes for the CUs
-    static const int min_split = [] { const char* e = getenv("LISEC_MIN_SPLITK"); return e ? atoi(e) : 2; }();
-    if (ns < 2 || ns < min_split) return p;
-    p.tile0_tail = ntiles - tail_tiles;
-    p.nsplit = ns;
-    p.ws_bytes = align_up(sizeof(float) * (size_t)ns * tail_tiles * BM * g.CoutP, 256);
-    return p;
+    if (ns > nsteps / tn.splitk_min_steps) ns = nsteps / tn.splitk_min_steps;
+    if (ns > tn.max_splitk) ns = tn.max_splitk;
+    if (tn.force_splitk > 0) ns = tn.force_splitk < nsteps ? tn.force_splitk : nsteps;     // measurement aid
+    if (ns < 2 || ns < tn.min_splitk) return;
+    p->tile0_tail = ntiles - tail_tiles;
+    p->nsplit = ns;
+    p->ws_bytes = align_up(sizeof(int) * kSplitCounters + sizeof(float) * (size_t)ns * tail_tiles * nnb * BM * BN, 256);
+}
+
+int plan_conv(const lisec_conv_geom* c, bool has_in_bn, int flags, const lisec_conv_extras* extras, double* stats_partials,
+              const void* workspace, size_t workspace_bytes, const int32_t* row_coords, const int32_t* row_count,
+              int row_capacity, ConvCall* p) {
+    ConvGeom& g = p->g;
+    if (int rc = conv_geom_check(c, &g)) return rc;
+    const lisec_tuning& tn = tuning();
+    const float* out_mask = extras ? extras->out_mask : nullptr;
+    LISEC_CHECK_ARG(!out_mask || (!c->ps && ((uintptr_t)out_mask & 15) == 0),
+                    "out_mask: 16-byte aligned, not with a pixel-shuffle store");
+    g.out_mask = out_mask;
+    const bool bwd_stats = extras && extras->bwd_y;
+    const lisec_bn_sink* sk = extras ? extras->sink : nullptr;
+    const bool table_stats = stats_partials != nullptr && !sk;     // per-tile partial table (laid out for 128-row tiles)
+    if (sk) {
+        LISEC_CHECK_ARG(sk->acc && sk->n_rows > 0 && !row_coords && !c->ps, "bn sink: accumulators, row count, dense rows");
+        LISEC_CHECK_ARG((sk->kind == LISEC_SINK_FORWARD && !bwd_stats && sk->gamma && sk->beta && sk->bnstate &&
+                         (sk->moving_mean == nullptr) == (sk->moving_var == nullptr)) ||
+                        (sk->kind == LISEC_SINK_BACKWARD && bwd_stats && sk->dgamma && sk->dbeta && sk->coef),
+                        "bn sink: kind 1 needs gamma/beta/bnstate and no bwd_y, kind 2 needs bwd_y and dgamma/dbeta/coef");
+        // a dummy non-NULL partial table keeps the statistics code paths on; the sink takes precedence in the kernels
+        if (!stats_partials) stats_partials = reinterpret_cast<double*>(sk->acc);
+    }
+    if (bwd_stats) {
+        LISEC_CHECK_ARG(extras->bwd_bnstate && stats_partials && !c->ps && !row_coords && c->Cout % 4 == 0 &&
+                        ((uintptr_t)extras->bwd_y & 15) == 0 && ((uintptr_t)extras->bwd_bnstate & 15) == 0,
+                        "backward statistics need y, its bnstate, a partials buffer, dense rows and Cout % 4 == 0");
+        g.bwd_y = extras->bwd_y; g.bwd_bn = extras->bwd_bnstate; g.bwd_relu = extras->bwd_relu ? 1 : 0;
+    }
+    p->stats = stats_partials;
+    // stride 2 along h and w, transposed gather (data gradient of a stride-2 Conv2D): rows are visited in parity
+    // classes so that a tile only runs the taps that divide -- 9/4 of the 9 taps on average
+    if (!row_coords && (!stats_partials || bwd_stats)) parity_order(c, &g);
+    if (row_coords) {
+        LISEC_CHECK_ARG(row_count && row_capacity > 0 && !stats_partials && !c->ps,
+                        "row list needs a device count, a capacity, and no stats / pixel-shuffle");
+        g.row_coords = row_coords; g.row_count = row_count; g.M = row_capacity; g.pointwise = 0;
+        // K slicing is planned for the capacity; workgroups past the device-side row count exit at once
+    }
+    plan_slices(g, p);
+    const int ntiles = p->ntiles = cdiv(g.M, BM), nnb = p->nnb = g.CoutP / BN;
+    if (!workspace || workspace_bytes < p->ws_bytes) { p->tile0_tail = ntiles; p->nsplit = 1; }
+    p->roofline = (flags & LISEC_CONV_TAG_ROOFLINE) != 0;
+    if (row_coords && extras && extras->queue && nnb == 1 && ntiles >= resident_slots() && !stats_partials && !g.out_mask &&
+        !p->roofline) {
+        g.queue = extras->queue;                     // one un-sliced launch of resident workgroups drawing tiles
+        p->tile0_tail = ntiles; p->nsplit = 1;
+    }
+    if (sk) {
+        g.sink.acc = static_cast<long long*>(sk->acc);
+        g.sink.kind = sk->kind; g.sink.C = g.Cout; g.sink.unbiased = sk->unbiased_moving;
+        g.sink.total = (unsigned)ntiles * (unsigned)nnb;          // every (tile, channel slab) stores exactly once
+        g.sink.N = sk->n_rows;
+        g.sink.gamma = sk->gamma; g.sink.beta = sk->beta; g.sink.mmean = sk->moving_mean; g.sink.mvar = sk->moving_var;
+        g.sink.bnstate = sk->bnstate; g.sink.dgamma = sk->dgamma; g.sink.dbeta = sk->dbeta; g.sink.coef = sk->coef;
+    }
+    p->xf = has_in_bn || (flags & LISEC_CONV_IN_RELU);
+    // 3-tap stride-1 pad-1 contraction along w over full lines: the w-halo kernel (one A tile per (kd, kh) pair)
+    const bool halo_geom = !g.row_coords && !g.ps && g.ls_w == 0 && g.KW == 3 && g.pw == 1 && g.Wi == g.Wo &&
+                           g.Wo >= 64 && g.in_stride % 4 == 0;       // <= 3 lines per 128-row tile
+    p->halo3 = g.Wo < BM - 2;                                        // more than two lines per tile possible
+    // planes that run different numbers of depth taps: one workgroup per PAIR of planes (see k_igemm_halo) when the layer
+    // runs as one launch of the halo kernel and the pairs still fill the chip
+    if (tn.plane_pair && halo_geom && g.Do % 2 == 0 && (g.Ho * g.Wo) % BM == 0 && !g.pc_span &&
+        (p->tile0_tail == ntiles || p->roofline) && (long long)(ntiles / 2) * nnb >= resident_slots()) {
+        int lo = 1 << 30, hi = 0;
+        for (int d = 0; d < g.Do; ++d) {
+            int live = 0;
+            for (int kd = 0; kd < g.KD; ++kd) {
+                if (c->mode == 0) { const int sd = (d << g.ls_d) - g.pd + kd; live += sd >= 0 && sd < g.Di; }
+                else { const int t = d + g.pd - kd; live += t >= 0 && (t & ((1 << g.ls_d) - 1)) == 0 && (t >> g.ls_d) < g.Di; }
+            }
+            lo = live < lo ? live : lo; hi = live > hi ? live : hi;
+        }
+        if (lo != hi) { g.plane_tiles = g.Ho * g.Wo / BM; g.plane_pair = 1; }
+    }
+    p->dense64 = false; p->half_n = false;
+    if (p->roofline && !p->xf) {                     // one launch, every tile, under its own symbol
+        p->halo = halo_geom && !p->halo3;
+        if (!p->halo) g.plane_pair = 0;
+        p->tile0_tail = ntiles; p->nsplit = 1;
+        p->kernel = p->halo ? KERN_HALO2 : KERN_IGEMM;
+        p->launch_tiles = g.plane_pair ? ntiles / 2 : ntiles;
+        return LISEC_OK;
+    }
+    p->roofline = false;
+    // Dense(64) and its data gradient: the resident-workgroup kernel
+    if (tn.dense64 && g.pointwise && g.Cin == 64 && g.Cout == 64 && g.in_stride == 64 && g.out_stride == 64 && !g.row_coords &&
+        !g.out_mask && !(flags & (LISEC_CONV_ACCUMULATE | LISEC_CONV_TAG_ROOFLINE)) && !table_stats &&
+        (!sk || (sk->kind == LISEC_SINK_BACKWARD && bwd_stats)) && !(bwd_stats && !sk) && ntiles >= resident_slots()) {
+        p->dense64 = true;
+        p->kernel = KERN_DENSE64;
+        p->tile0_tail = ntiles; p->nsplit = 1; p->halo = false; g.plane_pair = 0;
+        p->launch_tiles = resident_slots();
+        if (sk) g.sink.total = (unsigned)resident_slots();
+        return LISEC_OK;
+    }
+    // the halo kernel slices K by whole A tiles: (kd, kh, channel slab) entries
+    const int nstage = g.KD * g.KH * cdiv(g.Cin, BK);
+    p->halo = halo_geom && p->nsplit <= nstage;
+    if (!p->halo) g.plane_pair = 0;
+    p->launch_tiles = g.plane_pair ? ntiles / 2 : ntiles;
+    p->kernel = g.queue ? KERN_QUEUE : (p->halo ? (p->halo3 ? KERN_HALO3 : KERN_HALO2) : KERN_IGEMM);
+    // a layer that would run as two K slices (160-380 tiles): 32-column workgroups over the whole K instead -- as many
+    // workgroups, no slabs
+    if (tn.half_n && p->nsplit == 2 && p->tile0_tail == 0 && !g.queue) {
+        p->half_n = true;
+        p->nsplit = 1; p->tile0_tail = ntiles;
+        if (sk) g.sink.total = (unsigned)ntiles * (unsigned)cdiv(g.Cout, 32);
+    }
+    return LISEC_OK;
 }
 }  // namespace
 
 extern "C" size_t lisec_conv_forward_workspace_bytes(const lisec_conv_geom* c) {
-    ConvGeom g;
-    if (conv_geom_check(c, &g)) return 0;
-    const size_t plain = make_conv_plan(g).ws_bytes;
-    parity_order(c, &g);                              // the order a statistics-free call would use
-    const size_t par = make_conv_plan(g).ws_bytes;
-    return plain > par ? plain : par;
+    ConvCall p;
+    if (conv_geom_check(c, &p.g)) return 0;
+    plan_slices(p.g, &p);
+    const size_t plain = p.ws_bytes;
+    parity_order(c, &p.g);                            // the order a statistics-free call would use
+    plan_slices(p.g, &p);
+    return plain > p.ws_bytes ? plain : p.ws_bytes;
 }
 
 extern "C" size_t lisec_conv_forward_rows_workspace_bytes(const lisec_conv_geom* c, int row_capacity) {
-    ConvGeom g;
-    if (conv_geom_check(c, &g) || row_capacity <= 0) return 0;
-    g.M = row_capacity;
-    return make_conv_plan(g).ws_bytes;
+    ConvCall p;
+    if (conv_geom_check(c, &p.g) || row_capacity <= 0) return 0;
+    p.g.M = row_capacity;
+    plan_slices(p.g, &p);
+    return p.ws_bytes;
+}
+
+extern "C" int lisec_conv_plan_query(const lisec_conv_geom* c, int has_in_bnstate, int flags, const lisec_conv_extras* extras,
+                                     int has_stats_table, size_t workspace_bytes, int has_row_list, int row_capacity,
+                                     lisec_conv_plan* out) {
+    LISEC_CHECK_ARG(out, "NULL plan");
+    ConvCall p;
+    static double dummy_stats;
+    static int32_t dummy_rows[4];
+    if (int rc = plan_conv(c, has_in_bnstate != 0, flags, extras, has_stats_table ? &dummy_stats : nullptr,
+                           workspace_bytes ? &dummy_stats : nullptr, workspace_bytes, has_row_list ? dummy_rows : nullptr,
+                           has_row_list ? dummy_rows + 3 : nullptr, row_capacity, &p))
+        return rc;
+    out->kernel = p.kernel;
+    out->cols = p.half_n ? 32 : 64;
+    out->tiles = p.ntiles;
+    out->tail_tile0 = p.tile0_tail;
+    out->k_slices = p.nsplit;
+    out->plane_pair = p.g.plane_pair;
+    out->parity_classes = p.g.pc_span ? 1 : 0;
+    const int ycols = p.half_n ? cdiv(p.g.Cout, 32) : p.nnb;
+    int wgs = 0, launches = 0;
+    if (p.kernel == KERN_DENSE64 || p.kernel == KERN_QUEUE) { wgs = resident_slots(); launches = 1; }
+    else {
+        if (p.tile0_tail > 0) { wgs += (p.g.plane_pair ? p.launch_tiles : p.tile0_tail) * ycols; ++launches; }
+        if (p.tile0_tail < p.ntiles) { wgs += (p.ntiles - p.tile0_tail) * p.nnb * p.nsplit; ++launches; }
+    }
+    out->workgroups = wgs;
+    out->launches = launches;
+    return LISEC_OK;
 }
 
 extern "C" int lisec_conv_forward(const lisec_conv_geom* c, const float* in, const float* packed_w,
@@ -1181,98 +1280,27 @@ extern "C" int lisec_conv_forward_ex(const lisec_conv_geom* c, const float* in, 
                                      const lisec_conv_extras* extras, double* stats_partials, void* workspace,
                                      size_t workspace_bytes, const int32_t* row_coords,
                                      const int32_t* row_count, int row_capacity, lisec_stream_t stream_) {
-    ConvGeom g;
-    if (int rc = conv_geom_check(c, &g)) return rc;
-    const float* out_mask = extras ? extras->out_mask : nullptr;
-    LISEC_CHECK_ARG(!out_mask || (!c->ps && ((uintptr_t)out_mask & 15) == 0),
-                    "out_mask: 16-byte aligned, not with a pixel-shuffle store");
-    g.out_mask = out_mask;
-    const bool bwd_stats = extras && extras->bwd_y;
-    const lisec_bn_sink* sk = extras ? extras->sink : nullptr;
-    const bool table_stats = stats_partials != nullptr && !sk;     // per-tile partial table (laid out for 128-row tiles)
-    if (sk) {
-        LISEC_CHECK_ARG(sk->acc && sk->n_rows > 0 && !row_coords && !c->ps, "bn sink: accumulators, row count, dense rows");
-        LISEC_CHECK_ARG((sk->kind == LISEC_SINK_FORWARD && !bwd_stats && sk->gamma && sk->beta && sk->bnstate &&
-                         (sk->moving_mean == nullptr) == (sk->moving_var == nullptr)) ||
-                        (sk->kind == LISEC_SINK_BACKWARD && bwd_stats && sk->dgamma && sk->dbeta && sk->coef),
-                        "bn sink: kind 1 needs gamma/beta/bnstate and no bwd_y, kind 2 needs bwd_y and dgamma/dbeta/coef");
-        // a dummy non-NULL partial table keeps the statistics code paths on; the sink takes precedence in the kernels
-        if (!stats_partials) stats_partials = reinterpret_cast<double*>(sk->acc);
-    }
-    if (bwd_stats) {
-        LISEC_CHECK_ARG(extras->bwd_bnstate && stats_partials && !c->ps && !row_coords && c->Cout % 4 == 0 &&
-                        ((uintptr_t)extras->bwd_y & 15) == 0 && ((uintptr_t)extras->bwd_bnstate & 15) == 0,
-                        "backward statistics need y, its bnstate, a partials buffer, dense rows and Cout % 4 == 0");
-        g.bwd_y = extras->bwd_y; g.bwd_bn = extras->bwd_bnstate; g.bwd_relu = extras->bwd_relu ? 1 : 0;
-    }
-    // stride 2 along h and w, transposed gather (data gradient of a stride-2 Conv2D): rows are visited in parity
-    // classes so that a tile only runs the taps that divide -- 9/4 of the 9 taps on average
-    if (!row_coords && (!stats_partials || bwd_stats)) parity_order(c, &g);
-    if (row_coords) {
-        LISEC_CHECK_ARG(row_count && row_capacity > 0 && !stats_partials && !c->ps,
-                        "row list needs a device count, a capacity, and no stats / pixel-shuffle");
-        g.row_coords = row_coords; g.row_count = row_count; g.M = row_capacity; g.pointwise = 0;
-        // K slicing is planned for the capacity; workgroups past the device-side row count exit at once
-    }
+    ConvCall p;
+    if (int rc = plan_conv(c, in_bnstate != nullptr, flags, extras, stats_partials, workspace, workspace_bytes, row_coords,
+                           row_count, row_capacity, &p))
+        return rc;
+    const ConvGeom& g = p.g;
+    stats_partials = p.stats;
     LISEC_CHECK_ARG(in && packed_w && out, "NULL tensor pointer");
     LISEC_CHECK_ARG(((uintptr_t)in & 15) == 0 && ((uintptr_t)packed_w & 15) == 0, "in/weights must be 16-byte aligned");
-    ConvPlan plan = make_conv_plan(g);
-    if (!workspace || workspace_bytes < plan.ws_bytes) { plan.tile0_tail = cdiv(g.M, BM); plan.nsplit = 1; }
-    const int ntiles = cdiv(g.M, BM), nnb = g.CoutP / BN;
-    if (row_coords && extras && extras->queue && nnb == 1 && ntiles >= resident_slots() && !stats_partials && !g.out_mask &&
-        !(flags & LISEC_CONV_TAG_ROOFLINE)) {
-        g.queue = extras->queue;                     // one un-sliced launch of resident workgroups drawing tiles
-        plan.tile0_tail = ntiles; plan.nsplit = 1;
-    }
-    if (sk) {
-        g.sink.acc = static_cast<long long*>(sk->acc);
-        g.sink.kind = sk->kind; g.sink.C = g.Cout; g.sink.unbiased = sk->unbiased_moving;
-        g.sink.total = (unsigned)ntiles * (unsigned)nnb;          // every (tile, channel slab) stores exactly once
-        g.sink.N = sk->n_rows;
-        g.sink.gamma = sk->gamma; g.sink.beta = sk->beta; g.sink.mmean = sk->moving_mean; g.sink.mvar = sk->moving_var;
-        g.sink.bnstate = sk->bnstate; g.sink.dgamma = sk->dgamma; g.sink.dbeta = sk->dbeta; g.sink.coef = sk->coef;
-    }
-    size_t lds = (size_t)(A_FLOATS + B_FLOATS) * sizeof(float);
+    const int ntiles = p.ntiles, nnb = p.nnb;
+    const size_t lds = (size_t)(A_FLOATS + B_FLOATS) * sizeof(float);
+    const size_t lds_halo = halo_lds_bytes(p.halo3 ? 3 : 2);
     hipStream_t st = static_cast<hipStream_t>(stream_);
-    const bool xf = in_bnstate != nullptr || (flags & LISEC_CONV_IN_RELU);
+    const bool xf = p.xf;
     if (xf && !in_bnstate) {
         // ReLU on load without a BatchNormalization: the kernels always read a (scale, shift) table -- hand them the identity
         in_bnstate = identity_bnstate(g.Cin);
-        LISEC_CHECK_ARG(in_bnstate, "could not allocate the identity (scale, shift) table");
+        LISEC_CHECK_ARG(in_bnstate, "LISEC_CONV_IN_RELU without a bnstate supports Cin <= 4096");
     }
-#define LISEC_IG(M_, X_, GRID_, NS_, PART_, T0_) hipLaunchKernelGGL((k_igemm<M_, X_>), GRID_, dim3(kThreads), lds, st, g, in, \
-        packed_w, bias, in_bnstate, flags, out, stats_partials, NS_, PART_, T0_)
-#define LISEC_IG_ALL(GRID_, NS_, PART_, T0_)                                                                   \
-    do {                                                                                                       \
-        if (c->mode == 0) { if (xf) LISEC_IG(0, true, GRID_, NS_, PART_, T0_); else LISEC_IG(0, false, GRID_, NS_, PART_, T0_); } \
-        else              { if (xf) LISEC_IG(1, true, GRID_, NS_, PART_, T0_); else LISEC_IG(1, false, GRID_, NS_, PART_, T0_); } \
-    } while (0)
-    // 3-tap stride-1 pad-1 contraction along w over full lines: the w-halo kernel (one A tile per (kd, kh) pair)
-    const bool halo_geom = !g.row_coords && !g.ps && g.ls_w == 0 && g.KW == 3 && g.pw == 1 && g.Wi == g.Wo &&
-                           g.Wo >= 64 && g.in_stride % 4 == 0;       // <= 3 lines per 128-row tile
-    const bool halo3 = g.Wo < BM - 2;                                // more than two lines per tile possible
-    const size_t lds_halo = halo_lds_bytes(halo3 ? 3 : 2);
-    // planes that run different numbers of depth taps: one workgroup per PAIR of planes (see k_igemm_halo) when the layer
-    // runs as one launch of the halo kernel and the pairs still fill the chip; LISEC_PLANE_PAIR=0 turns it off
-    static const bool pair_ok = [] { const char* e = getenv("LISEC_PLANE_PAIR"); return !e || atoi(e) != 0; }();
-    if (pair_ok && halo_geom && g.Do % 2 == 0 && (g.Ho * g.Wo) % BM == 0 && !g.pc_span &&
-        (plan.tile0_tail == ntiles || (flags & LISEC_CONV_TAG_ROOFLINE)) && (long long)(ntiles / 2) * nnb >= resident_slots()) {
-        int lo = 1 << 30, hi = 0;
-        for (int d = 0; d < g.Do; ++d) {
-            int live = 0;
-            for (int kd = 0; kd < g.KD; ++kd) {
-                if (c->mode == 0) { const int sd = (d << g.ls_d) - g.pd + kd; live += sd >= 0 && sd < g.Di; }
-                else { const int t = d + g.pd - kd; live += t >= 0 && (t & ((1 << g.ls_d) - 1)) == 0 && (t >> g.ls_d) < g.Di; }
-            }
-            lo = live < lo ? live : lo; hi = live > hi ? live : hi;
-        }
-        if (lo != hi) { g.plane_tiles = g.Ho * g.Wo / BM; g.plane_pair = 1; }
-    }
-    const int launch_tiles = g.plane_pair ? ntiles / 2 : ntiles;     // workgroups along x of an every-tile launch
-    if ((flags & LISEC_CONV_TAG_ROOFLINE) && !xf) {
-        dim3 grid(halo_geom && !halo3 ? launch_tiles : ntiles, nnb, 1);   // one launch, every tile, under its own symbol
-        if (!(halo_geom && !halo3)) g.plane_pair = 0;
-        if (halo_geom && !halo3) {
+    if (p.roofline) {
+        dim3 grid(p.halo ? p.launch_tiles : ntiles, nnb, 1);
+        if (p.halo) {
             if (c->mode == 0)
                 hipLaunchKernelGGL((k_igemm_halo<0, false, 1, 2>), grid, dim3(kThreads), halo_lds_bytes(2), st, g, in, packed_w,
                                    bias, in_bnstate, flags, out, stats_partials, 1, (float*)nullptr, 0);
@@ -1289,14 +1317,9 @@ extern "C" int lisec_conv_forward_ex(const lisec_conv_geom* c, const float* in, 
         LISEC_LAUNCH_CHECK();
         return LISEC_OK;
     }
-    // Dense(64) and its data gradient: the resident-workgroup kernel (LISEC_DENSE64=0: the generic path)
-    static const bool dense64 = [] { const char* e = getenv("LISEC_DENSE64"); return !e || atoi(e) != 0; }();
-    if (dense64 && g.pointwise && g.Cin == 64 && g.Cout == 64 && g.in_stride == 64 && g.out_stride == 64 && !g.row_coords &&
-        !g.out_mask && !(flags & (LISEC_CONV_ACCUMULATE | LISEC_CONV_TAG_ROOFLINE)) && !table_stats &&
-        (!sk || (sk->kind == LISEC_SINK_BACKWARD && bwd_stats)) && !(bwd_stats && !sk) && ntiles >= resident_slots()) {
+    if (p.dense64) {
         const int wgs = resident_slots();
-        if (sk) g.sink.total = (unsigned)wgs;
-        const bool xf_bn = in_bnstate != nullptr;
+        const bool xf_bn = in_bnstate != nullptr, bwd_stats = g.bwd_y != nullptr;
 #define LISEC_D64(X_, B_) hipLaunchKernelGGL((k_dense64<X_, B_>), dim3(wgs), dim3(kThreads), lds, st, g, in, packed_w, bias, \
         in_bnstate, flags, out)
         if (bwd_stats) { if (xf_bn) LISEC_D64(true, true); else LISEC_D64(false, true); }
@@ -1305,9 +1328,14 @@ extern "C" int lisec_conv_forward_ex(const lisec_conv_geom* c, const float* in, 
         LISEC_LAUNCH_CHECK();
         return LISEC_OK;
     }
-    // the halo kernel slices K by whole A tiles: (kd, kh, channel slab) entries
-    const int nstage = g.KD * g.KH * cdiv(g.Cin, BK);
-    const bool halo = halo_geom && plan.nsplit <= nstage;
+    const bool halo = p.halo, halo3 = p.halo3;
+#define LISEC_IG(M_, X_, GRID_, NS_, PART_, T0_) hipLaunchKernelGGL((k_igemm<M_, X_>), GRID_, dim3(kThreads), lds, st, g, in, \
+        packed_w, bias, in_bnstate, flags, out, stats_partials, NS_, PART_, T0_)
+#define LISEC_IG_ALL(GRID_, NS_, PART_, T0_)                                                                   \
+    do {                                                                                                       \
+        if (c->mode == 0) { if (xf) LISEC_IG(0, true, GRID_, NS_, PART_, T0_); else LISEC_IG(0, false, GRID_, NS_, PART_, T0_); } \
+        else              { if (xf) LISEC_IG(1, true, GRID_, NS_, PART_, T0_); else LISEC_IG(1, false, GRID_, NS_, PART_, T0_); } \
+    } while (0)
 #define LISEC_IH(M_, X_, GRID_, NS_, PART_, T0_)                                                                 \
     do {                                                                                                         \
         if (halo3) hipLaunchKernelGGL((k_igemm_halo<M_, X_, 0, 3>), GRID_, dim3(kThreads), lds_halo, st, g, in, packed_w, \
@@ -1322,13 +1350,8 @@ extern "C" int lisec_conv_forward_ex(const lisec_conv_geom* c, const float* in, 
             else              { if (xf) LISEC_IH(1, true, GRID_, NS_, PART_, T0_); else LISEC_IH(1, false, GRID_, NS_, PART_, T0_); } \
         } else LISEC_IG_ALL(GRID_, NS_, PART_, T0_);                                                           \
     } while (0)
-    if (!halo) g.plane_pair = 0;
-    // a layer that would run as two K slices + a combine launch (160-380 tiles): 32-column workgroups over the whole K
-    // instead -- as many workgroups, no slabs, no combine.  LISEC_HALF_N=0: the two slices.
-    static const bool half_n = [] { const char* e = getenv("LISEC_HALF_N"); return !e || atoi(e) != 0; }();
-    if (half_n && plan.nsplit == 2 && plan.tile0_tail == 0 && !g.queue) {
+    if (p.half_n) {
         dim3 grid(ntiles, cdiv(g.Cout, 32), 1);       // (no workgroups for column blocks beyond Cout: the 16-column heads)
-        if (sk) g.sink.total = grid.x * grid.y;
 #define LISEC_HN(KERNEL_, LDS_) hipLaunchKernelGGL(KERNEL_, grid, dim3(kThreads), LDS_, st, g, in, packed_w, bias, in_bnstate, \
         flags, out, stats_partials, 1, (float*)nullptr, 0)
 #define LISEC_HN_MX(M_, X_)                                                                            \
@@ -1354,19 +1377,15 @@ extern "C" int lisec_conv_forward_ex(const lisec_conv_geom* c, const float* in, 
         LISEC_LAUNCH_CHECK();
         return LISEC_OK;
     }
-    if (plan.tile0_tail > 0) {                       // whole rounds, single pass
-        dim3 grid(g.plane_pair ? launch_tiles : plan.tile0_tail, nnb, 1);
+    if (p.tile0_tail > 0) {                          // whole rounds, single pass
+        dim3 grid(g.plane_pair ? p.launch_tiles : p.tile0_tail, nnb, 1);
         LISEC_IG_ANY(grid, 1, (float*)nullptr, 0);
     }
-    if (plan.tile0_tail < ntiles) {                  // K-sliced tail (or the whole small layer)
-        LISEC_CHECK_ARG(((uintptr_t)out & 15) == 0, "split-K needs a 16-byte aligned output");
+    if (p.tile0_tail < ntiles) {                     // K-sliced tail (or the whole small layer), combined inside the kernel
+        LISEC_CHECK_ARG(((uintptr_t)workspace & 15) == 0, "split-K needs a 16-byte aligned workspace");
         float* partial = static_cast<float*>(workspace);
-        const int tail = ntiles - plan.tile0_tail;
-        dim3 grid(tail, nnb, plan.nsplit);
-        LISEC_IG_ANY(grid, plan.nsplit, partial, plan.tile0_tail);
-        hipLaunchKernelGGL((k_splitk_reduce<BM>), dim3(tail, nnb), dim3(BM * 8), 0, st, partial, plan.nsplit, g.M, g.Cout,
-                           g.CoutP, bias, flags, out, g.out_stride, stats_partials, plan.tile0_tail, tail * BM, g.row_count,
-                           g.out_mask, g.pc_span, g.pc_rows, g.Wo, g.bwd_y, g.bwd_bn, g.bwd_relu, g.sink);
+        dim3 grid(ntiles - p.tile0_tail, nnb, p.nsplit);
+        LISEC_IG_ANY(grid, p.nsplit, partial, p.tile0_tail);
     }
 #undef LISEC_IG_ANY
 #undef LISEC_IH

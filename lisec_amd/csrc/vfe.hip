@@ -29,7 +29,6 @@
 // the compact per-voxel outputs (vout / delta) on the side.
 #include "vfe_common.h"
 
-#include <cstdlib>
 
 namespace lisec {
 namespace {
@@ -532,8 +531,8 @@ extern "C" int lisec_vfe_forward(const lisec_vfe_params* p, const int32_t* info,
     // or 512 workgroups of 8 waves, pooled-input weights in registers or LDS -- all within 57.7-58.8 us for the whole
     // call; fewer (128) or smaller (4-, 2-wave) workgroups are slower.  Default: one 8-wave workgroup per CU, LDS weights;
     // two per CU for big sweeps (84 000 voxels: 253 -> 215 us for the call; nothing to choose between them at 9 400).
-    static const int shape_env = [] { const char* e = getenv("LISEC_VFE_SHAPE"); return e ? atoi(e) : -1; }();
-    const int shape = shape_env >= 0 ? shape_env : (cap_voxels > 32768 ? 5 : 1);
+    const int shape_set = tuning().vfe_shape;
+    const int shape = shape_set >= 0 ? shape_set : (cap_voxels > 32768 ? 5 : 1);
 #define LISEC_STAGE(ST_, ...)                                                                                   \
     do {                                                                                                        \
         if (shape == 0) hipLaunchKernelGGL((k_vfe_stage<ST_, 8, false>), dim3(256), dim3(512), 0, st, __VA_ARGS__);      \

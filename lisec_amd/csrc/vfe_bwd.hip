@@ -21,7 +21,6 @@
 #include "vfe_common.h"
 
 #include <cstdio>
-#include <cstdlib>
 
 namespace lisec {
 namespace {
@@ -833,8 +832,8 @@ extern "C" int lisec_vfe_backward(const lisec_vfe_params* p, const int32_t* info
     hipLaunchKernelGGL(k_l3_stats, dim3(kBwdBlocks), dim3(256), 0, st, in, sv.bn3, sv.ymm3, ws.dout, ws.parts_a);
     LISEC_LAUNCH_CHECK();
     if (int rc = launch_bn_bwd_finalize(ws.parts_a, kBwdBlocks, 64, N, g->gamma[2], g->beta[2], ws.coef, st)) return rc;
-    // LISEC_DEBUG_SYNC=1 (diagnostic): synchronise and report after every launch of this call
-    static const bool dbg = getenv("LISEC_DEBUG_SYNC") != nullptr;
+    // lisec_tuning.debug_sync (diagnostic): synchronise and report after every launch of this call
+    const bool dbg = tuning().debug_sync != 0;
 #define LISEC_DBG(WHAT_)                                                                       \
     do {                                                                                       \
         if (dbg) {                                                                             \

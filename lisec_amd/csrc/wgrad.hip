@@ -13,7 +13,6 @@
 // into the Keras kernel layout.
 #include "conv.h"
 
-#include <cstdlib>
 
 namespace lisec {
 namespace {
@@ -24,6 +23,19 @@ constexpr int BMW = 128, BC = 64;                // rows per M tile, channel blo
 constexpr int kThreads = 256;
 constexpr int TILE_FLOATS = BMW * BC;            // 8192 (32 KB)
 
+// diagnostic (tools/wgrad_stamps.py): 100 MHz s_memrealtime stamps of thread 0 of every workgroup at its phase boundaries
+// (0 entry, 1 first tile in LDS, 2 loop done, 3 slabs stored; 5 = tiles run, 6 = HW_ID | XCC_ID << 32); nullptr = off
+__device__ unsigned long long* g_wgrad_stamps = nullptr;
+#define WGRAD_STAMP(K_)                                                                                    \
+    do {                                                                                                   \
+        if (stamps && threadIdx.x == 0 && stamp_wg < 8192) {                                               \
+            stamps[(size_t)stamp_wg * 8 + (K_)] = __builtin_amdgcn_s_memrealtime();                        \
+            if ((K_) == 0)                                                                                 \
+                stamps[(size_t)stamp_wg * 8 + 6] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | \
+                                                   ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32); \
+        }                                                                                                  \
+    } while (0)
+
 // RL: row-list instantiation (tiles are tested for work by their decoded row masks, see first_live)
 template <int MODE, int TG, bool RL = false>
 __global__ void __launch_bounds__(kThreads)
@@ -31,6 +43,9 @@ k_wgrad(ConvGeom g, const float* __restrict__ in, const float* __restrict__ in_b
         const float* __restrict__ dy, const float* __restrict__ dy_bn, int nsplit, int tiles_per_split,
         float* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    unsigned long long* stamps = g_wgrad_stamps;
+    const unsigned stamp_wg = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    WGRAD_STAMP(0);
     float* sA = smem;
     float* sD = smem + TILE_FLOATS;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -104,13 +119,10 @@ k_wgrad(ConvGeom g, const float* __restrict__ in, const float* __restrict__ in_b
         dvalid = 0;
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
-            int m = tile * BMW + p * 16 + (tid >> 4);
-            if (m < mlimit && cokD) {
-                rd[p] = *reinterpret_cast<const float4*>(dy + (size_t)m * g.out_stride + cD);
-                dvalid |= 1u << p;
-            } else {
-                rd[p] = make_float4(0, 0, 0, 0);
-            }
+            const int m = tile * BMW + p * 16 + (tid >> 4);
+            const bool ok = m < mlimit && cokD;                      // branch-free: rows beyond the layer read element 0
+            rd[p] = *reinterpret_cast<const float4*>(dy + (ok ? (size_t)m * g.out_stride + cD : (size_t)0));
+            dvalid |= ok ? (1u << p) : 0u;
         }
     };
     auto store_a = [&]() {
@@ -170,7 +182,10 @@ k_wgrad(ConvGeom g, const float* __restrict__ in, const float* __restrict__ in_b
         store_d();
     }
     __syncthreads();
+    WGRAD_STAMP(1);
+    int stamp_tiles = 0;
     while (tile < t_end) {
+        stamp_tiles += t == 0;
         // next step
         int ntile = tile, nt = t + 1;
         if (nt == TG) {
@@ -208,6 +223,7 @@ k_wgrad(ConvGeom g, const float* __restrict__ in, const float* __restrict__ in_b
         t = nt;
     }
 
+    WGRAD_STAMP(2);
     // partial slab [split][tap][Cin][Cout]; C layout: col = lane&31 (n), row = (r&3)+8*(r>>2)+4*(lane>>5) (c)
     const int ntaps = g.KD * g.KH * g.KW;
 #pragma unroll
@@ -220,6 +236,8 @@ k_wgrad(ConvGeom g, const float* __restrict__ in, const float* __restrict__ in_b
             if (c < g.Cin && n < g.Cout) base[(size_t)c * g.Cout + n] = acc[tt][r];
         }
     }
+    WGRAD_STAMP(3);
+    if (stamps && threadIdx.x == 0 && stamp_wg < 8192) stamps[(size_t)stamp_wg * 8 + 5] = (unsigned long long)stamp_tiles;
 }
 
 
@@ -230,21 +248,31 @@ k_wgrad(ConvGeom g, const float* __restrict__ in, const float* __restrict__ in_b
 // kernel, no per-row address arithmetic, and 3x longer MFMA runs between barriers.  The contraction runs over the
 // rows; the tiles of a line are made equal (W' = 400 -> 4 x 100 rows) so that no short tail tile pays a full staging round.
 
-template <bool XF>
-__global__ void __launch_bounds__(kThreads)
+// The (kd, kh) groups a launch runs: groups no output line can read (depth stride 2 over a two-plane input: a third of
+// them) get no workgroups at all.
+struct LiveGroups { int n; unsigned char id[16]; };
+
+// NP: staging passes of 16 rows.  7 (tiles of <= 110 rows: the 400-wide middle layers run 4 x 100) needs 12 registers
+// fewer than 9 and, with the fragment reads software-pipelined by hand, fits three workgroups per CU.
+template <bool XF, int NP>
+__global__ void __launch_bounds__(kThreads, NP == 7 ? 3 : 2)
 k_wgrad_halo(ConvGeom g, const float* __restrict__ in, const float* __restrict__ in_bn, int flags,
              const float* __restrict__ dy, int nsplit, int tiles_per_split, float* __restrict__ partial, int flip,
-             int LT) {
+             int LT, LiveGroups live) {
+    constexpr int PA = NP, PD = NP == 7 ? 7 : 8;
     // LT <= 128: rows per tile, chosen by the host so that the tiles of one line are equal (W' = 400 -> 4 x 100) and,
     // with DR = LT rounded up to 8, the workgroup's LDS is (2 DR + 2) x 256 B: 53 760 B at LT = 100, three per CU
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    unsigned long long* stamps = g_wgrad_stamps;
+    const unsigned stamp_wg = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    WGRAD_STAMP(0);
     const int DR = (LT + 7) & ~7;
     float* sA = smem;                                  // [DR + 2][64]: halo rows, zero beyond len + 2
     float* sD = smem + (DR + 2) * BC;                  // [DR][64]: dY rows, zero beyond len
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ngroups = g.KD * g.KH;
-    const int split = blockIdx.x / ngroups, group = blockIdx.x - split * ngroups;
+    const int ngroups = live.n;
+    const int split = blockIdx.x / ngroups, group = live.id[blockIdx.x - split * ngroups];
     const int kd = group / g.KH, kh = group - kd * g.KH;
     const int c0 = blockIdx.y * BC, n0 = blockIdx.z * BC;
     const int tpl = (g.Wo + LT - 1) / LT;              // tiles per output line
@@ -263,8 +291,8 @@ k_wgrad_halo(ConvGeom g, const float* __restrict__ in, const float* __restrict__
     const float relu_lo = (flags & LISEC_CONV_IN_RELU) ? 0.f : -INFINITY;
 
     f32x16 acc0 = {0}, acc1 = {0}, acc2 = {0};
-    float4 ra[9], rd[8];
-    unsigned amask = 0;
+    float4 ra[PA], rd[PD];
+    unsigned amask = 0, dmask = 0;
     int cur_len = 0, nxt_len = 0;
 
     // tile -> (output line, w0, len, source line offset or -1)
@@ -288,8 +316,9 @@ k_wgrad_halo(ConvGeom g, const float* __restrict__ in, const float* __restrict__
         (void)tile_info(tile, w0, len, src_line, dy_line);
         nxt_len = len;
         amask = 0;
+        dmask = 0;
 #pragma unroll
-        for (int p = 0; p < 9; ++p) {                  // halo rows: slot s <-> source w = w0 - pw + s
+        for (int p = 0; p < PA; ++p) {                 // halo rows: slot s <-> source w = w0 - pw + s
             const int s_ = p * 16 + rsub;
             const int sw = w0 - g.pw + s_;
             const bool ok = cokA && s_ < len + 2 && sw >= 0 && sw < g.Wi;
@@ -298,17 +327,17 @@ k_wgrad_halo(ConvGeom g, const float* __restrict__ in, const float* __restrict__
             amask |= ok ? (1u << p) : 0u;
         }
 #pragma unroll
-        for (int p = 0; p < 8; ++p) {
+        for (int p = 0; p < PD; ++p) {
             const int j = p * 16 + rsub;
             const bool ok = cokD && j < len;
             const long long off = ok ? (dy_line + w0 + j) * g.out_stride + cD : 0;
-            const float4 v = *reinterpret_cast<const float4*>(dy + off);
-            rd[p] = ok ? v : make_float4(0, 0, 0, 0);
+            rd[p] = *reinterpret_cast<const float4*>(dy + off);      // (zeroed in store(): a select here would make the
+            dmask |= ok ? (1u << p) : 0u;                            //  wave wait for the load before its MFMAs)
         }
     };
     auto store = [&]() {
 #pragma unroll
-        for (int p = 0; p < 9; ++p) {
+        for (int p = 0; p < PA; ++p) {
             const int s_ = p * 16 + rsub;
             if (s_ < DR + 2) {
                 float4 v = ra[p];
@@ -325,8 +354,9 @@ k_wgrad_halo(ConvGeom g, const float* __restrict__ in, const float* __restrict__
             }
         }
 #pragma unroll
-        for (int p = 0; p < 8; ++p)
-            if (p * 16 + rsub < DR) *reinterpret_cast<float4*>(sD + (p * 16 + rsub) * BC + piece * 4) = rd[p];
+        for (int p = 0; p < PD; ++p)
+            if (p * 16 + rsub < DR)
+                *reinterpret_cast<float4*>(sD + (p * 16 + rsub) * BC + piece * 4) = (dmask >> p) & 1 ? rd[p] : make_float4(0, 0, 0, 0);
         cur_len = nxt_len;
     };
 
@@ -336,34 +366,62 @@ k_wgrad_halo(ConvGeom g, const float* __restrict__ in, const float* __restrict__
     int tile = next_live(t_begin);
     if (tile < t_end) { issue(tile); store(); }
     __syncthreads();
+    WGRAD_STAMP(1);
+    int stamp_tiles = 0;
     while (tile < t_end) {
+        ++stamp_tiles;
         const int ntile = next_live(tile + 1);
         if (ntile < t_end) issue(ntile);
         const int nk = (cur_len + 7) >> 3;             // rows beyond len are zero in sD: whole 8-row chunks only
-        for (int kk = 0; kk < nk; ++kk) {
-            const float* ap = aCol + kk * 8 * BC;
-            const float* dp = dCol + kk * 8 * BC;
-            const float b0 = dp[0], b1 = dp[BC], b2 = dp[2 * BC], b3 = dp[3 * BC];
-            const float a0 = ap[0], a1 = ap[BC], a2 = ap[2 * BC], a3 = ap[3 * BC], a4 = ap[4 * BC], a5 = ap[5 * BC];
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc1, 0, 0, 0);
-            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b0, acc2, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b1, acc1, 0, 0, 0);
-            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, b1, acc2, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b2, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, b2, acc1, 0, 0, 0);
-            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4, b2, acc2, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, b3, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4, b3, acc1, 0, 0, 0);
-            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a5, b3, acc2, 0, 0, 0);
+        // software-pipelined by hand: the ten fragment reads of chunk kk + 1 are issued BEFORE the twelve MFMAs of chunk kk
+        // (sched_barrier pins that; left alone the reads follow the MFMAs and every chunk waits out the LDS latency)
+        float fa[2][6], fb[2][4];
+#define LISEC_WG_READ(S_, KK_)                                                                                          \
+        do {                                                                                                            \
+            const float* ap = aCol + (KK_) * 8 * BC;                                                                    \
+            const float* dp = dCol + (KK_) * 8 * BC;                                                                    \
+            fb[S_][0] = dp[0]; fb[S_][1] = dp[BC]; fb[S_][2] = dp[2 * BC]; fb[S_][3] = dp[3 * BC];                      \
+            fa[S_][0] = ap[0]; fa[S_][1] = ap[BC]; fa[S_][2] = ap[2 * BC]; fa[S_][3] = ap[3 * BC];                      \
+            fa[S_][4] = ap[4 * BC]; fa[S_][5] = ap[5 * BC];                                                             \
+        } while (0)
+#define LISEC_WG_MFMA(S_)                                                                                               \
+        do {                                                                                                            \
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[S_][0], fb[S_][0], acc0, 0, 0, 0);                           \
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[S_][1], fb[S_][0], acc1, 0, 0, 0);                           \
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[S_][2], fb[S_][0], acc2, 0, 0, 0);                           \
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[S_][1], fb[S_][1], acc0, 0, 0, 0);                           \
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[S_][2], fb[S_][1], acc1, 0, 0, 0);                           \
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[S_][3], fb[S_][1], acc2, 0, 0, 0);                           \
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[S_][2], fb[S_][2], acc0, 0, 0, 0);                           \
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[S_][3], fb[S_][2], acc1, 0, 0, 0);                           \
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[S_][4], fb[S_][2], acc2, 0, 0, 0);                           \
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[S_][3], fb[S_][3], acc0, 0, 0, 0);                           \
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[S_][4], fb[S_][3], acc1, 0, 0, 0);                           \
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[S_][5], fb[S_][3], acc2, 0, 0, 0);                           \
+        } while (0)
+        int kk = 0;
+        if (nk > 0) LISEC_WG_READ(0, 0);
+        for (; kk + 1 < nk; kk += 2) {
+            LISEC_WG_READ(1, kk + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            LISEC_WG_MFMA(0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kk + 2 < nk) LISEC_WG_READ(0, kk + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            LISEC_WG_MFMA(1);
+            __builtin_amdgcn_sched_barrier(0);
         }
+        if (kk < nk) LISEC_WG_MFMA(0);
+#undef LISEC_WG_READ
+#undef LISEC_WG_MFMA
         __syncthreads();
         if (ntile < t_end) store();
         __syncthreads();
         tile = ntile;
     }
 
+    WGRAD_STAMP(2);
+    if (stamps && threadIdx.x == 0 && stamp_wg < 8192) stamps[(size_t)stamp_wg * 8 + 5] = (unsigned long long)stamp_tiles;
     const int ntaps = g.KD * g.KH * g.KW;
     const int tap0 = (kd * g.KH + kh) * g.KW;
     const int n = n0 + (wave & 1) * 32 + (lane & 31);
@@ -379,6 +437,7 @@ k_wgrad_halo(ConvGeom g, const float* __restrict__ in, const float* __restrict__
             if (c < g.Cin && n < g.Cout) base[(size_t)c * g.Cout + n] = acc[r];
         }
     }
+    WGRAD_STAMP(3);
 }
 
 // dW = sum over splits (index order).  transpose: write [tap][n][c] (Conv2DTranspose kernels are (kh,kw,out,in)).
@@ -386,13 +445,14 @@ k_wgrad_halo(ConvGeom g, const float* __restrict__ in, const float* __restrict__
 // added in slab order, so the result does not depend on the launch geometry.
 __global__ void __launch_bounds__(256)
 k_wgrad_reduce(const float* __restrict__ partial, int nsplit, int ntaps, int Cin, int Cout,
-               int transpose, float* __restrict__ dW) {
+               int transpose, float* __restrict__ dW, unsigned long long dead_taps) {
     const long long per = (long long)ntaps * Cin * Cout;          // Cout % 4 == 0
     const long long per4 = per >> 2;
+    const long long tap4 = ((long long)Cin * Cout) >> 2;
     for (long long i4 = blockIdx.x * 256LL + threadIdx.x; i4 < per4; i4 += (long long)gridDim.x * 256) {
         const float4* src = reinterpret_cast<const float4*>(partial) + i4;
         float4 s = make_float4(0, 0, 0, 0);
-        int k = 0;
+        int k = (dead_taps >> (i4 / tap4)) & 1 ? nsplit : 0;      // a tap no workgroup ran: its slabs were never written
         for (; k + 8 <= nsplit; k += 8) {
             float4 v[8];
 #pragma unroll
@@ -422,13 +482,14 @@ k_wgrad_reduce(const float* __restrict__ partial, int nsplit, int ntaps, int Cin
 // 8 float4 outputs per block (loads batched 8 deep), combined in lane order through LDS.
 __global__ void __launch_bounds__(256)
 k_wgrad_reduce_lanes(const float* __restrict__ partial, int nsplit, int ntaps, int Cin, int Cout,
-                     int transpose, float* __restrict__ dW) {
+                     int transpose, float* __restrict__ dW, unsigned long long dead_taps) {
     __shared__ float4 red[32][8];
     const long long per4 = ((long long)ntaps * Cin * Cout) >> 2;
+    const long long tap4 = ((long long)Cin * Cout) >> 2;
     const int tx = threadIdx.x & 7, ty = threadIdx.x >> 3;
     const long long i4 = blockIdx.x * 8LL + tx;
     float4 s = make_float4(0, 0, 0, 0);
-    if (i4 < per4) {
+    if (i4 < per4 && !((dead_taps >> (i4 / tap4)) & 1)) {
         const float4* src = reinterpret_cast<const float4*>(partial) + i4;
         int k = ty;
         for (; k + 7 * 32 < nsplit; k += 8 * 32) {
@@ -465,6 +526,7 @@ struct WgradPlan {
     int LT;              // halo kernel: rows per tile
     bool halo;
     size_t ws_bytes;
+    LiveGroups live;     // halo kernel: the (kd, kh) groups that read inside the input for at least one output line
 };
 
 WgradPlan make_plan(const ConvGeom& g, int mode = 0, bool dy_xf = false) {
@@ -475,15 +537,25 @@ WgradPlan make_plan(const ConvGeom& g, int mode = 0, bool dy_xf = false) {
     p.ntiles = cdiv(g.M, BMW);
     // 3 taps along w at stride 1 over every position of the map: the halo kernel (tiles follow the output lines)
     p.halo = mode == 0 && g.KW == 3 && g.ls_w == 0 && !g.row_coords && !dy_xf && g.Wo >= 8;
+    p.live.n = 0;
     if (p.halo) {
         p.TG = 3;
-        p.ngroups = g.KD * g.KH;
         p.LT = cdiv(g.Wo, cdiv(g.Wo, BMW));         // equal tiles per line
         p.ntiles = g.Do * g.Ho * cdiv(g.Wo, p.LT);
+        for (int kd = 0; kd < g.KD; ++kd) {
+            bool dlive = false;
+            for (int d = 0; d < g.Do && !dlive; ++d) { const int sd = (d << g.ls_d) - g.pd + kd; dlive = sd >= 0 && sd < g.Di; }
+            for (int kh = 0; kh < g.KH; ++kh) {
+                bool hlive = false;
+                for (int h = 0; h < g.Ho && !hlive; ++h) { const int sh = (h << g.ls_h) - g.ph + kh; hlive = sh >= 0 && sh < g.Hi; }
+                if (dlive && hlive && p.live.n < 16) p.live.id[p.live.n++] = (unsigned char)(kd * g.KH + kh);
+            }
+        }
+        p.ngroups = p.live.n > 0 ? p.live.n : 1;
     }
     int cb = cdiv(g.Cin, BC), nb = cdiv(g.Cout, BC);
     int base = p.ngroups * cb * nb;
-    int want = cdiv(1024, base);                // ~2 rounds of the 512 resident workgroups (measured: 512-1024 blocks
+    int want = cdiv(tuning().wgrad_blocks, base);   // 1024: ~2 rounds of the 512 resident workgroups (measured: 512-1024 blocks
                                                 // beat 1536+, whose extra slabs cost more in the reduce than they balance)
     if (want < 1) want = 1;
     if (want > p.ntiles) want = p.ntiles;
@@ -493,21 +565,11 @@ WgradPlan make_plan(const ConvGeom& g, int mode = 0, bool dy_xf = false) {
     return p;
 }
 
-// Weight gradients are leaves of the backward graph and run on a second stream beside the latency-critical
-// BatchNormalization-backward / data-gradient chain.  Their workgroups are long-lived; at three per CU they hold all
-// 160 KB of LDS and the chain's short kernels queue behind them.  LISEC_WGRAD_LDS_KB raises the LDS request so that at
-// most two fit per CU and one chain workgroup (<= 52 KB) always finds room.
-inline size_t wgrad_lds_floor() {
-    static const size_t v = [] { const char* e = getenv("LISEC_WGRAD_LDS_KB"); return e ? (size_t)atoi(e) * 1024 : (size_t)0; }();
-    return v;
-}
-
 template <int MODE>
 int launch_wgrad(const ConvGeom& g, const WgradPlan& p, const float* in, const float* in_bn, int flags,
                  const float* dy, const float* dy_bn, float* partial, hipStream_t st) {
     dim3 grid(p.nsplit * p.ngroups, cdiv(g.Cin, BC), cdiv(g.Cout, BC));
-    size_t lds = 2 * TILE_FLOATS * sizeof(float);
-    if (lds < wgrad_lds_floor()) lds = wgrad_lds_floor();
+    const size_t lds = 2 * TILE_FLOATS * sizeof(float);
 #define LISEC_WG(T)                                                                                               \
     if (g.row_coords)                                                                                             \
         hipLaunchKernelGGL((k_wgrad<MODE, T, true>), grid, dim3(kThreads), lds, st, g, in, in_bn, flags, dy, dy_bn, \
@@ -570,14 +632,13 @@ extern "C" int lisec_conv_wgrad(const lisec_conv_geom* c, const float* in, const
     if (p.halo) {
         dim3 grid(p.nsplit * p.ngroups, cdiv(g.Cin, BC), cdiv(g.Cout, BC));
         const int DR = (p.LT + 7) & ~7;
-        size_t lds = (size_t)(2 * DR + 2) * BC * sizeof(float);
-        if (lds < wgrad_lds_floor()) lds = wgrad_lds_floor();
-        if (in_bnstate || (flags & LISEC_CONV_IN_RELU))
-            hipLaunchKernelGGL(k_wgrad_halo<true>, grid, dim3(kThreads), lds, st, g, in, in_bnstate, flags, dy, p.nsplit,
-                               p.tiles_per_split, partial, flip ? 1 : 0, p.LT);
-        else
-            hipLaunchKernelGGL(k_wgrad_halo<false>, grid, dim3(kThreads), lds, st, g, in, in_bnstate, flags, dy, p.nsplit,
-                               p.tiles_per_split, partial, flip ? 1 : 0, p.LT);
+        const size_t lds = (size_t)(2 * DR + 2) * BC * sizeof(float);
+        const bool xf = in_bnstate || (flags & LISEC_CONV_IN_RELU);
+#define LISEC_WH(X_, NP_) hipLaunchKernelGGL((k_wgrad_halo<X_, NP_>), grid, dim3(kThreads), lds, st, g, in, in_bnstate, flags, dy, \
+        p.nsplit, p.tiles_per_split, partial, flip ? 1 : 0, p.LT, p.live)
+        if (p.LT + 2 <= 7 * 16) { if (xf) LISEC_WH(true, 7); else LISEC_WH(false, 7); }
+        else                    { if (xf) LISEC_WH(true, 9); else LISEC_WH(false, 9); }
+#undef LISEC_WH
         LISEC_LAUNCH_CHECK();
     } else {
         rc = c->mode == 0 ? launch_wgrad<0>(g, p, in, in_bnstate, flags, dy, dy_bnstate, partial, st)
@@ -585,15 +646,34 @@ extern "C" int lisec_conv_wgrad(const lisec_conv_geom* c, const float* in, const
     }
     if (rc) return rc;
     const int ntaps = g.KD * g.KH * g.KW;
+    unsigned long long dead_taps = 0;           // taps of the (kd, kh) groups the halo launch left out: written as zeros
+    if (p.halo) {
+        unsigned ran = 0;
+        for (int i = 0; i < p.live.n; ++i) ran |= 1u << p.live.id[i];
+        for (int gi = 0; gi < g.KD * g.KH; ++gi) {
+            if ((ran >> gi) & 1) continue;
+            const int kd = gi / g.KH, kh = gi - kd * g.KH;
+            for (int tt = 0; tt < 3; ++tt) {
+                const int tap = flip ? ((g.KD - 1 - kd) * g.KH + (g.KH - 1 - kh)) * g.KW + (2 - tt) : gi * g.KW + tt;
+                dead_taps |= 1ULL << tap;
+            }
+        }
+    }
     long long per = (long long)ntaps * g.Cin * g.Cout;
     int gb = cdiv(per / 4, 256);
     if (gb > 4096) gb = 4096;
     if (gb < 64 && p.nsplit >= 128)
         hipLaunchKernelGGL(k_wgrad_reduce_lanes, dim3(cdiv(per / 4, 8)), dim3(256), 0, st, partial, p.nsplit, ntaps,
-                           g.Cin, g.Cout, transpose_out, dW);
+                           g.Cin, g.Cout, transpose_out, dW, dead_taps);
     else
         hipLaunchKernelGGL(k_wgrad_reduce, dim3(gb), dim3(256), 0, st, partial, p.nsplit, ntaps, g.Cin, g.Cout,
-                           transpose_out, dW);
+                           transpose_out, dW, dead_taps);
     LISEC_LAUNCH_CHECK();
+    return LISEC_OK;
+}
+
+// Diagnostic: points the weight-gradient kernels' stamp buffer at `buf` (device, 8192*8 uint64) or NULL.
+extern "C" int lisec_debug_wgrad_stamps(unsigned long long* buf) {
+    LISEC_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_wgrad_stamps), &buf, sizeof(buf)));
     return LISEC_OK;
 }

@@ -34,8 +34,13 @@ class ConvLayer:
 
 
 class LisecNet:
-    def __init__(self, nx, ny, nz, maxPoints, params=None, device=None):
+    def __init__(self, nx, ny, nz, maxPoints, params=None, device=None, compose_head=True):
+        """compose_head: the three Conv2DTranspose branches and the 1x1 heads run as 16-channel contractions with composite
+        kernels (csrc/head_fused.hip; exact by linearity, the (Ho,Wo,768) concat is never formed).  False keeps the
+        layer-by-layer form (256-channel upsampling into the concat, then the 768 -> 16 heads) -- what the tests compare
+        the collapsed form against."""
         self.device = device or _lib.require_gpu()
+        self.compose_head = bool(compose_head)
         self.lib = _lib.load()
         if nx % 8 or ny % 8:
             raise ValueError("nx and ny must be multiples of 8 (three stride-2 RPN blocks)")
@@ -88,7 +93,8 @@ class LisecNet:
             self.fold_src = None
         src, src_bn = prev, None
         Ho, Wo = H // 2, W // 2
-        buf("concat", Ho, Wo, 768)
+        if not self.compose_head:
+            buf("concat", Ho, Wo, 768)
         for b, (cout, q) in enumerate(RPN_BLOCKS):
             for j in range(q + 1):
                 s = 2 if j == 0 else 1
@@ -113,9 +119,27 @@ class LisecNet:
                 g = ops.geom(1, (1, h, w), (1, h * s, w * s), (1, k, k), (1, s, s), (0, pad, pad), cin, 256,
                              out_stride=768)
                 pack = (k * k, cin, 256, 256 * cin, 1, cin)
-            self.layers.append(dict(kind="deconv", name=f"up{b+1}", src=src, slot=b, k=k, s=s, pad=pad, hw=(h, w),
-                                    cin=cin, conv=ConvLayer(f"up{b+1}", g, f"up{b+1}.kernel", pack,
-                                                            bias=f"up{b+1}.bias", in_bn=src_bn, in_relu=True)))
+            L = dict(kind="deconv", name=f"up{b+1}", src=src, slot=b, k=k, s=s, pad=pad, hw=(h, w),
+                     cin=cin, conv=ConvLayer(f"up{b+1}", g, f"up{b+1}.kernel", pack,
+                                             bias=f"up{b+1}.bias", in_bn=src_bn, in_relu=True))
+            if self.compose_head:
+                # the branch and the heads as ONE contraction to 16 channels: Wc[tap][c][j] = sum_n W[tap][n][c] H[256b+n][j]
+                taps = k * k
+                L["Wc"] = torch.empty(taps * cin * 16, dtype=f32, device=dev)
+                if k == s:
+                    # kernel == stride: a 1x1 contraction with columns (tap, j), pixel-shuffled into the head afterwards
+                    gf = ops.geom(0, (1, h, w), (1, h, w), (1, 1, 1), (1, 1, 1), (0, 0, 0), cin, taps * 16)
+                    L["wc_strides"] = (16, taps * 16)                # Wc[c][tap*16 + j]
+                    fpack = (1, cin, taps * 16, 0, taps * 16, 1)
+                    L["T"] = torch.empty((h * w, taps * 16), dtype=f32, device=dev)
+                else:
+                    gf = ops.geom(1, (1, h, w), (1, h * s, w * s), (1, k, k), (1, s, s), (0, pad, pad), cin, 16)
+                    L["wc_strides"] = (cin * 16, 16)                 # Wc[tap][c][j]
+                    fpack = (taps, cin, 16, cin * 16, 16, 1)
+                    L["T"] = None                                    # written straight into the head map
+                L["conv"] = ConvLayer(f"up{b+1}.fused", gf, None, fpack, in_bn=src_bn, in_relu=True)
+                L["up_kernel"], L["up_bias"] = f"up{b+1}.kernel", f"up{b+1}.bias"
+            self.layers.append(L)
         buf("head", Ho, Wo, 16)
         self.Ho, self.Wo = Ho, Wo
         self.head_geom = ops.geom(0, (1, Ho, Wo), (1, Ho, Wo), (1, 1, 1), (1, 1, 1), (0, 0, 0), 768, 16)
@@ -134,6 +158,10 @@ class LisecNet:
         self.packed["head"] = torch.empty(ops.packed_floats(1, 768, 16), dtype=f32, device=dev)
         self.head_w = torch.empty(768, 16, dtype=f32, device=dev)
         self.head_b = torch.empty(16, dtype=f32, device=dev)
+        self.fused_bias = torch.empty(16, dtype=f32, device=dev)     # b' = head bias + the branch biases through H
+        if self.compose_head:
+            self._shuffle = ops.HeadShuffle(Ho, Wo, [(L["T"], L["s"]) for L in self.layers
+                                                     if L["kind"] == "deconv" and L["T"] is not None])
         self.parts = torch.empty(max_parts, dtype=torch.float64, device=dev)
         self._sinks, self._bsinks = {}, {}
         self.early_pack = os.environ.get("LISEC_PACK_EARLY", "1") == "1"
@@ -175,23 +203,39 @@ class LisecNet:
         if self._packed_version == (self.params_version, self.params.version):
             return
         p = self.params
-        if getattr(self, "_pack_table", None) is None:
-            entries = []
-            for L in self.layers:
-                for key in ("conv", "dense"):
-                    if key in L:
-                        c = L[key]
-                        entries.append((p.view(c.wname), self.packed[c.name]) + tuple(c.pack))
-            self._pack_table = ops.PackTable(entries, self.device)
-        self._pack_table.run()
         if getattr(self, "_head_merge", None) is None:     # Keras-shaped head variables -> the merged (768,16) layout
             self._head_merge = ops.CopyTable([(p.view("cls.kernel")[0, 0], self.head_w[:, :2]),
                                               (p.view("reg.kernel")[0, 0], self.head_w[:, 2:]),
                                               (p.view("cls.bias"), self.head_b[:2]),
                                               (p.view("reg.bias"), self.head_b[2:])], self.device)
         self._head_merge.run()
-        ops.pack_weights(self.head_w, 1, 768, 16, 0, 16, 1, out=self.packed["head"])
+        if self.compose_head:
+            self._compose_all()
+        if getattr(self, "_pack_table", None) is None:
+            entries = []
+            for L in self.layers:
+                for key in ("conv", "dense"):
+                    if key in L:
+                        c = L[key]
+                        src = p.view(c.wname) if c.wname else L["Wc"]
+                        entries.append((src, self.packed[c.name]) + tuple(c.pack))
+            self._pack_table = ops.PackTable(entries, self.device)
+        self._pack_table.run()
+        if not self.compose_head:
+            ops.pack_weights(self.head_w, 1, 768, 16, 0, 16, 1, out=self.packed["head"])
         self._packed_version = (self.params_version, self.params.version)
+
+    def _compose_all(self):
+        """Composite kernels of the three upsampling branches with the heads, and the composite bias (head_fused.hip)."""
+        p = self.params
+        bias_in = self.head_b
+        for L in self.layers:
+            if L["kind"] != "deconv":
+                continue
+            b, ts, cs = L["slot"], *L["wc_strides"]
+            ops.head_compose(p.view(L["up_kernel"]), p.view(L["up_bias"]), self.head_w[256 * b:256 * (b + 1)], L["k"] * L["k"],
+                             L["cin"], 256, L["Wc"], ts, cs, bias_in=bias_in, bias_out=self.fused_bias)
+            bias_in = self.fused_bias
 
     def _fwd_sink(self, c):
         """BnSink of a conv layer's BatchNormalization: batch statistics summed and finalised inside the conv call."""
@@ -308,6 +352,19 @@ class LisecNet:
                 self._run_conv(L["conv"], a[L["src"]], a[L["dst"]], training)
             else:
                 b = L["slot"]
+                if self.compose_head:
+                    # 16-channel contraction: straight into the head map (with the composite bias) or into the branch's
+                    # (tap, j) columns, added to the head by the shuffle pass below
+                    c = L["conv"]
+                    dst = a["head"] if L["T"] is None else L["T"]
+
+                    def run(ws_tag, c=c, L=L, dst=dst):
+                        ops.conv_forward(c.g, a[L["src"]], self.packed[c.name], dst,
+                                         bias=self.fused_bias if L["T"] is None else None, in_bn=self.bnstate[c.in_bn],
+                                         flags=ops.IN_RELU, ws_tag=ws_tag)
+                else:
+                    def run(ws_tag, L=L, b=b):
+                        self._run_conv(L["conv"], a[L["src"]], a["concat"][:, :, 256 * b:], training, ws_tag=ws_tag)
                 if self.branch_overlap and b < len(DECONVS) - 1:
                     # an upsampling branch that is not the last: beside the next block, on the second stream
                     main = torch.cuda.current_stream()
@@ -316,17 +373,20 @@ class LisecNet:
                     self._wait(fork, self.side)
                     pin = _lib.pin_stream(self.side.cuda_stream)
                     try:
-                        self._run_conv(L["conv"], a[L["src"]], a["concat"][:, :, 256 * b:], training, ws_tag="side")
+                        run("side")
                     finally:
                         _lib.pin_stream(pin)
                     side_used = True
                 else:
-                    self._run_conv(L["conv"], a[L["src"]], a["concat"][:, :, 256 * b:], training)
+                    run("main")
         if side_used:
             join = self._event("fwd_join")
             self._record(join, self.side)
             self._wait(join, torch.cuda.current_stream())
-        ops.conv_forward(self.head_geom, a["concat"], self.packed["head"], a["head"], bias=self.head_b)
+        if self.compose_head:
+            self._shuffle.run(a["head"])
+        else:
+            ops.conv_forward(self.head_geom, a["concat"], self.packed["head"], a["head"], bias=self.head_b)
         head = a["head"]
         return head[None, :, :, :2], head[None, :, :, 2:]
 
@@ -352,7 +412,23 @@ class LisecNet:
             g = c.g
             ntaps = g.KD * g.KH * g.KW
             ws_bytes = max(ws_bytes, ops.wgrad_workspace_bytes(g))
-            if L["kind"] == "deconv":
+            if L["kind"] == "deconv" and self.compose_head:
+                # the 16-channel contraction's gradients: G = dL/dWc by the ordinary weight gradient, the data gradient with
+                # the composite kernel transposed; dy is the head gradient itself or its (tap, j) columns (dT)
+                k, sd, pad, (h, w), cin = L["k"], L["s"], L["pad"], L["hw"], L["cin"]
+                taps = k * k
+                L["G"] = torch.empty(taps * cin * 16, dtype=f32, device=dev)
+                if k == sd:
+                    L["dT"] = torch.empty_like(L["T"])
+                    self.dgeom[c.name] = ops.geom(0, (1, h, w), (1, h, w), (1, 1, 1), (1, 1, 1), (0, 0, 0), taps * 16, cin)
+                    spec = (1, taps * 16, cin, 0, 1, taps * 16)
+                else:
+                    L["dT"] = None
+                    self.dgeom[c.name] = ops.geom(0, (1, Ho, Wo), (1, h, w), (1, k, k), (1, sd, sd), (0, pad, pad), 16, cin)
+                    spec = (taps, 16, cin, cin * 16, 1, 16)
+                self.packed_t[c.name] = (torch.empty(ops.packed_floats(spec[0], spec[1], spec[2]), dtype=f32, device=dev),
+                                         spec)
+            elif L["kind"] == "deconv":
                 # data gradient of a transposed conv = plain strided conv over dY (K = out, N = in)
                 k, sd, pad, (h, w), cin = L["k"], L["s"], L["pad"], L["hw"], L["cin"]
                 ntaps = k * k
@@ -384,7 +460,11 @@ class LisecNet:
         self.dout_rows = None
         self.rows_queue = torch.zeros(2, dtype=torch.int32, device=dev)      # tile counter of the row-list data gradient
         self.head_dgeom = ops.geom(0, (1, Ho, Wo), (1, Ho, Wo), (1, 1, 1), (1, 1, 1), (0, 0, 0), 16, 768)
-        self.packed_t["head"] = (torch.empty(ops.packed_floats(1, 16, 768), dtype=f32, device=dev), None)
+        if not self.compose_head:
+            self.packed_t["head"] = (torch.empty(ops.packed_floats(1, 16, 768), dtype=f32, device=dev), None)
+        else:
+            self._dshuffle = ops.HeadShuffle(Ho, Wo, [(L["dT"], L["s"]) for L in self.layers
+                                                      if L["kind"] == "deconv" and L["dT"] is not None])
         self.head_dw = torch.empty(768, 16, dtype=f32, device=dev)
         self.up_db = torch.empty(768, dtype=f32, device=dev)
         self._fork_events, self._join_event = [], None
@@ -424,6 +504,8 @@ class LisecNet:
         if self._packed_t_version == (self.params_version, self.params.version):
             return
         p = self.params
+        if self.compose_head and self._packed_version != (self.params_version, self.params.version):
+            self._pack_all()                 # the composite kernels (Wc) are made there
         if getattr(self, "_pack_table_t", None) is None:
             entries = []
             for L in self.layers:
@@ -431,8 +513,9 @@ class LisecNet:
                     if key in L:
                         c = L[key]
                         buf, spec = self.packed_t[c.name]
-                        entries.append((p.view(c.wname), buf) + tuple(spec))
-            entries.append((self.head_w, self.packed_t["head"][0], 1, 16, 768, 0, 1, 16))
+                        entries.append((p.view(c.wname) if c.wname else L["Wc"], buf) + tuple(spec))
+            if not self.compose_head:
+                entries.append((self.head_w, self.packed_t["head"][0], 1, 16, 768, 0, 1, 16))
             self._pack_table_t = ops.PackTable(entries, self.device)
         self._pack_table_t.run()
         self._packed_t_version = (self.params_version, self.params.version)
@@ -513,9 +596,10 @@ class LisecNet:
                                               (self.head_dw[:, 2:], p.grad_view(G, "reg.kernel")[0, 0]),
                                               (self.head_db[:2], p.grad_view(G, "cls.bias")),
                                               (self.head_db[2:], p.grad_view(G, "reg.bias"))], self.device)
-            self._up_bias_split = ops.CopyTable(
-                [(self.up_db[256 * L["slot"]:256 * (L["slot"] + 1)], p.grad_view(G, L["conv"].bias))
-                 for L in self.layers if L["kind"] == "deconv"], self.device)
+            if not self.compose_head:
+                self._up_bias_split = ops.CopyTable(
+                    [(self.up_db[256 * L["slot"]:256 * (L["slot"] + 1)], p.grad_view(G, L["conv"].bias))
+                     for L in self.layers if L["kind"] == "deconv"], self.device)
 
         def head_leaves():
             ops.conv_wgrad(self.head_geom, a["concat"], d["head"], self.head_dw, self.wgrad_ws)
@@ -527,10 +611,17 @@ class LisecNet:
             ops.colsum(d["concat"], 768, M, 768, self.up_db, ws_tag="side")
             self._up_bias_split.run()
 
-        on_side(head_leaves)
-        ops.conv_forward(self.head_dgeom, d["head"], self.packed_t["head"][0], d["concat"])
-        on_side(concat_leaves)
+        if self.compose_head:
+            # collapsed branches + heads: the head gradient feeds the three 16-channel contractions directly; its column
+            # sums (the heads' bias gradient, and through H the branch biases) are the only pass over it
+            self._dshuffle.run(d["head"], backward=True)
+            on_side(lambda: ops.colsum(d["head"], 16, M, 16, self.head_db, ws_tag="side"))
+        else:
+            on_side(head_leaves)
+            ops.conv_forward(self.head_dgeom, d["head"], self.packed_t["head"][0], d["concat"])
+            on_side(concat_leaves)
         layers = self.layers
+        branches_left = [len(DECONVS)]
         first_write = set()                    # gradient buffers that already hold a contribution
 
         # ---- RPN blocks, last to first -------------------------------------------------------------
@@ -559,8 +650,27 @@ class LisecNet:
                              bwd=bwd, sink=sink, ws_tag=ws_tag)
             first_write.add(dst_name)
 
+        def branch_dy(L):
+            """The gradient a branch's contraction produced: a concat slice, or (collapsed form) the head gradient / its
+            (tap, j) columns."""
+            if not self.compose_head:
+                return d["concat"][:, :, 256 * L["slot"]:]
+            return d["head"] if L["dT"] is None else L["dT"]
+
         def deconv_wgrad(L):
             c = L["conv"]
+            if self.compose_head:
+                b, (ts, cs) = L["slot"], L["wc_strides"]
+                ops.conv_wgrad(c.g, a[L["src"]], branch_dy(L), L["G"], self.wgrad_ws, in_bn=self.bnstate[c.in_bn],
+                               flags=ops.IN_RELU)
+                ops.head_compose_backward(L["G"], ts, cs, p.view(L["up_kernel"]), p.view(L["up_bias"]),
+                                          self.head_w[256 * b:256 * (b + 1)],
+                                          self.head_db, L["k"] * L["k"], L["cin"], 256, p.grad_view(G, L["up_kernel"]),
+                                          p.grad_view(G, L["up_bias"]), self.head_dw[256 * b:256 * (b + 1)])
+                branches_left[0] -= 1
+                if branches_left[0] == 0:
+                    self._head_split.run()         # every row of dH is final: merged (768,16) -> the Keras-shaped slots
+                return
             dy = d["concat"][:, :, 256 * L["slot"]:]
             if "wgeom" in L:
                 ops.conv_wgrad(L["wgeom"], dy, a[L["src"]], p.grad_view(G, c.wname), self.wgrad_ws,
@@ -578,7 +688,7 @@ class LisecNet:
                 if L["kind"] == "deconv" and L["slot"] < len(DECONVS) - 1:
                     def branch(L=L):
                         deconv_wgrad(L)
-                        dgrad_into(L["conv"], d["concat"][:, :, 256 * L["slot"]:], L["src"], ws_tag="side")
+                        dgrad_into(L["conv"], branch_dy(L), L["src"], ws_tag="side")
                     on_side(branch)
                     flush_side()
                     ev = self._event("bwd_branch%d" % L["slot"])
@@ -592,7 +702,7 @@ class LisecNet:
                 if L["name"] in early_layers:
                     continue
                 on_side(lambda L=L: deconv_wgrad(L))
-                dgrad_into(c, d["concat"][:, :, 256 * L["slot"]:], L["src"])
+                dgrad_into(c, branch_dy(L), L["src"])
             elif L["kind"] == "conv":
                 dst = L["dst"]
                 C = c.g.Cout

@@ -97,7 +97,8 @@ _SPLITK_WS = {}
 
 def conv_workspace(g, device, row_capacity=0, tag="main"):
     """Shared split-K scratch for `g` (None when the layer is large enough to run in one pass); one buffer per stream
-    role (tag): contractions that may run at the same time on two streams must not share their slabs."""
+    role (tag): contractions that may run at the same time on two streams must not share their slabs.  Zero-filled:
+    it starts with the arrival counters of the K slices, which every call leaves at zero (include/lisec_hip.h)."""
     lib = _lib.load()
     need = (lib.lisec_conv_forward_rows_workspace_bytes(ctypes.byref(g), row_capacity) if row_capacity > 0
             else lib.lisec_conv_forward_workspace_bytes(ctypes.byref(g)))
@@ -105,7 +106,9 @@ def conv_workspace(g, device, row_capacity=0, tag="main"):
         return None
     key = (str(device), tag)
     if key not in _SPLITK_WS or _SPLITK_WS[key].numel() < need:
-        _SPLITK_WS[key] = torch.empty(need, dtype=torch.uint8, device=device)
+        if key in _SPLITK_WS:
+            torch.cuda.synchronize(device)          # a call on another stream may still be using the old buffer
+        _SPLITK_WS[key] = torch.zeros(need, dtype=torch.uint8, device=device)
     return _SPLITK_WS[key]
 
 
@@ -150,6 +153,25 @@ def conv_forward(g, x, wp, out, bias=None, in_bn=None, flags=0, stats=None, spli
                                                  ws.numel() if ws is not None else 0,
                                                  _lib.ptr(rc), _lib.ptr(rn), cap, _lib.current_stream()))
     return out
+
+
+def conv_plan(g, in_bn=False, flags=0, stats=False, splitk=True, rows_capacity=0, out_mask=None, bwd=None, sink=None,
+              queue=None):
+    """The launch plan conv_forward(...) with the same arguments runs (lisec_conv_plan_query), as a dict."""
+    lib = _lib.load()
+    ws_bytes = 0
+    if splitk:
+        ws_bytes = (lib.lisec_conv_forward_rows_workspace_bytes(ctypes.byref(g), rows_capacity) if rows_capacity > 0
+                    else lib.lisec_conv_forward_workspace_bytes(ctypes.byref(g)))
+    ex = _lib.ConvExtras(_lib.ptr(out_mask), _lib.ptr(bwd[0]) if bwd is not None else None,
+                         _lib.ptr(bwd[1]) if bwd is not None else None, 1 if (bwd is not None and bwd[2]) else 0,
+                         sink.ref if sink is not None else None, _lib.ptr(queue))
+    plan = _lib.ConvPlan()
+    _lib.check(lib.lisec_conv_plan_query(ctypes.byref(g), 1 if in_bn else 0, flags, ctypes.byref(ex), 1 if stats else 0,
+                                         ws_bytes, 1 if rows_capacity > 0 else 0, rows_capacity, ctypes.byref(plan)))
+    d = {n: getattr(plan, n) for n, _ in _lib.ConvPlan._fields_}
+    d["kernel"] = _lib.KERNEL_NAMES[d["kernel"]]
+    return d
 
 
 def num_mblocks_bwd(g):
@@ -293,3 +315,32 @@ def const_field_grads(W, S, cvec, ntaps, cin, cout, dW=None, g_all=None, cvec_ro
     _lib.check(_lib.load().lisec_const_field_grads(_lib.ptr(W), _lib.ptr(S), _lib.ptr(cvec), _lib.ptr(cvec_row),
                                                    cvec_row_max, ntaps, cin, cout, _lib.ptr(dW), _lib.ptr(g_all),
                                                    _lib.current_stream()))
+
+
+def head_compose(up_kernel, up_bias, head_w, taps, cin, cup, Wc, tap_stride, c_stride, bias_in=None, bias_out=None):
+    """Composite kernel of one upsampling branch and the heads (lisec_head_compose): Wc[tap*tap_stride + c*c_stride + j]."""
+    _lib.check(_lib.load().lisec_head_compose(_lib.ptr(up_kernel), _lib.ptr(up_bias), _lib.ptr(head_w), taps, cin, cup,
+                                              tap_stride, c_stride, _lib.ptr(Wc), _lib.ptr(bias_in), _lib.ptr(bias_out),
+                                              _lib.current_stream()))
+
+
+def head_compose_backward(G, tap_stride, c_stride, up_kernel, up_bias, head_w, S, taps, cin, cup, d_up_kernel, d_up_bias,
+                          d_head_w):
+    _lib.check(_lib.load().lisec_head_compose_backward(_lib.ptr(G), tap_stride, c_stride, _lib.ptr(up_kernel),
+                                                       _lib.ptr(up_bias), _lib.ptr(head_w), _lib.ptr(S), taps, cin, cup,
+                                                       _lib.ptr(d_up_kernel),
+                                                       _lib.ptr(d_up_bias), _lib.ptr(d_head_w), _lib.current_stream()))
+
+
+class HeadShuffle:
+    """lisec_head_shuffle over fixed branch buffers: head += pixel-shuffled T_b (forward) / T_b = shuffled dhead (backward)."""
+
+    def __init__(self, Ho, Wo, branches):
+        self.Ho, self.Wo, self.n = Ho, Wo, len(branches)
+        self.keep = [t for t, _ in branches]
+        self.T = (ctypes.c_void_p * self.n)(*[t.data_ptr() for t, _ in branches])
+        self.ps = (ctypes.c_int * self.n)(*[p for _, p in branches])
+
+    def run(self, head, backward=False):
+        _lib.check(_lib.load().lisec_head_shuffle(_lib.ptr(head), self.Ho, self.Wo, self.n, self.T, self.ps,
+                                                  1 if backward else 0, _lib.current_stream()))
