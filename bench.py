@@ -12,9 +12,11 @@ MSE+MSE loss (the reference's compile(), model_training.py:296) -> full backward
 all-reduce of the 6.49 M fp32 gradients) -> SGD-Nesterov update.  Weak scaling: one sample per GPU.
 
 Prints ONE JSON line (rank 0) with the contract fields plus
-  roofline      dominant kernel = the mid1 Conv3D implicit GEMM (fp32 MFMA bound), timed live with
-                HIP events on the launch stream
+  roofline      dominant kernel = the data gradient of the second middle Conv3D (k_igemm_halo, fp32 MFMA bound), timed
+                live with HIP events on the launch stream; clock and HBM traffic of that kernel come from the PMC passes
+                summarised in profiles/r03_pmc_dominant.json (tools/pmc_summary.py writes it; null when absent)
   roofline_vfe  the VFE grid writer (HBM bound)
+  r200k, smoothl1_ce   the same step on a 200 000-point sweep / with BASELINE config 4's loss pair
   cpu_baseline  the dense torch-CPU oracle (port of the reference's dense Keras graph) timed on this
                 host, on a stated shrunken grid, extrapolated by dense row count.
 """
@@ -32,11 +34,18 @@ import torch  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_HBM_GBS = 8000.0            # HBM3E spec (6.3 TB/s achievable per the same guide)
-# rocprofv3 --pmc passes of the dominant kernel's own launch (profiles/r02_pmc_and_experiments.txt, "round 2, field form"):
-# FETCH_SIZE 73 360 KiB (x2: the gfx950 correction for wide coalesced reads) + WRITE_SIZE 80 000 KiB per launch (algorithmic:
-# 41 MB read + 82 MB written -- the depth / halo re-reads that miss L2 make up the rest); GRBM_GUI_ACTIVE / 8 / duration
-MID2_DGRAD_TRAFFIC_BYTES = (2 * 73359.6 + 80000.0) * 1024
-MID2_DGRAD_CLOCK_GHZ = 2.30
+
+
+def pmc_dominant():
+    """Counters of the dominant kernel's own launch from the committed PMC summary (rocprofv3 --pmc passes of this file,
+    one counter set per pass, gfx950 correction FETCH_SIZE x2 applied by tools/pmc_summary.py): clock_ghz, traffic_bytes."""
+    path = os.path.join(ROOT, "profiles", "r03_pmc_dominant.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        return d
+    except (OSError, ValueError):
+        return {}
 
 
 def u20k_cloud(seed, n=20000):
@@ -277,13 +286,15 @@ def main():
         dp.broadcast_(net.params.state)
         net.params.touch()
     allreduce = dp.bucketed() if dp is not None else None
-    # LISEC_GRAPH=1 (one GPU only): the whole step (voxelise + forward + backward + SGD) captured once as a HIP graph
-    # and replayed.  Off by default: measured on ROCm 7.2 / MI355X the replay of this 260-node, two-stream graph takes
-    # 12.2 ms per step against 5.7 ms for the eager launches -- the host is not the limiter here.
-    use_graph = dp is None and os.environ.get("LISEC_GRAPH", "0") == "1"
-    if use_graph:
-        from lisec_amd.network import CapturedStep
-        captured = CapturedStep(net, vox, len(cloud), dtype=pts.dtype, loss=args.loss)
+    # One GPU: the whole step (voxelise + forward + backward + SGD + the repack for the next step) is recorded once as a
+    # step plan of the C ABI and re-issued by ONE call per step (lisec_step_plan_run: the eager launches on the same two
+    # streams, without the Python schedule in front of each of them).  LISEC_TUNING=step_plan=0, and every data-parallel
+    # run, issue each step from the Python schedule.
+    from lisec_amd import _lib
+    use_plan = dp is None and _lib.knob("step_plan", True)
+    if use_plan:
+        from lisec_amd.network import RecordedStep
+        captured = RecordedStep(net, vox, len(cloud), dtype=pts.dtype, loss=args.loss)
         captured.load(pts, ycls, yreg)          # inputs resident in HBM before the timed region, as in the eager path
         step = captured.replay
     else:
@@ -291,14 +302,8 @@ def main():
             sample = vox(pts)
             return net.train_step(sample, ycls, yreg, loss=args.loss, allreduce=allreduce)
 
-    # LISEC_MAIN_PRIORITY: run the step's main chain on a stream of that priority (the weight-gradient side stream has
-    # its own, LISEC_SIDE_PRIORITY) -- which of the two hardware queues the dispatcher favours is a scheduling knob
-    import contextlib
-    main_prio = os.environ.get("LISEC_MAIN_PRIORITY")
     torch.cuda.synchronize()
-    ctx = (torch.cuda.stream(torch.cuda.Stream(device=dev, priority=int(main_prio))) if main_prio not in (None, "")
-           else contextlib.nullcontext())
-    with ctx:
+    if True:
         for _ in range(args.warmup):
             step()
         if dp is not None:
@@ -331,6 +336,8 @@ def main():
             # symbol in the rocprofv3 --stats summary of this command is this layer alone
             ops.conv_forward(dg2, dz2, net.packed_t[c2.name][0], du1, flags=ops.TAG_ROOFLINE)
         ms = event_time_ms(run_mid2_dgrad, 20)
+        pmc = pmc_dominant()
+        pmc_src = "PMC passes of this file: " + pmc.get("source", "profiles/r03_pmc_dominant.json absent")
         # algorithmic FLOPs: 2 * output positions of the layer * 27 taps * 64 * 64 -- every (position, tap)
         # pair of the forward contraction is one pair of its transpose; the kernel runs exactly those (depth taps that
         # fall outside are skipped per tile), so executed == algorithmic here
@@ -339,8 +346,9 @@ def main():
         roofline = dict(bound="mfma", kernel="k_igemm_halo<1,false,1,2,64> mid2 Conv3D 64->64 k3 s1 data gradient", achieved=tf,
                         peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s", frac=tf / PEAK_F32_MFMA_TFLOPS,
                         frac_executed=tf / PEAK_F32_MFMA_TFLOPS, executed_share=1.0,
-                        clock_ghz=MID2_DGRAD_CLOCK_GHZ, clock_note="GRBM_GUI_ACTIVE/8/duration, PMC offline (gradient data)",
-                        traffic=MID2_DGRAD_TRAFFIC_BYTES, traffic_unit="bytes/launch (PMC, offline)",
+                        clock_ghz=pmc.get("clock_ghz"), clock_note="GRBM_GUI_ACTIVE/8/duration, " + pmc_src,
+                        traffic=pmc.get("traffic_bytes"), traffic_unit="bytes/launch, " + pmc_src,
+                        mfma_busy=pmc.get("mfma_busy"),
                         us_per_launch=ms * 1e3, flops_per_launch=flops)
         # the other large contractions, same clock: mid2 forward, and the dense form of the first Conv3D (the dominant
         # kernel of rounds 1-2; sweeps beyond LISEC_FIELD_MAX_VOXELS still take it)
@@ -391,20 +399,35 @@ def main():
                                               "grid (per-voxel outputs only, read by the field form of the first Conv3D); "
                                               "latency-bound, not an HBM roofline case"))
         voxelizer = voxelizer_leg(vox, dev, args.no_cpu_baseline)
-        r200k = None
-        if args.cloud == "u20k" and world == 1 and not use_graph:
-            # real Lyft sweeps are ~200 000 points (model_training.py:116): the same step on the R200k sweep, 10 steps
-            pts2 = torch.from_numpy(r200k_cloud(rank)).to(dev)
+        def side_leg(points_np, loss_name, steps=10):
+            """The same step on another sweep / loss pair, `steps` timed steps after 2 warm-up steps."""
+            p2 = torch.from_numpy(points_np).to(dev)
+            if use_plan:
+                from lisec_amd.network import RecordedStep
+                rec = RecordedStep(net, vox, len(points_np), dtype=p2.dtype, loss=loss_name)
+                rec.load(p2, ycls, yreg)
+                run = rec.replay
+            else:
+                rec, run = None, (lambda: net.train_step(vox(p2), ycls, yreg, loss=loss_name))
             for _ in range(2):
-                net.train_step(vox(pts2), ycls, yreg, loss=args.loss)
+                run()
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            for _ in range(10):
-                net.train_step(vox(pts2), ycls, yreg, loss=args.loss)
+            for _ in range(steps):
+                run()
             torch.cuda.synchronize()
-            d2 = (time.perf_counter() - t1) / 10
-            r200k = dict(value=1.0 / d2, unit="samples/s", ms_per_step=1e3 * d2, points=int(pts2.shape[0]),
-                         voxels=vox(pts2).host_info()["V"], steps=10)
+            d2 = (time.perf_counter() - t1) / steps
+            if rec is not None:
+                rec.close()
+            return dict(value=1.0 / d2, unit="samples/s", ms_per_step=1e3 * d2, points=int(p2.shape[0]),
+                        voxels=vox(p2).host_info()["V"], steps=steps, loss=loss_name)
+        r200k = other_loss = None
+        if args.cloud == "u20k" and world == 1:
+            # real Lyft sweeps are ~200 000 points (model_training.py:116): the same step on the R200k sweep
+            r200k = side_leg(r200k_cloud(rank), args.loss)
+            # the loss pair BASELINE config 4 names, next to the reference's own ['mse','mse'] (model_training.py:296)
+            other = "smoothl1_ce" if args.loss == "mse" else "mse"
+            other_loss = side_leg(cloud, other)
         result = {
             "metric": "lyft_samples_per_sec_fwd_bwd", "value": world * args.steps / dt, "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
@@ -418,10 +441,13 @@ def main():
                                    "voxelise+VFE+3xConv3D+RPN fwd+bwd, "
                                    + ("MSE+MSE" if args.loss == "mse" else "sigmoid-CE+SmoothL1") + ", SGD-Nesterov",
                        "global_batch": world, "parallelism": f"dp{world}", "points_per_sample": int(len(cloud)),
-                       "launch": "hipGraph replay of the captured step" if use_graph else "eager (ctypes launches)",
+                       "launch": ("step plan (lisec_step_plan_run: %d recorded launches / event edges per step)" % captured.launches)
+                                 if use_plan else "Python schedule (one ctypes call per launch)",
                        "voxels": hi["V"], "final_loss": loss_val},
             "roofline": roofline, "roofline_vfe": roofline_vfe, "voxelizer": voxelizer, "r200k": r200k,
         }
+        if other_loss is not None:
+            result[other_loss["loss"]] = other_loss
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline()
         else:

@@ -558,6 +558,29 @@ int lisec_rpn_labels(const lisec_rpn_cfg* cfg, const double* fixed_boxes, int n_
                      lisec_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * 5b. Step plans: a whole training step recorded once and re-issued by ONE call (csrc/plan.hip).
+ *     The reference repeats one static schedule 180 times (model.fit(batch_size=1, steps_per_epoch=180),
+ *     model_training.py:299).  Between lisec_step_plan_begin and lisec_step_plan_end every launch the CALLING THREAD makes
+ *     through this library -- on any stream -- and every lisec_event_record / lisec_stream_wait_event is executed as usual
+ *     AND appended to the plan with a copy of its arguments; lisec_step_plan_run re-issues them in the recorded order on
+ *     the recorded streams (plain launches, no HIP graph).  Arguments are frozen at record time: what changes from step
+ *     to step must sit in device memory the recorded launches point at (the sweep in a fixed-capacity point buffer --
+ *     pad it with points outside the grid --, the targets, the device-side iteration counter of
+ *     lisec_sgd_nesterov_step_dev).  The caller keeps every buffer alive and unchanged in address for the plan's life.
+ * ------------------------------------------------------------------------------------------ */
+typedef void* lisec_step_plan_t;
+int lisec_step_plan_create(lisec_step_plan_t* plan);
+int lisec_step_plan_begin(lisec_step_plan_t plan);
+int lisec_step_plan_end(lisec_step_plan_t plan);
+int lisec_step_plan_run(lisec_step_plan_t plan);
+int lisec_step_plan_size(lisec_step_plan_t plan);    /* recorded operations, -1 for NULL */
+int lisec_step_plan_destroy(lisec_step_plan_t plan);
+/* hipEventRecord(event, stream) / hipStreamWaitEvent(stream, event, 0) through the library, so that a recording plan sees
+ * the fork / join edges between the streams of a step; event: a hipEvent_t the caller made. */
+int lisec_event_record(void* event, lisec_stream_t stream);
+int lisec_stream_wait_event(lisec_stream_t stream, void* event);
+
+/* ------------------------------------------------------------------------------------------
  * 6. Launch-plan tuning and diagnostics.  Not needed by a caller of the hot path: the defaults are the measured
  *    optimum on MI355X; tools/ and bench.py use them to measure the alternatives.
  *    The tuning record is process-wide and read when a call is planned: change it only while no call is in flight.

@@ -196,6 +196,16 @@ def _declare(lib):
     lib.lisec_head_compose_backward.argtypes = [P, LL, LL, P, P, P, P, c_int, c_int, c_int, P, P, P, P]
     lib.lisec_head_shuffle.restype = c_int
     lib.lisec_head_shuffle.argtypes = [P, c_int, c_int, c_int, POINTER(c_void_p), POINTER(c_int), c_int, P]
+    lib.lisec_step_plan_create.restype = c_int
+    lib.lisec_step_plan_create.argtypes = [POINTER(c_void_p)]
+    for name in ("lisec_step_plan_begin", "lisec_step_plan_end", "lisec_step_plan_run", "lisec_step_plan_size",
+                 "lisec_step_plan_destroy"):
+        getattr(lib, name).restype = c_int
+        getattr(lib, name).argtypes = [P]
+    lib.lisec_event_record.restype = c_int
+    lib.lisec_event_record.argtypes = [P, P]
+    lib.lisec_stream_wait_event.restype = c_int
+    lib.lisec_stream_wait_event.argtypes = [P, P]
     lib.lisec_comm_probe.restype = c_int
     lib.lisec_comm_probe.argtypes = []
     lib.lisec_comm_count.restype = c_int
@@ -237,6 +247,18 @@ def load():
             set_tuning(**{k.strip(): int(v) for k, v in (kv.split("=") for kv in spec.split(",") if kv.strip())
                           if k.strip() in dict(Tuning._fields_)})
     return _lib
+
+
+def knob(name, default):
+    """Schedule knobs of the Python host layer (measurement aids; the defaults are the measured optimum): read once from
+    the same LISEC_TUNING="key=value,..." string as the library's lisec_tuning record."""
+    spec = os.environ.get("LISEC_TUNING", "")
+    for kv in spec.split(","):
+        if "=" in kv:
+            k, v = kv.split("=", 1)
+            if k.strip() == name:
+                return type(default)(v) if not isinstance(default, bool) else v.strip() not in ("0", "false", "")
+    return default
 
 
 def get_tuning():
@@ -319,8 +341,6 @@ def _hiprt():
     if _hip is None:
         _hip = ctypes.CDLL("libamdhip64.so")
         _hip.hipEventCreateWithFlags.argtypes = [POINTER(c_void_p), ctypes.c_uint]
-        _hip.hipEventRecord.argtypes = [c_void_p, c_void_p]
-        _hip.hipStreamWaitEvent.argtypes = [c_void_p, c_void_p, ctypes.c_uint]
         _hip.hipEventDestroy.argtypes = [c_void_p]
     return _hip
 
@@ -338,14 +358,11 @@ class DeviceEvent:
         self.handle = h
 
     def record(self, stream_handle):
-        rc = _hiprt().hipEventRecord(self.handle, c_void_p(stream_handle))
-        if rc != 0:
-            raise LisecError(f"hipEventRecord failed ({rc})")
+        # through the library (lisec_event_record), so that a recording step plan sees the edge
+        check(load().lisec_event_record(self.handle, c_void_p(stream_handle)))
 
     def wait(self, stream_handle):
-        rc = _hiprt().hipStreamWaitEvent(c_void_p(stream_handle), self.handle, 0)
-        if rc != 0:
-            raise LisecError(f"hipStreamWaitEvent failed ({rc})")
+        check(load().lisec_stream_wait_event(c_void_p(stream_handle), self.handle))
 
     def __del__(self):
         try:

@@ -123,7 +123,7 @@ k_bn_bwd_finalize(const double* __restrict__ parts, int nparts, int C, double N,
 
 int launch_bn_bwd_finalize(const double* parts, int nparts, int C, double N, float* dgamma, float* dbeta,
                            float* coef, hipStream_t st) {
-    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(cdiv(C, kRedCols)), dim3(1024), 0, st, parts, nparts, C, N, dgamma,
+    LISEC_LAUNCH(k_bn_bwd_finalize, dim3(cdiv(C, kRedCols)), dim3(1024), 0, st, parts, nparts, C, N, dgamma,
                        dbeta, coef);
     LISEC_LAUNCH_CHECK();
     return 0;
@@ -132,7 +132,7 @@ int launch_bn_bwd_finalize(const double* parts, int nparts, int C, double N, flo
 int launch_bn_finalize(const double* partials, int nparts, int C, double N, const float* gamma,
                        const float* beta, float* moving_mean, float* moving_var, int unbiased_moving,
                        float* bnstate, hipStream_t st) {
-    hipLaunchKernelGGL(k_bn_finalize, dim3(cdiv(C, kRedCols)), dim3(1024), 0, st, partials, nparts, C, N, gamma,
+    LISEC_LAUNCH(k_bn_finalize, dim3(cdiv(C, kRedCols)), dim3(1024), 0, st, partials, nparts, C, N, gamma,
                        beta, moving_mean, moving_var, unbiased_moving, bnstate);
     LISEC_LAUNCH_CHECK();
     return 0;
@@ -140,7 +140,7 @@ int launch_bn_finalize(const double* partials, int nparts, int C, double N, cons
 
 int launch_bn_fold(const float* gamma, const float* beta, const float* moving_mean,
                    const float* moving_var, int C, float* bnstate, hipStream_t st) {
-    hipLaunchKernelGGL(k_bn_fold, dim3(cdiv(C, 64)), dim3(64), 0, st, gamma, beta, moving_mean,
+    LISEC_LAUNCH(k_bn_fold, dim3(cdiv(C, 64)), dim3(64), 0, st, gamma, beta, moving_mean,
                        moving_var, C, bnstate);
     LISEC_LAUNCH_CHECK();
     return 0;
@@ -148,7 +148,7 @@ int launch_bn_fold(const float* gamma, const float* beta, const float* moving_me
 
 int launch_reduce_parts(const double* parts, int nparts, int C, double scale, float* out_f, double* out_d,
                         hipStream_t st) {
-    hipLaunchKernelGGL(k_reduce_parts, dim3(cdiv(C, kRedCols)), dim3(1024), 0, st, parts, nparts, C, scale,
+    LISEC_LAUNCH(k_reduce_parts, dim3(cdiv(C, kRedCols)), dim3(1024), 0, st, parts, nparts, C, scale,
                        out_f, out_d);
     LISEC_LAUNCH_CHECK();
     return 0;

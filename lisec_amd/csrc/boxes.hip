@@ -305,14 +305,14 @@ extern "C" int lisec_rpn_to_region(const lisec_rpn_cfg* cfg, const float* cls, i
     }
     hipStream_t st = static_cast<hipStream_t>(stream_);
     LISEC_HIP_TRY(hipMemsetAsync(ws.npicks, 0, sizeof(int) * 4, st));
-    hipLaunchKernelGGL(k_rpn_decode, dim3(cdiv(n, 256)), dim3(256), 0, st, cls, cls_stride, reg, reg_stride, *cfg,
+    LISEC_LAUNCH(k_rpn_decode, dim3(cdiv(n, 256)), dim3(256), 0, st, cls, cls_stride, reg, reg_stride, *cfg,
                        ws.boxes, ws.probs, ws.alive);
     for (int k = 0; k < max_picks; ++k) {
-        hipLaunchKernelGGL(k_nms_pick, dim3(1), dim3(1024), 0, st, ws.probs, ws.alive, n, ws.picks, ws.npicks, max_picks);
-        hipLaunchKernelGGL(k_nms_suppress, dim3(cdiv(n, 256)), dim3(256), 0, st, ws.boxes, ws.alive, n, ws.picks,
+        LISEC_LAUNCH(k_nms_pick, dim3(1), dim3(1024), 0, st, ws.probs, ws.alive, n, ws.picks, ws.npicks, max_picks);
+        LISEC_LAUNCH(k_nms_suppress, dim3(cdiv(n, 256)), dim3(256), 0, st, ws.boxes, ws.alive, n, ws.picks,
                            max_picks, overlap_thresh, cfg->anchors[0][0], cfg->anchors[0][1]);
     }
-    hipLaunchKernelGGL(k_nms_gather, dim3(1), dim3(256), 0, st, ws.boxes, ws.probs, ws.picks, ws.npicks, out_boxes,
+    LISEC_LAUNCH(k_nms_gather, dim3(1), dim3(256), 0, st, ws.boxes, ws.probs, ws.picks, ws.npicks, out_boxes,
                        out_probs);
     LISEC_HIP_TRY(hipMemcpyAsync(out_count, ws.npicks, sizeof(int), hipMemcpyDeviceToDevice, st));
     LISEC_LAUNCH_CHECK();
@@ -347,12 +347,12 @@ extern "C" int lisec_rpn_labels(const lisec_rpn_cfg* cfg, const double* fixed_bo
     LISEC_HIP_TRY(hipMemsetAsync(count, 0, sizeof(int) * (n_boxes + 1), st));
     LISEC_HIP_TRY(hipMemsetAsync(best_order, 0x7f, sizeof(int) * (n_boxes + 1), st));
     const int n = 2 * (int)cells;
-    hipLaunchKernelGGL(k_label_anchors, dim3(cdiv(n, 128)), dim3(128), 0, st, *cfg, fixed_boxes, n_boxes, iou_lo, iou_hi,
+    LISEC_LAUNCH(k_label_anchors, dim3(cdiv(n, 128)), dim3(128), 0, st, *cfg, fixed_boxes, n_boxes, iou_lo, iou_hi,
                        valid, overlap, out_regress, best_bits, count);
     if (n_boxes > 0) {
-        hipLaunchKernelGGL(k_label_best_order, dim3(cdiv(n, 128)), dim3(128), 0, st, *cfg, fixed_boxes, n_boxes, best_bits,
+        LISEC_LAUNCH(k_label_best_order, dim3(cdiv(n, 128)), dim3(128), 0, st, *cfg, fixed_boxes, n_boxes, best_bits,
                            best_order);
-        hipLaunchKernelGGL(k_label_fixup, dim3(1), dim3(64), 0, st, *cfg, fixed_boxes, n_boxes, best_bits, best_order,
+        LISEC_LAUNCH(k_label_fixup, dim3(1), dim3(64), 0, st, *cfg, fixed_boxes, n_boxes, best_bits, best_order,
                            count, valid, overlap, out_regress);
     }
     LISEC_LAUNCH_CHECK();

@@ -4,6 +4,9 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdint>
+#include <functional>
+#include <tuple>
+#include <utility>
 
 #include "../../include/lisec_hip.h"
 
@@ -41,6 +44,29 @@ const lisec_tuning& tuning();      // the process-wide launch-plan knobs (core.h
             return LISEC_EHIP;                                                            \
         }                                                                                 \
     } while (0)
+
+// ---- step plans (plan.hip; lisec_step_plan_* of the ABI) -----------------------------------------------------------------
+// Every kernel launch of the library goes through lisec::launch.  While the calling thread records a step plan, the
+// launch (kernel, geometry, stream and a COPY of its arguments) is also appended to the plan, so that lisec_step_plan_run
+// can re-issue the whole step -- ~250 launches on two streams with their fork / join events -- from one C call, without
+// the Python schedule, the plan selection or the argument marshalling that produced it.
+struct StepPlan;
+StepPlan* plan_recording();                                   // the plan this thread is recording, or nullptr
+void plan_append(StepPlan* plan, std::function<hipError_t()> op);
+
+template <typename... KArgs, typename... Args>
+inline void launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t lds, hipStream_t st, Args... args) {
+    static_assert(sizeof...(KArgs) == sizeof...(Args), "kernel argument count");
+    if (StepPlan* plan = plan_recording()) {
+        std::tuple<KArgs...> params{static_cast<KArgs>(args)...};
+        plan_append(plan, [=]() -> hipError_t {
+            std::apply([&](const KArgs&... a) { hipLaunchKernelGGL(kernel, grid, block, (unsigned)lds, st, a...); }, params);
+            return hipGetLastError();
+        });
+    }
+    hipLaunchKernelGGL(kernel, grid, block, (unsigned)lds, st, static_cast<KArgs>(args)...);
+}
+#define LISEC_LAUNCH(...) ::lisec::launch(__VA_ARGS__)
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }

@@ -290,15 +290,15 @@ extern "C" int lisec_bn_backward(const float* dA, int da_stride, const float* y,
     int nb = (int)((M + rows_per_iter - 1) / rows_per_iter);
     if (nb > kEwBlocks) nb = kEwBlocks;
     if (relu)
-        hipLaunchKernelGGL(k_bn_bwd_reduce<true>, dim3(nb), dim3(kEwThreads), 0, st, dA, da_stride, y, bnstate, M, C, parts);
+        LISEC_LAUNCH(k_bn_bwd_reduce<true>, dim3(nb), dim3(kEwThreads), 0, st, dA, da_stride, y, bnstate, M, C, parts);
     else
-        hipLaunchKernelGGL(k_bn_bwd_reduce<false>, dim3(nb), dim3(kEwThreads), 0, st, dA, da_stride, y, bnstate, M, C, parts);
+        LISEC_LAUNCH(k_bn_bwd_reduce<false>, dim3(nb), dim3(kEwThreads), 0, st, dA, da_stride, y, bnstate, M, C, parts);
     if (int rc = launch_bn_bwd_finalize(parts, nb, C, (double)M, dgamma, dbeta, coef, st)) return rc;
     double* bparts = dbias ? parts : nullptr;
     if (relu)
-        hipLaunchKernelGGL(k_bn_bwd_apply<true>, dim3(nb), dim3(kEwThreads), 0, st, dA, da_stride, y, bnstate, coef, M, C, dy, bparts);
+        LISEC_LAUNCH(k_bn_bwd_apply<true>, dim3(nb), dim3(kEwThreads), 0, st, dA, da_stride, y, bnstate, coef, M, C, dy, bparts);
     else
-        hipLaunchKernelGGL(k_bn_bwd_apply<false>, dim3(nb), dim3(kEwThreads), 0, st, dA, da_stride, y, bnstate, coef, M, C, dy, bparts);
+        LISEC_LAUNCH(k_bn_bwd_apply<false>, dim3(nb), dim3(kEwThreads), 0, st, dA, da_stride, y, bnstate, coef, M, C, dy, bparts);
     LISEC_LAUNCH_CHECK();
     if (dbias) return launch_reduce_parts(parts, nb, C, 1.0, dbias, nullptr, st);
     return LISEC_OK;
@@ -322,10 +322,10 @@ extern "C" int lisec_bn_backward_apply(const float* dA, int da_stride, const flo
     int nb = (int)((M + rows_per_iter - 1) / rows_per_iter);
     if (nb > kEwBlocks) nb = kEwBlocks;
     if (relu)
-        hipLaunchKernelGGL(k_bn_bwd_apply<true>, dim3(nb), dim3(kEwThreads), 0, st, dA, da_stride, y, bnstate, coef, M, C, dy,
+        LISEC_LAUNCH(k_bn_bwd_apply<true>, dim3(nb), dim3(kEwThreads), 0, st, dA, da_stride, y, bnstate, coef, M, C, dy,
                            (double*)nullptr);
     else
-        hipLaunchKernelGGL(k_bn_bwd_apply<false>, dim3(nb), dim3(kEwThreads), 0, st, dA, da_stride, y, bnstate, coef, M, C, dy,
+        LISEC_LAUNCH(k_bn_bwd_apply<false>, dim3(nb), dim3(kEwThreads), 0, st, dA, da_stride, y, bnstate, coef, M, C, dy,
                            (double*)nullptr);
     LISEC_LAUNCH_CHECK();
     return LISEC_OK;
@@ -342,10 +342,10 @@ extern "C" int lisec_bn_backward_apply_coef(const float* dA, int da_stride, cons
     int nb = (int)((M + rows_per_iter - 1) / rows_per_iter);
     if (nb > kEwBlocks) nb = kEwBlocks;
     if (relu)
-        hipLaunchKernelGGL(k_bn_bwd_apply<true>, dim3(nb), dim3(kEwThreads), 0, st, dA, da_stride, y, bnstate, coef, M, C, dy,
+        LISEC_LAUNCH(k_bn_bwd_apply<true>, dim3(nb), dim3(kEwThreads), 0, st, dA, da_stride, y, bnstate, coef, M, C, dy,
                            (double*)nullptr);
     else
-        hipLaunchKernelGGL(k_bn_bwd_apply<false>, dim3(nb), dim3(kEwThreads), 0, st, dA, da_stride, y, bnstate, coef, M, C, dy,
+        LISEC_LAUNCH(k_bn_bwd_apply<false>, dim3(nb), dim3(kEwThreads), 0, st, dA, da_stride, y, bnstate, coef, M, C, dy,
                            (double*)nullptr);
     LISEC_LAUNCH_CHECK();
     return LISEC_OK;
@@ -364,7 +364,7 @@ __global__ void k_copy2d_batched(const lisec_copy_desc* __restrict__ tab) {
 
 extern "C" int lisec_copy2d_batched(const lisec_copy_desc* device_table, int n, lisec_stream_t stream_) {
     LISEC_CHECK_ARG(device_table && n > 0, "bad batched copy arguments");
-    hipLaunchKernelGGL(k_copy2d_batched, dim3(n, 16), dim3(256), 0, static_cast<hipStream_t>(stream_), device_table);
+    LISEC_LAUNCH(k_copy2d_batched, dim3(n, 16), dim3(256), 0, static_cast<hipStream_t>(stream_), device_table);
     LISEC_LAUNCH_CHECK();
     return LISEC_OK;
 }
@@ -372,7 +372,7 @@ extern "C" int lisec_copy2d_batched(const lisec_copy_desc* device_table, int n, 
 extern "C" int lisec_relu_mask(float* grad, const float* act, long long n, lisec_stream_t stream_) {
     LISEC_CHECK_ARG(grad && act && n >= 0 && n % 4 == 0, "relu_mask: n must be a multiple of 4");
     if (n == 0) return LISEC_OK;
-    hipLaunchKernelGGL(k_relu_mask, dim3(ew_blocks(n / 4)), dim3(kEwThreads), 0, static_cast<hipStream_t>(stream_),
+    LISEC_LAUNCH(k_relu_mask, dim3(ew_blocks(n / 4)), dim3(kEwThreads), 0, static_cast<hipStream_t>(stream_),
                        grad, act, n / 4);
     LISEC_LAUNCH_CHECK();
     return LISEC_OK;
@@ -395,7 +395,7 @@ extern "C" int lisec_colsum(const float* x, int stride, long long M, int C, floa
     const int cap = kEwBlocks * 2 * 256 / C;                 // partial rows the workspace holds
     if (nb > cap) nb = cap;
     if (nb > kEwBlocks) nb = kEwBlocks;
-    hipLaunchKernelGGL(k_colsum, dim3(nb, slabs), dim3(kEwThreads), 0, st, x, stride, M, C, parts);
+    LISEC_LAUNCH(k_colsum, dim3(nb, slabs), dim3(kEwThreads), 0, st, x, stride, M, C, parts);
     LISEC_LAUNCH_CHECK();
     return launch_reduce_parts(parts, nb, C, 1.0, out, nullptr, st);
 }
@@ -412,8 +412,8 @@ extern "C" int lisec_rpn_loss(const float* head, const float* y_cls, const float
     hipStream_t st = static_cast<hipStream_t>(stream_);
     double* parts = static_cast<double*>(workspace);
     int nb = ew_blocks(M * 16);
-    hipLaunchKernelGGL(k_loss, dim3(nb), dim3(kEwThreads), 0, st, head, y_cls, y_reg, M, kind, grad_scale, dhead, parts);
-    hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(256), 0, st, parts, nb, (double)M, loss_out);
+    LISEC_LAUNCH(k_loss, dim3(nb), dim3(kEwThreads), 0, st, head, y_cls, y_reg, M, kind, grad_scale, dhead, parts);
+    LISEC_LAUNCH(k_loss_finalize, dim3(1), dim3(256), 0, st, parts, nb, (double)M, loss_out);
     LISEC_LAUNCH_CHECK();
     return LISEC_OK;
 }
@@ -422,7 +422,7 @@ extern "C" int lisec_sgd_nesterov_step(float* theta, const float* grad, float* v
                                        float lr_t, float momentum, lisec_stream_t stream_) {
     LISEC_CHECK_ARG(theta && grad && velocity && n >= 0 && n % 4 == 0, "sgd: n must be a multiple of 4");
     if (n == 0) return LISEC_OK;
-    hipLaunchKernelGGL(k_sgd_nesterov, dim3(ew_blocks(n / 4)), dim3(kEwThreads), 0, static_cast<hipStream_t>(stream_),
+    LISEC_LAUNCH(k_sgd_nesterov, dim3(ew_blocks(n / 4)), dim3(kEwThreads), 0, static_cast<hipStream_t>(stream_),
                        theta, grad, velocity, n / 4, lr_t, momentum);
     LISEC_LAUNCH_CHECK();
     return LISEC_OK;
@@ -432,7 +432,7 @@ extern "C" int lisec_sgd_nesterov_step_dev(float* theta, const float* grad, floa
                                            double decay, float momentum, long long* state, lisec_stream_t stream_) {
     LISEC_CHECK_ARG(theta && grad && velocity && state && n >= 0 && n % 4 == 0, "sgd: n must be a multiple of 4");
     if (n == 0) return LISEC_OK;
-    hipLaunchKernelGGL(k_sgd_nesterov_dev, dim3(ew_blocks(n / 4)), dim3(kEwThreads), 0, static_cast<hipStream_t>(stream_),
+    LISEC_LAUNCH(k_sgd_nesterov_dev, dim3(ew_blocks(n / 4)), dim3(kEwThreads), 0, static_cast<hipStream_t>(stream_),
                        theta, grad, velocity, n / 4, lr, decay, momentum, state);
     LISEC_LAUNCH_CHECK();
     return LISEC_OK;
@@ -441,7 +441,7 @@ extern "C" int lisec_sgd_nesterov_step_dev(float* theta, const float* grad, floa
 extern "C" int lisec_fold_depth(const float* in, float* out, int D, long long HW, int C, int inverse, const float* mask,
                                 lisec_stream_t stream_) {
     LISEC_CHECK_ARG(in && out && D >= 1 && HW >= 1 && C >= 1, "bad fold arguments");
-    hipLaunchKernelGGL(k_fold_depth, dim3(ew_blocks((long long)D * HW * C)), dim3(kEwThreads), 0,
+    LISEC_LAUNCH(k_fold_depth, dim3(ew_blocks((long long)D * HW * C)), dim3(kEwThreads), 0,
                        static_cast<hipStream_t>(stream_), in, out, D, HW, C, inverse, mask);
     LISEC_LAUNCH_CHECK();
     return LISEC_OK;
@@ -450,7 +450,7 @@ extern "C" int lisec_fold_depth(const float* in, float* out, int D, long long HW
 extern "C" int lisec_scale(float* x, long long n, float s, lisec_stream_t stream_) {
     LISEC_CHECK_ARG(x && n >= 0 && n % 4 == 0, "scale: n must be a multiple of 4");
     if (n == 0) return LISEC_OK;
-    hipLaunchKernelGGL(k_scale, dim3(ew_blocks(n / 4)), dim3(kEwThreads), 0, static_cast<hipStream_t>(stream_), x, n / 4, s);
+    LISEC_LAUNCH(k_scale, dim3(ew_blocks(n / 4)), dim3(kEwThreads), 0, static_cast<hipStream_t>(stream_), x, n / 4, s);
     LISEC_LAUNCH_CHECK();
     return LISEC_OK;
 }

@@ -333,11 +333,11 @@ extern "C" int lisec_conv_field_forward(const lisec_conv_geom* c, const float* v
     // big ones: the KW taps of a (kd, kh) pair share one staged A tile (84 000 voxels: 268 us against 302 us for the call)
     const int tpw_env = tuning().field_tpw;
     const int tpw = (tpw_env == 1 || tpw_env == g.KW) ? tpw_env : (row_capacity > 65536 ? g.KW : 1);
-    hipLaunchKernelGGL(k_field_taps, dim3(cdiv((long long)row_capacity + 1, FM), ntaps / tpw), dim3(kFieldThreads),
+    LISEC_LAUNCH(k_field_taps, dim3(cdiv((long long)row_capacity + 1, FM), ntaps / tpw), dim3(kFieldThreads),
                        (size_t)(FM * FLDA + FC * FC) * sizeof(float), st, g, vout, delta, info, coords, row_capacity,
                        packed_w, Z, zstride, Zc, tpw);
     const size_t dyn = sizeof(int) * ((size_t)g.KD * g.KH * LW + seg_len);
-    hipLaunchKernelGGL(k_field_combine, dim3(nblocks), dim3(kCombineThreads), dyn, st, g, cell_voxel, row_capacity,
+    LISEC_LAUNCH(k_field_combine, dim3(nblocks), dim3(kCombineThreads), dyn, st, g, cell_voxel, row_capacity,
                        (const float*)Z, zstride, (const float*)Zc, bias, out, nseg, seg_len, LW);
     LISEC_LAUNCH_CHECK();
     return LISEC_OK;

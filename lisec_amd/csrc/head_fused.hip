@@ -23,29 +23,44 @@ namespace {
 constexpr int kHeadCols = 16;
 constexpr int kMaxUp = 512;                      // channels of an upsampling branch (the reference: 256)
 
-// thread <-> (tap, c); H in LDS; the Cup values of W_b[tap][:][c] are read coalesced over c
+// Workgroup = 16 consecutive (tap, c) pairs x 16 slices of n: thread (pair p, slice q) sums n = q, q + 16, ... and the
+// slices are added in slice order through LDS (fixed order: deterministic).  A thread per (tap, c) walking all Cup rows
+// (5 workgroups for the first branch) took 60 us at the head of every step, in front of the weight repack.
+constexpr int kPairs = 16, kSlices = 16;
 __global__ void __launch_bounds__(256)
 k_head_compose(const float* __restrict__ up_kernel, const float* __restrict__ up_bias, const float* __restrict__ head_w,
                int taps, int Cin, int Cup, long long ts, long long cs, float* __restrict__ Wc,
                const float* __restrict__ bias_in, float* __restrict__ bias_out) {
     __shared__ float sH[kMaxUp * kHeadCols];
+    __shared__ float red[kSlices][kPairs][kHeadCols + 1];
     for (int i = threadIdx.x; i < Cup * kHeadCols; i += 256) sH[i] = head_w[i];
     __syncthreads();
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx < taps * Cin) {
-        const int tap = idx / Cin, c = idx - tap * Cin;
-        float acc[kHeadCols];
+    const int pl = threadIdx.x & (kPairs - 1), q = threadIdx.x / kPairs;
+    const int idx = blockIdx.x * kPairs + pl;
+    const bool live = idx < taps * Cin;
+    const int tap = live ? idx / Cin : 0, c = live ? idx - tap * Cin : 0;
+    float acc[kHeadCols];
 #pragma unroll
-        for (int j = 0; j < kHeadCols; ++j) acc[j] = 0.f;
-        const float* w = up_kernel + (size_t)tap * Cup * Cin + c;
-        for (int n = 0; n < Cup; ++n) {
-            const float v = w[(size_t)n * Cin];
+    for (int j = 0; j < kHeadCols; ++j) acc[j] = 0.f;
+    const float* w = up_kernel + (size_t)tap * Cup * Cin + c;
+    for (int n = q; n < Cup; n += kSlices) {
+        const float v = live ? w[(size_t)n * Cin] : 0.f;
 #pragma unroll
-            for (int j = 0; j < kHeadCols; ++j) acc[j] = fmaf(v, sH[n * kHeadCols + j], acc[j]);
+        for (int j = 0; j < kHeadCols; ++j) acc[j] = fmaf(v, sH[n * kHeadCols + j], acc[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < kHeadCols; ++j) red[q][pl][j] = acc[j];
+    __syncthreads();
+    {
+        const int p2 = threadIdx.x / kHeadCols, j = threadIdx.x % kHeadCols;      // 16 pairs x 16 columns
+        const int id2 = blockIdx.x * kPairs + p2;
+        if (id2 < taps * Cin) {
+            float v = 0.f;
+#pragma unroll
+            for (int k = 0; k < kSlices; ++k) v += red[k][p2][j];
+            const int t2 = id2 / Cin, c2 = id2 - t2 * Cin;
+            Wc[t2 * ts + c2 * cs + j] = v;
         }
-        float* o = Wc + tap * ts + c * cs;
-#pragma unroll
-        for (int j = 0; j < kHeadCols; ++j) o[j] = acc[j];
     }
     if (blockIdx.x == 0 && threadIdx.x < kHeadCols && bias_out) {
         const int j = threadIdx.x;
@@ -55,14 +70,16 @@ k_head_compose(const float* __restrict__ up_kernel, const float* __restrict__ up
     }
 }
 
-// dW_b[tap][n][c] = sum_j G[tap][c][j] H[n][j]
+// dW_b[tap][n][c] = sum_j G[tap][c][j] H[n][j]:  thread (tap, c) of 64 consecutive pairs x one of 4 n-quarters of the
+// 32 rows blockIdx.y owns
 __global__ void __launch_bounds__(256)
 k_head_compose_bwd_w(const float* __restrict__ G, long long ts, long long cs, const float* __restrict__ head_w, int taps,
                      int Cin, int Cup, float* __restrict__ d_up_kernel) {
-    __shared__ float sH[kMaxUp * kHeadCols];
-    for (int i = threadIdx.x; i < Cup * kHeadCols; i += 256) sH[i] = head_w[i];
+    __shared__ float sH[32 * kHeadCols];
+    const int n0 = blockIdx.y * 32;
+    for (int i = threadIdx.x; i < 32 * kHeadCols; i += 256) sH[i] = n0 * kHeadCols + i < Cup * kHeadCols ? head_w[n0 * kHeadCols + i] : 0.f;
     __syncthreads();
-    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int idx = blockIdx.x * 64 + (threadIdx.x & 63), nq = threadIdx.x >> 6;
     if (idx >= taps * Cin) return;
     const int tap = idx / Cin, c = idx - tap * Cin;
     float gq[kHeadCols];
@@ -70,10 +87,12 @@ k_head_compose_bwd_w(const float* __restrict__ G, long long ts, long long cs, co
 #pragma unroll
     for (int j = 0; j < kHeadCols; ++j) gq[j] = gp[j];
     float* o = d_up_kernel + (size_t)tap * Cup * Cin + c;
-    for (int n = 0; n < Cup; ++n) {
+    for (int i = nq * 8; i < nq * 8 + 8; ++i) {
+        const int n = n0 + i;
+        if (n >= Cup) break;
         float v = 0.f;
 #pragma unroll
-        for (int j = 0; j < kHeadCols; ++j) v = fmaf(gq[j], sH[n * kHeadCols + j], v);
+        for (int j = 0; j < kHeadCols; ++j) v = fmaf(gq[j], sH[i * kHeadCols + j], v);
         o[(size_t)n * Cin] = v;
     }
 }
@@ -146,7 +165,7 @@ extern "C" int lisec_head_compose(const float* up_kernel, const float* up_bias, 
                                   const float* bias_in, float* bias_out, lisec_stream_t stream) {
     LISEC_CHECK_ARG(up_kernel && head_w && Wc && taps > 0 && Cin > 0 && Cup > 0 && Cup <= kMaxUp, "bad compose arguments");
     LISEC_CHECK_ARG(!bias_out || up_bias, "a composite bias needs the branch bias");
-    hipLaunchKernelGGL(k_head_compose, dim3(cdiv((long long)taps * Cin, 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+    LISEC_LAUNCH(k_head_compose, dim3(cdiv((long long)taps * Cin, kPairs)), dim3(256), 0, static_cast<hipStream_t>(stream),
                        up_kernel, up_bias, head_w, taps, Cin, Cup, out_tap_stride, out_c_stride, Wc, bias_in, bias_out);
     LISEC_LAUNCH_CHECK();
     return LISEC_OK;
@@ -159,9 +178,9 @@ extern "C" int lisec_head_compose_backward(const float* G, long long g_tap_strid
     LISEC_CHECK_ARG(G && up_kernel && head_w && S && d_up_kernel && d_head_w && taps > 0 && Cin > 0 && Cup > 0 && Cup <= kMaxUp,
                     "bad compose-backward arguments");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(k_head_compose_bwd_w, dim3(cdiv((long long)taps * Cin, 256)), dim3(256), 0, st, G, g_tap_stride,
-                       g_c_stride, head_w, taps, Cin, Cup, d_up_kernel);
-    hipLaunchKernelGGL(k_head_compose_bwd_h, dim3(Cup), dim3(256), 0, st, G, g_tap_stride, g_c_stride, up_kernel, up_bias, head_w, S,
+    LISEC_LAUNCH(k_head_compose_bwd_w, dim3(cdiv((long long)taps * Cin, 64), cdiv(Cup, 32)), dim3(256), 0, st, G,
+                       g_tap_stride, g_c_stride, head_w, taps, Cin, Cup, d_up_kernel);
+    LISEC_LAUNCH(k_head_compose_bwd_h, dim3(Cup), dim3(256), 0, st, G, g_tap_stride, g_c_stride, up_kernel, up_bias, head_w, S,
                        taps, Cin, Cup, d_head_w, d_up_bias);
     LISEC_LAUNCH_CHECK();
     return LISEC_OK;
@@ -178,8 +197,8 @@ extern "C" int lisec_head_shuffle(float* head, int Ho, int Wo, int n_branches, f
     }
     const int blocks = cdiv((long long)Ho * Wo * (kHeadCols / 4), 256);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (backward) hipLaunchKernelGGL(k_head_shuffle<true>, dim3(blocks), dim3(256), 0, st, head, Ho, Wo, br);
-    else hipLaunchKernelGGL(k_head_shuffle<false>, dim3(blocks), dim3(256), 0, st, head, Ho, Wo, br);
+    if (backward) LISEC_LAUNCH(k_head_shuffle<true>, dim3(blocks), dim3(256), 0, st, head, Ho, Wo, br);
+    else LISEC_LAUNCH(k_head_shuffle<false>, dim3(blocks), dim3(256), 0, st, head, Ho, Wo, br);
     LISEC_LAUNCH_CHECK();
     return LISEC_OK;
 }

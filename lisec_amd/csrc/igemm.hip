@@ -965,7 +965,7 @@ extern "C" int lisec_conv_pack_weights(const float* src, int ntaps, int K, int N
     long long total = (long long)ntaps * Kp * Np;
     int gb = cdiv(total, 256);
     if (gb > 8192) gb = 8192;
-    hipLaunchKernelGGL(k_pack_weights, dim3(gb), dim3(256), 0, static_cast<hipStream_t>(stream_), src, ntaps,
+    LISEC_LAUNCH(k_pack_weights, dim3(gb), dim3(256), 0, static_cast<hipStream_t>(stream_), src, ntaps,
                        K, N, tap_stride, k_stride, n_stride, Kp, Np, dst);
     LISEC_LAUNCH_CHECK();
     return LISEC_OK;
@@ -977,7 +977,7 @@ extern "C" int lisec_conv_pack_weights_batched(const lisec_pack_desc* device_tab
     LISEC_CHECK_ARG(total % 4 == 0, "packed sizes are multiples of 4");
     int gb = cdiv(total / 4, 256);
     if (gb > 8192) gb = 8192;
-    hipLaunchKernelGGL(k_pack_weights_batched, dim3(gb), dim3(256), 0, static_cast<hipStream_t>(stream_),
+    LISEC_LAUNCH(k_pack_weights_batched, dim3(gb), dim3(256), 0, static_cast<hipStream_t>(stream_),
                        device_table, n, total);
     LISEC_LAUNCH_CHECK();
     return LISEC_OK;
@@ -1302,16 +1302,16 @@ extern "C" int lisec_conv_forward_ex(const lisec_conv_geom* c, const float* in, 
         dim3 grid(p.halo ? p.launch_tiles : ntiles, nnb, 1);
         if (p.halo) {
             if (c->mode == 0)
-                hipLaunchKernelGGL((k_igemm_halo<0, false, 1, 2>), grid, dim3(kThreads), halo_lds_bytes(2), st, g, in, packed_w,
+                LISEC_LAUNCH((k_igemm_halo<0, false, 1, 2>), grid, dim3(kThreads), halo_lds_bytes(2), st, g, in, packed_w,
                                    bias, in_bnstate, flags, out, stats_partials, 1, (float*)nullptr, 0);
             else
-                hipLaunchKernelGGL((k_igemm_halo<1, false, 1, 2>), grid, dim3(kThreads), halo_lds_bytes(2), st, g, in, packed_w,
+                LISEC_LAUNCH((k_igemm_halo<1, false, 1, 2>), grid, dim3(kThreads), halo_lds_bytes(2), st, g, in, packed_w,
                                    bias, in_bnstate, flags, out, stats_partials, 1, (float*)nullptr, 0);
         } else if (c->mode == 0) {
-            hipLaunchKernelGGL((k_igemm<0, false, 1>), grid, dim3(kThreads), lds, st, g, in, packed_w, bias, in_bnstate,
+            LISEC_LAUNCH((k_igemm<0, false, 1>), grid, dim3(kThreads), lds, st, g, in, packed_w, bias, in_bnstate,
                                flags, out, stats_partials, 1, (float*)nullptr, 0);
         } else {
-            hipLaunchKernelGGL((k_igemm<1, false, 1>), grid, dim3(kThreads), lds, st, g, in, packed_w, bias, in_bnstate,
+            LISEC_LAUNCH((k_igemm<1, false, 1>), grid, dim3(kThreads), lds, st, g, in, packed_w, bias, in_bnstate,
                                flags, out, stats_partials, 1, (float*)nullptr, 0);
         }
         LISEC_LAUNCH_CHECK();
@@ -1320,7 +1320,7 @@ extern "C" int lisec_conv_forward_ex(const lisec_conv_geom* c, const float* in, 
     if (p.dense64) {
         const int wgs = resident_slots();
         const bool xf_bn = in_bnstate != nullptr, bwd_stats = g.bwd_y != nullptr;
-#define LISEC_D64(X_, B_) hipLaunchKernelGGL((k_dense64<X_, B_>), dim3(wgs), dim3(kThreads), lds, st, g, in, packed_w, bias, \
+#define LISEC_D64(X_, B_) LISEC_LAUNCH((k_dense64<X_, B_>), dim3(wgs), dim3(kThreads), lds, st, g, in, packed_w, bias, \
         in_bnstate, flags, out)
         if (bwd_stats) { if (xf_bn) LISEC_D64(true, true); else LISEC_D64(false, true); }
         else           { if (xf_bn) LISEC_D64(true, false); else LISEC_D64(false, false); }
@@ -1329,7 +1329,7 @@ extern "C" int lisec_conv_forward_ex(const lisec_conv_geom* c, const float* in, 
         return LISEC_OK;
     }
     const bool halo = p.halo, halo3 = p.halo3;
-#define LISEC_IG(M_, X_, GRID_, NS_, PART_, T0_) hipLaunchKernelGGL((k_igemm<M_, X_>), GRID_, dim3(kThreads), lds, st, g, in, \
+#define LISEC_IG(M_, X_, GRID_, NS_, PART_, T0_) LISEC_LAUNCH((k_igemm<M_, X_>), GRID_, dim3(kThreads), lds, st, g, in, \
         packed_w, bias, in_bnstate, flags, out, stats_partials, NS_, PART_, T0_)
 #define LISEC_IG_ALL(GRID_, NS_, PART_, T0_)                                                                   \
     do {                                                                                                       \
@@ -1338,9 +1338,9 @@ extern "C" int lisec_conv_forward_ex(const lisec_conv_geom* c, const float* in, 
     } while (0)
 #define LISEC_IH(M_, X_, GRID_, NS_, PART_, T0_)                                                                 \
     do {                                                                                                         \
-        if (halo3) hipLaunchKernelGGL((k_igemm_halo<M_, X_, 0, 3>), GRID_, dim3(kThreads), lds_halo, st, g, in, packed_w, \
+        if (halo3) LISEC_LAUNCH((k_igemm_halo<M_, X_, 0, 3>), GRID_, dim3(kThreads), lds_halo, st, g, in, packed_w, \
                                       bias, in_bnstate, flags, out, stats_partials, NS_, PART_, T0_);            \
-        else hipLaunchKernelGGL((k_igemm_halo<M_, X_, 0, 2>), GRID_, dim3(kThreads), lds_halo, st, g, in, packed_w, bias, \
+        else LISEC_LAUNCH((k_igemm_halo<M_, X_, 0, 2>), GRID_, dim3(kThreads), lds_halo, st, g, in, packed_w, bias, \
                                 in_bnstate, flags, out, stats_partials, NS_, PART_, T0_);                        \
     } while (0)
 #define LISEC_IG_ANY(GRID_, NS_, PART_, T0_)                                                                   \
@@ -1352,7 +1352,7 @@ extern "C" int lisec_conv_forward_ex(const lisec_conv_geom* c, const float* in, 
     } while (0)
     if (p.half_n) {
         dim3 grid(ntiles, cdiv(g.Cout, 32), 1);       // (no workgroups for column blocks beyond Cout: the 16-column heads)
-#define LISEC_HN(KERNEL_, LDS_) hipLaunchKernelGGL(KERNEL_, grid, dim3(kThreads), LDS_, st, g, in, packed_w, bias, in_bnstate, \
+#define LISEC_HN(KERNEL_, LDS_) LISEC_LAUNCH(KERNEL_, grid, dim3(kThreads), LDS_, st, g, in, packed_w, bias, in_bnstate, \
         flags, out, stats_partials, 1, (float*)nullptr, 0)
 #define LISEC_HN_MX(M_, X_)                                                                            \
         do {                                                                                           \
@@ -1369,7 +1369,7 @@ extern "C" int lisec_conv_forward_ex(const lisec_conv_geom* c, const float* in, 
     }
     if (g.queue) {
         dim3 grid(resident_slots(), 1, 1);
-#define LISEC_IQ(M_, X_) hipLaunchKernelGGL((k_igemm_queue<M_, X_>), grid, dim3(kThreads), lds, st, g, in, packed_w, bias, \
+#define LISEC_IQ(M_, X_) LISEC_LAUNCH((k_igemm_queue<M_, X_>), grid, dim3(kThreads), lds, st, g, in, packed_w, bias, \
         in_bnstate, flags, out)
         if (c->mode == 0) { if (xf) LISEC_IQ(0, true); else LISEC_IQ(0, false); }
         else              { if (xf) LISEC_IQ(1, true); else LISEC_IQ(1, false); }

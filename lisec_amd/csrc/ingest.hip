@@ -37,7 +37,7 @@ extern "C" int lisec_lidar_transform(const float* raw, int n_points, int raw_str
     for (int i = 0; i < 3; ++i) ps.t[i] = translation3[i];
     int gb = cdiv(n_points, 256);
     if (gb > 2048) gb = 2048;
-    hipLaunchKernelGGL(k_lidar_transform, dim3(gb), dim3(256), 0, static_cast<hipStream_t>(stream_), raw, n_points,
+    LISEC_LAUNCH(k_lidar_transform, dim3(gb), dim3(256), 0, static_cast<hipStream_t>(stream_), raw, n_points,
                        raw_stride, ps, out);
     LISEC_LAUNCH_CHECK();
     return LISEC_OK;

@@ -181,11 +181,11 @@ extern "C" int lisec_conv_tap_sums_bn(const lisec_conv_geom* c, const float* dz,
     hipStream_t st = static_cast<hipStream_t>(stream_);
     float* line_s = static_cast<float*>(workspace);
     if (apply)
-        hipLaunchKernelGGL(k_line_sums<true>, dim3(g.Do * g.Ho), dim3(256), 0, st, g, dz, line_s, y, bnstate, coef, dy);
+        LISEC_LAUNCH(k_line_sums<true>, dim3(g.Do * g.Ho), dim3(256), 0, st, g, dz, line_s, y, bnstate, coef, dy);
     else
-        hipLaunchKernelGGL(k_line_sums<false>, dim3(g.Do * g.Ho), dim3(256), 0, st, g, dz, line_s, (const float*)nullptr,
+        LISEC_LAUNCH(k_line_sums<false>, dim3(g.Do * g.Ho), dim3(256), 0, st, g, dz, line_s, (const float*)nullptr,
                            (const float*)nullptr, (const float*)nullptr, (float*)nullptr);
-    hipLaunchKernelGGL(k_tap_sums, dim3(g.KD * g.KH * g.KW), dim3(1024), 0, st, g, line_s, S);
+    LISEC_LAUNCH(k_tap_sums, dim3(g.KD * g.KH * g.KW), dim3(1024), 0, st, g, line_s, S);
     LISEC_LAUNCH_CHECK();
     return LISEC_OK;
 }
@@ -202,14 +202,14 @@ extern "C" int lisec_const_field_grads(const float* W, const float* S, const flo
     hipStream_t st = static_cast<hipStream_t>(stream_);
     if (g_all) {
         LISEC_CHECK_ARG(W, "W is needed for g_all");
-        hipLaunchKernelGGL(k_const_field_gall, dim3(Cin), dim3(256), 0, st, W, S, ntaps, Cin, Cout, g_all);
+        LISEC_LAUNCH(k_const_field_gall, dim3(Cin), dim3(256), 0, st, W, S, ntaps, Cin, Cout, g_all);
     }
     if (dW) {
         LISEC_CHECK_ARG(cvec, "cvec is needed for dW");
         long long total = (long long)ntaps * Cin * Cout;
         int gb = cdiv(total, 256);
         if (gb > 2048) gb = 2048;
-        hipLaunchKernelGGL(k_const_field_dw, dim3(gb), dim3(256), 0, st, S, cvec, cvec_row, cvec_row_max, ntaps, Cin, Cout, dW);
+        LISEC_LAUNCH(k_const_field_dw, dim3(gb), dim3(256), 0, st, S, cvec, cvec_row, cvec_row_max, ntaps, Cin, Cout, dW);
     }
     LISEC_LAUNCH_CHECK();
     return LISEC_OK;

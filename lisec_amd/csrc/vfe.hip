@@ -535,16 +535,16 @@ extern "C" int lisec_vfe_forward(const lisec_vfe_params* p, const int32_t* info,
     const int shape = shape_set >= 0 ? shape_set : (cap_voxels > 32768 ? 5 : 1);
 #define LISEC_STAGE(ST_, ...)                                                                                   \
     do {                                                                                                        \
-        if (shape == 0) hipLaunchKernelGGL((k_vfe_stage<ST_, 8, false>), dim3(256), dim3(512), 0, st, __VA_ARGS__);      \
-        else if (shape == 5) hipLaunchKernelGGL((k_vfe_stage<ST_, 8, true>), dim3(512), dim3(512), 0, st, __VA_ARGS__);  \
-        else hipLaunchKernelGGL((k_vfe_stage<ST_, 8, true>), dim3(256), dim3(512), 0, st, __VA_ARGS__);                  \
+        if (shape == 0) LISEC_LAUNCH((k_vfe_stage<ST_, 8, false>), dim3(256), dim3(512), 0, st, __VA_ARGS__);      \
+        else if (shape == 5) LISEC_LAUNCH((k_vfe_stage<ST_, 8, true>), dim3(512), dim3(512), 0, st, __VA_ARGS__);  \
+        else LISEC_LAUNCH((k_vfe_stage<ST_, 8, true>), dim3(256), dim3(512), 0, st, __VA_ARGS__);                  \
     } while (0)
     if (training) {
         long long* stats = reinterpret_cast<long long*>(row_stats_);
         if (!stats) {                                   // no moments from the voxeliser: sum them here
             stats = own_stats;
-            hipLaunchKernelGGL(k_vfe_stats_zero, dim3(1), dim3(1024), 0, st, stats);
-            hipLaunchKernelGGL(k_vfe_stats, dim3(256), dim3(256), 0, st, in, stats);
+            LISEC_LAUNCH(k_vfe_stats_zero, dim3(1), dim3(1024), 0, st, stats);
+            LISEC_LAUNCH(k_vfe_stats, dim3(256), dim3(256), 0, st, in, stats);
         }
         long long* acc2 = stats + LISEC_ROW_STATS_MOMENT_WORDS;       // zero on entry, re-zeroed by the grid writer
         LISEC_STAGE(2, in, p->kernel[0], p->kernel[1], p->kernel[2], bn, N, sv.ymm1, sv.ymm2, sv.ymm3,
@@ -553,7 +553,7 @@ extern "C" int lisec_vfe_forward(const lisec_vfe_params* p, const int32_t* info,
                     (const long long*)nullptr, (const long long*)acc2, acc3, (long long*)nullptr, sv.arg1, sv.arg2,
                     sv.arg3, sv.y2rows);
         LISEC_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_vfe_grid, dim3(2048), dim3(256), 0, st, info, cell_voxel, ncells, cap_voxels,
+        LISEC_LAUNCH(k_vfe_grid, dim3(2048), dim3(256), 0, st, info, cell_voxel, ncells, cap_voxels,
                            sv.ymm3, sv.bn3, grid, sv.vout, sv.delta, (const long long*)acc3, N, p->gamma[2],
                            p->beta[2], p->moving_mean[2], p->moving_var[2], acc2);
     } else {
@@ -561,7 +561,7 @@ extern "C" int lisec_vfe_forward(const lisec_vfe_params* p, const int32_t* info,
                     (const long long*)nullptr, (const long long*)nullptr, (long long*)nullptr, (long long*)nullptr,
                     (unsigned char*)nullptr, (unsigned char*)nullptr, (unsigned char*)nullptr, (float*)nullptr);
         LISEC_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_vfe_grid, dim3(2048), dim3(256), 0, st, info, cell_voxel, ncells, cap_voxels,
+        LISEC_LAUNCH(k_vfe_grid, dim3(2048), dim3(256), 0, st, info, cell_voxel, ncells, cap_voxels,
                            sv.ymm3, sv.bn3, grid, sv.vout, sv.delta, (const long long*)nullptr, N,
                            (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (float*)nullptr,
                            (long long*)nullptr);
@@ -575,7 +575,7 @@ extern "C" int lisec_vfe_grid_from_saved(const int32_t* info, const int32_t* cel
                                          int cap_voxels, const float* saved, float* grid, lisec_stream_t stream_) {
     LISEC_CHECK_ARG(info && cell_voxel && saved && grid && ncells > 0 && cap_voxels >= 0, "bad arguments");
     VfeSaved sv(const_cast<float*>(saved), cap_voxels);
-    hipLaunchKernelGGL(k_vfe_grid, dim3(2048), dim3(256), 0, static_cast<hipStream_t>(stream_), info, cell_voxel,
+    LISEC_LAUNCH(k_vfe_grid, dim3(2048), dim3(256), 0, static_cast<hipStream_t>(stream_), info, cell_voxel,
                        ncells, cap_voxels, sv.ymm3, sv.bn3, grid, (float*)nullptr, (float*)nullptr,
                        (const long long*)nullptr, 0.0, (const float*)nullptr, (const float*)nullptr, (float*)nullptr,
                        (float*)nullptr, (long long*)nullptr);

@@ -816,20 +816,20 @@ extern "C" int lisec_vfe_backward(const lisec_vfe_params* p, const int32_t* info
     // 1. route the grid gradient to voxels
     if (dgrid) {
         const int gblocks = 1024;
-        hipLaunchKernelGGL(k_gather, dim3(gblocks), dim3(256), 0, st, info, cell_voxel, ncells, cap_voxels, dgrid,
+        LISEC_LAUNCH(k_gather, dim3(gblocks), dim3(256), 0, st, info, cell_voxel, ncells, cap_voxels, dgrid,
                            ws.dout, ws.parts_a);
-        hipLaunchKernelGGL(k_virtual_dout, dim3(1), dim3(1024), 0, st, info, cap_voxels, ws.parts_a, gblocks, ws.dout);
+        LISEC_LAUNCH(k_virtual_dout, dim3(1), dim3(1024), 0, st, info, cap_voxels, ws.parts_a, gblocks, ws.dout);
     } else {
         // rows [0,V) were computed at the occupied cells only; the virtual voxel gets total - occupied
         ws.dout = dout_rows;
         const int cb = 256;
-        hipLaunchKernelGGL(k_rows_colsum, dim3(cb), dim3(256), 0, st, info, cap_voxels, dout_rows, ws.parts_a);
-        hipLaunchKernelGGL(k_virtual_from_total, dim3(1), dim3(1024), 0, st, info, cap_voxels, ws.parts_a, cb, g_all,
+        LISEC_LAUNCH(k_rows_colsum, dim3(cb), dim3(256), 0, st, info, cap_voxels, dout_rows, ws.parts_a);
+        LISEC_LAUNCH(k_virtual_from_total, dim3(1), dim3(1024), 0, st, info, cap_voxels, ws.parts_a, cb, g_all,
                            dout_rows);
     }
     LISEC_LAUNCH_CHECK();
     // 2. layer 3 (fcn)
-    hipLaunchKernelGGL(k_l3_stats, dim3(kBwdBlocks), dim3(256), 0, st, in, sv.bn3, sv.ymm3, ws.dout, ws.parts_a);
+    LISEC_LAUNCH(k_l3_stats, dim3(kBwdBlocks), dim3(256), 0, st, in, sv.bn3, sv.ymm3, ws.dout, ws.parts_a);
     LISEC_LAUNCH_CHECK();
     if (int rc = launch_bn_bwd_finalize(ws.parts_a, kBwdBlocks, 64, N, g->gamma[2], g->beta[2], ws.coef, st)) return rc;
     // lisec_tuning.debug_sync (diagnostic): synchronise and report after every launch of this call
@@ -852,34 +852,34 @@ extern "C" int lisec_vfe_backward(const lisec_vfe_params* p, const int32_t* info
         if (vblocks > 2048) vblocks = 2048;
         if (vblocks < 1) vblocks = 1;
         TileCtx cx{ws.slot_vox, ws.pool1, ws.pool2, ws.aw1, ws.aw2, ws.aw3};
-        hipLaunchKernelGGL(k_slot_prep, dim3(vblocks), dim3(256), 0, st, in, sv.bn1, sv.bn2, sv.bn3, sv.ymm1, sv.ymm2,
+        LISEC_LAUNCH(k_slot_prep, dim3(vblocks), dim3(256), 0, st, in, sv.bn1, sv.bn2, sv.bn3, sv.ymm1, sv.ymm2,
                            sv.arg1, sv.arg2, sv.arg3, ws.slot_vox, ws.pool1, ws.pool2, ws.aw1, ws.aw2, ws.aw3);
         LISEC_DBG("k_slot_prep");
         const size_t ldsT3 = (size_t)(4 * 2 * 32 * kLdT + 2 * 64 * 64 + 6 * 64 + 2 * 32 + 96) * sizeof(float);
-        hipLaunchKernelGGL(k_bwd_tile<3>, dim3(kTileBlocks), dim3(256), ldsT3, st, in, cx, p->kernel[2], p->kernel[0],
+        LISEC_LAUNCH(k_bwd_tile<3>, dim3(kTileBlocks), dim3(256), ldsT3, st, in, cx, p->kernel[2], p->kernel[0],
                            sv.bn2, sv.bn3, ws.coef, sv.y2rows, ws.dout, ws.gh, ws.parts_dw);
         LISEC_LAUNCH_CHECK();
         LISEC_DBG("k_bwd_tile<3>");
         if (int rc = launch_reduce_parts(ws.parts_dw, kTileBlocks, 64 * 64, 1.0, g->kernel[2], nullptr, st)) return rc;
-        hipLaunchKernelGGL(k_post<3>, dim3(vblocks), dim3(256), 0, st, in, p->kernel[0], sv.bn2, ws.aw2, sv.y2rows,
+        LISEC_LAUNCH(k_post<3>, dim3(vblocks), dim3(256), 0, st, in, p->kernel[0], sv.bn2, ws.aw2, sv.y2rows,
                            ws.gh, ws.gz2, ws.parts_a);
         LISEC_LAUNCH_CHECK();
         LISEC_DBG("k_post<3>");
         if (int rc = launch_bn_bwd_finalize(ws.parts_a, vblocks, 32, N, g->gamma[1], g->beta[1], ws.coef, st)) return rc;
         const size_t ldsT2 = (size_t)(4 * 2 * 32 * kLdT + 2 * 32 * 32 + 6 * 32 + 2 * 16 + 96) * sizeof(float);
-        hipLaunchKernelGGL(k_bwd_tile<2>, dim3(kTileBlocks), dim3(256), ldsT2, st, in, cx, p->kernel[1], p->kernel[0],
+        LISEC_LAUNCH(k_bwd_tile<2>, dim3(kTileBlocks), dim3(256), ldsT2, st, in, cx, p->kernel[1], p->kernel[0],
                            sv.bn1, sv.bn2, ws.coef, sv.y2rows, ws.gz2, ws.gh, ws.parts_dw);
         LISEC_LAUNCH_CHECK();
         LISEC_DBG("k_bwd_tile<2>");
         if (int rc = launch_reduce_parts(ws.parts_dw, kTileBlocks, 32 * 32, 1.0, g->kernel[1], nullptr, st)) return rc;
-        hipLaunchKernelGGL(k_post<2>, dim3(vblocks), dim3(256), 0, st, in, p->kernel[0], sv.bn1, ws.aw1, sv.y2rows,
+        LISEC_LAUNCH(k_post<2>, dim3(vblocks), dim3(256), 0, st, in, p->kernel[0], sv.bn1, ws.aw1, sv.y2rows,
                            ws.gh, ws.gz1, ws.parts_a);
         LISEC_LAUNCH_CHECK();
         LISEC_DBG("k_post<2>");
         if (int rc = launch_bn_bwd_finalize(ws.parts_a, vblocks, 16, N, g->gamma[0], g->beta[0], ws.coef, st)) return rc;
     } else {
         size_t lds3 = (size_t)(4 * 2 * kMaxRows * 32 + 64 * 64) * sizeof(float);
-        hipLaunchKernelGGL(k_l3, dim3(kL3Blocks), dim3(256), lds3, st, in, p->kernel[0], p->kernel[1], p->kernel[2],
+        LISEC_LAUNCH(k_l3, dim3(kL3Blocks), dim3(256), lds3, st, in, p->kernel[0], p->kernel[1], p->kernel[2],
                            sv.bn1, sv.bn2, sv.bn3, ws.coef, sv.ymm1, sv.ymm2, sv.ymm3, ws.dout, ws.gz2, ws.parts_dw,
                            ws.parts_a);
         LISEC_LAUNCH_CHECK();
@@ -887,14 +887,14 @@ extern "C" int lisec_vfe_backward(const lisec_vfe_params* p, const int32_t* info
         if (int rc = launch_bn_bwd_finalize(ws.parts_a, kL3Blocks, 32, N, g->gamma[1], g->beta[1], ws.coef, st)) return rc;
         // 3. layer 2
         size_t lds2 = (size_t)(4 * 2 * kMaxRows * 16 + 32 * 32) * sizeof(float);
-        hipLaunchKernelGGL(k_l2, dim3(kBwdBlocks), dim3(256), lds2, st, in, p->kernel[0], p->kernel[1], sv.bn1, sv.bn2,
+        LISEC_LAUNCH(k_l2, dim3(kBwdBlocks), dim3(256), lds2, st, in, p->kernel[0], p->kernel[1], sv.bn1, sv.bn2,
                            ws.coef, sv.ymm1, ws.gz2, ws.gz1, ws.parts_dw, ws.parts_a);
         LISEC_LAUNCH_CHECK();
         if (int rc = launch_reduce_parts(ws.parts_dw, kBwdBlocks, 32 * 32, 1.0, g->kernel[1], nullptr, st)) return rc;
         if (int rc = launch_bn_bwd_finalize(ws.parts_a, kBwdBlocks, 16, N, g->gamma[0], g->beta[0], ws.coef, st)) return rc;
     }
     // 4. layer 1
-    hipLaunchKernelGGL(k_l1, dim3(kBwdBlocks), dim3(256), 0, st, in, p->kernel[0], sv.bn1, ws.coef, ws.gz1,
+    LISEC_LAUNCH(k_l1, dim3(kBwdBlocks), dim3(256), 0, st, in, p->kernel[0], sv.bn1, ws.coef, ws.gz1,
                        ws.parts_dw);
     LISEC_LAUNCH_CHECK();
     return launch_reduce_parts(ws.parts_dw, kBwdBlocks, 6 * 16, 1.0, g->kernel[0], nullptr, st);

@@ -407,38 +407,38 @@ extern "C" int lisec_voxelize(const lisec_voxel_cfg* cfg, const void* points, in
     {
         int zb = cdiv(g.ncells >> 2, 256);
         if (zb > 1024) zb = 1024;
-        hipLaunchKernelGGL(k_zero_counts, dim3(zb < 1 ? 1 : zb), dim3(256), 0, st, w.cell_count, g.ncells, info);
+        LISEC_LAUNCH(k_zero_counts, dim3(zb < 1 ? 1 : zb), dim3(256), 0, st, w.cell_count, g.ncells, info);
     }
     const int nblk = cdiv(g.ncells, kCellsPerBlock);
     if (n_points > 0) {
         int gb = cdiv(n_points, 256);
         if (dtype == 0)
-            hipLaunchKernelGGL(k_key_count<float>, dim3(gb), dim3(256), 0, st, (const float*)points,
+            LISEC_LAUNCH(k_key_count<float>, dim3(gb), dim3(256), 0, st, (const float*)points,
                                n_points, point_stride, g, w.cell_count, w.key, w.rank);
         else
-            hipLaunchKernelGGL(k_key_count<double>, dim3(gb), dim3(256), 0, st, (const double*)points,
+            LISEC_LAUNCH(k_key_count<double>, dim3(gb), dim3(256), 0, st, (const double*)points,
                                n_points, point_stride, g, w.cell_count, w.key, w.rank);
         LISEC_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(k_cell_totals, dim3(nblk), dim3(kScanThreads), 0, st, w.cell_count, g, w.totals);
+    LISEC_LAUNCH(k_cell_totals, dim3(nblk), dim3(kScanThreads), 0, st, w.cell_count, g, w.totals);
     long long* stats = reinterpret_cast<long long*>(row_stats);
-    hipLaunchKernelGGL(k_scan_totals, dim3(1), dim3(1024), 0, st, w.totals, nblk, cap_voxels, info,
+    LISEC_LAUNCH(k_scan_totals, dim3(1), dim3(1024), 0, st, w.totals, nblk, cap_voxels, info,
                        row_start, stats);
-    hipLaunchKernelGGL(k_cell_assign, dim3(nblk), dim3(kScanThreads), 0, st, w.cell_count, w.totals, g,
+    LISEC_LAUNCH(k_cell_assign, dim3(nblk), dim3(kScanThreads), 0, st, w.cell_count, w.totals, g,
                        cap_voxels, cell_voxel, coords, counts, npts, w.pt_start, row_start, info);
     LISEC_LAUNCH_CHECK();
     if (n_points > 0 && cap_voxels > 0) {
         int gb = cdiv(n_points, 256);
-        hipLaunchKernelGGL(k_place, dim3(gb), dim3(256), 0, st, w.key, w.rank, n_points, cell_voxel,
+        LISEC_LAUNCH(k_place, dim3(gb), dim3(256), 0, st, w.key, w.rank, n_points, cell_voxel,
                            w.pt_start, w.bucket);
         int fb = cdiv(cap_voxels, 4);
         if (fb > 2048) fb = 2048;
         if (dtype == 0)
-            hipLaunchKernelGGL(k_features<float>, dim3(fb), dim3(256), 0, st, (const float*)points,
+            LISEC_LAUNCH(k_features<float>, dim3(fb), dim3(256), 0, st, (const float*)points,
                                point_stride, info, cap_voxels, g.T, counts, w.pt_start, row_start,
                                w.bucket, rows, row_point, stats);
         else
-            hipLaunchKernelGGL(k_features<double>, dim3(fb), dim3(256), 0, st, (const double*)points,
+            LISEC_LAUNCH(k_features<double>, dim3(fb), dim3(256), 0, st, (const double*)points,
                                point_stride, info, cap_voxels, g.T, counts, w.pt_start, row_start,
                                w.bucket, rows, row_point, stats);
         LISEC_LAUNCH_CHECK();
@@ -456,7 +456,7 @@ extern "C" int lisec_voxel_rows_to_padded(const int32_t* info, const int32_t* np
     long long total = (long long)cap_voxels * sampleSize * 6;
     int gb = cdiv(total, 256);
     if (gb > 4096) gb = 4096;
-    hipLaunchKernelGGL(k_rows_to_padded, dim3(gb), dim3(256), 0, st, info, cap_voxels, npts, row_start,
+    LISEC_LAUNCH(k_rows_to_padded, dim3(gb), dim3(256), 0, st, info, cap_voxels, npts, row_start,
                        rows, sampleSize, padded);
     LISEC_LAUNCH_CHECK();
     return LISEC_OK;

@@ -572,10 +572,10 @@ int launch_wgrad(const ConvGeom& g, const WgradPlan& p, const float* in, const f
     const size_t lds = 2 * TILE_FLOATS * sizeof(float);
 #define LISEC_WG(T)                                                                                               \
     if (g.row_coords)                                                                                             \
-        hipLaunchKernelGGL((k_wgrad<MODE, T, true>), grid, dim3(kThreads), lds, st, g, in, in_bn, flags, dy, dy_bn, \
+        LISEC_LAUNCH((k_wgrad<MODE, T, true>), grid, dim3(kThreads), lds, st, g, in, in_bn, flags, dy, dy_bn, \
                            p.nsplit, p.tiles_per_split, partial);                                                 \
     else                                                                                                          \
-        hipLaunchKernelGGL((k_wgrad<MODE, T, false>), grid, dim3(kThreads), lds, st, g, in, in_bn, flags, dy, \
+        LISEC_LAUNCH((k_wgrad<MODE, T, false>), grid, dim3(kThreads), lds, st, g, in, in_bn, flags, dy, \
                                        dy_bn, p.nsplit, p.tiles_per_split, partial)
     switch (p.TG) {
         case 1: LISEC_WG(1); break;
@@ -634,7 +634,7 @@ extern "C" int lisec_conv_wgrad(const lisec_conv_geom* c, const float* in, const
         const int DR = (p.LT + 7) & ~7;
         const size_t lds = (size_t)(2 * DR + 2) * BC * sizeof(float);
         const bool xf = in_bnstate || (flags & LISEC_CONV_IN_RELU);
-#define LISEC_WH(X_, NP_) hipLaunchKernelGGL((k_wgrad_halo<X_, NP_>), grid, dim3(kThreads), lds, st, g, in, in_bnstate, flags, dy, \
+#define LISEC_WH(X_, NP_) LISEC_LAUNCH((k_wgrad_halo<X_, NP_>), grid, dim3(kThreads), lds, st, g, in, in_bnstate, flags, dy, \
         p.nsplit, p.tiles_per_split, partial, flip ? 1 : 0, p.LT, p.live)
         if (p.LT + 2 <= 7 * 16) { if (xf) LISEC_WH(true, 7); else LISEC_WH(false, 7); }
         else                    { if (xf) LISEC_WH(true, 9); else LISEC_WH(false, 9); }
@@ -663,10 +663,10 @@ extern "C" int lisec_conv_wgrad(const lisec_conv_geom* c, const float* in, const
     int gb = cdiv(per / 4, 256);
     if (gb > 4096) gb = 4096;
     if (gb < 64 && p.nsplit >= 128)
-        hipLaunchKernelGGL(k_wgrad_reduce_lanes, dim3(cdiv(per / 4, 8)), dim3(256), 0, st, partial, p.nsplit, ntaps,
+        LISEC_LAUNCH(k_wgrad_reduce_lanes, dim3(cdiv(per / 4, 8)), dim3(256), 0, st, partial, p.nsplit, ntaps,
                            g.Cin, g.Cout, transpose_out, dW, dead_taps);
     else
-        hipLaunchKernelGGL(k_wgrad_reduce, dim3(gb), dim3(256), 0, st, partial, p.nsplit, ntaps, g.Cin, g.Cout,
+        LISEC_LAUNCH(k_wgrad_reduce, dim3(gb), dim3(256), 0, st, partial, p.nsplit, ntaps, g.Cin, g.Cout,
                            transpose_out, dW, dead_taps);
     LISEC_LAUNCH_CHECK();
     return LISEC_OK;

@@ -312,7 +312,7 @@ class Model:
                 i = int(order[st % len(order)])
                 yc, yr = target(i)
                 if captured is not None:
-                    # the whole step (voxelise + forward + backward + update) replayed as one HIP graph
+                    # the whole step (voxelise + forward + backward + update) re-issued from its recorded plan: one C call
                     captured(samples[i]._keepalive, yc, yr)
                 else:
                     self.net.forward(samples[i], training=True)
@@ -335,10 +335,10 @@ class Model:
         return hist
 
     def _captured_step(self, samples):
-        """The HIP-graph form of the step (lisec_amd.network.CapturedStep), opt-in with LISEC_GRAPH=1, when it
-        applies: one GPU, every sample a voxelised sweep that still holds its device points, one grid.  Off by default:
-        on ROCm 7.2 the replay of the 260-node two-stream graph is 2x slower than the eager launches."""
-        if self.dp is not None or os.environ.get("LISEC_GRAPH", "0") != "1" or not samples:
+        """The recorded form of the step (lisec_amd.network.RecordedStep: the eager schedule re-issued by
+        lisec_step_plan_run, one C call per step), when it applies: one GPU, every sample a voxelised sweep that still
+        holds its device points, one grid.  Otherwise (None) the Python schedule issues every step."""
+        if self.dp is not None or not _lib.knob("step_plan", True) or not samples:
             return None
         pts = [getattr(s, "_keepalive", None) for s in samples]
         if any(p is None or not p.is_cuda for p in pts):
@@ -352,13 +352,15 @@ class Model:
         dtype = torch.float64 if any(p.dtype == torch.float64 for p in pts) else torch.float32
         need = max(int(p.shape[0]) for p in pts)
         o = self.optimizer
-        key = (key0, dtype, self.loss, o.lr, o.decay, o.momentum)
+        key = (key0, dtype, self.loss, o.lr, o.decay, o.momentum, id(self.net), torch.cuda.current_stream().cuda_stream)
         cur = getattr(self, "_captured", None)
         if cur is not None and cur[0] == key and cur[1].capacity >= need:
             return cur[1]
-        from .network import CapturedStep
-        capacity = max(1024, -(-need // 4096) * 4096)        # a little head-room: later fits reuse the capture
-        step = CapturedStep(self.net, Voxelizer(*key0[:3], key0[3], *key0[4:], device=self.net.device), capacity,
+        if cur is not None:
+            cur[1].close()                    # another grid / optimizer / network: the old plan points at dead buffers
+        from .network import RecordedStep
+        capacity = max(1024, -(-need // 4096) * 4096)        # a little head-room: later fits reuse the plan
+        step = RecordedStep(self.net, Voxelizer(*key0[:3], key0[3], *key0[4:], device=self.net.device), capacity,
                             dtype=dtype, loss=self.loss, lr=o.lr, decay=o.decay, momentum=o.momentum)
         self._captured = (key, step)
         return step

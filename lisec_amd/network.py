@@ -63,10 +63,10 @@ class LisecNet:
         # the dense VFE output: only the dense form of the first Conv3D reads it (allocated on first use, 164 MB)
         self.grid_shape = (D, H, W, 64)
         # field form of the first Conv3D (csrc/field_conv.hip): sweeps with a voxel capacity (= min(points, cells)) up to
-        # this never form the grid -- beyond ~40 % occupancy the dense contraction is the cheaper one;
-        # LISEC_FIELD_CONV=0 keeps the dense contraction for every sweep
-        self.field_conv = os.environ.get("LISEC_FIELD_CONV", "1") == "1"
-        self.field_max_voxels = int(os.environ.get("LISEC_FIELD_MAX_VOXELS", "262144"))
+        # this never form the grid -- beyond ~40 % occupancy the dense contraction is the cheaper one
+        # (LISEC_TUNING=field_conv=0 keeps the dense contraction for every sweep)
+        self.field_conv = _lib.knob("field_conv", True)
+        self.field_max_voxels = _lib.knob("field_max_voxels", 262144)
         self.field_ws = None
         self._used_field = False
         # ---- middle layers (model_training.py:236-238) ----------------------------------------
@@ -164,7 +164,7 @@ class LisecNet:
                                                      if L["kind"] == "deconv" and L["T"] is not None])
         self.parts = torch.empty(max_parts, dtype=torch.float64, device=dev)
         self._sinks, self._bsinks = {}, {}
-        self.early_pack = os.environ.get("LISEC_PACK_EARLY", "1") == "1"
+        self.early_pack = _lib.knob("pack_early", True)
         # The second HIP stream.  Backward: weight gradients are leaves of the graph and run beside the BN-backward /
         # data-gradient chain (the RPN layers are too small to fill 256 CUs on their own).  Forward and backward: the
         # Conv2DTranspose branches of RPN blocks 1 and 2 (model_training.py:246,249) only meet the rest of the network at the
@@ -172,10 +172,8 @@ class LisecNet:
         # ROCm multiplexes same-priority streams onto a few hardware queues round-robin, so a plain second stream
         # can land on the main stream's queue (it does once RCCL has made its own streams) and then nothing
         # overlaps; a different priority level always gets its own hardware queue.
-        self.side = torch.cuda.Stream(device=dev, priority=int(os.environ.get("LISEC_SIDE_PRIORITY", "-1")))
-        self.branch_overlap = os.environ.get("LISEC_BRANCH_OVERLAP", "1") == "1"
-        # fork / join events with a device-scope release (LISEC_DEVICE_EVENTS=0: torch.cuda.Event, system-scope release)
-        self.device_events = os.environ.get("LISEC_DEVICE_EVENTS", "1") == "1"
+        self.side = torch.cuda.Stream(device=dev, priority=_lib.knob("side_priority", -1))
+        self.branch_overlap = _lib.knob("branch_overlap", True)
         self._fwd_events = {}
         self._packed_version = -1
         self.params_version = 0
@@ -276,21 +274,17 @@ class LisecNet:
         return ev
 
     def _new_event(self):
-        return _lib.DeviceEvent() if getattr(self, "device_events", False) else torch.cuda.Event()
+        """Fork / join events: device-scope release, recorded and waited for through the library (lisec_event_record),
+        so that a step plan sees them."""
+        return _lib.DeviceEvent()
 
     @staticmethod
     def _record(ev, stream):
-        if isinstance(ev, _lib.DeviceEvent):
-            ev.record(stream.cuda_stream)
-        else:
-            ev.record(stream)
+        ev.record(stream.cuda_stream)
 
     @staticmethod
     def _wait(ev, stream):
-        if isinstance(ev, _lib.DeviceEvent):
-            ev.wait(stream.cuda_stream)
-        else:
-            stream.wait_event(ev)
+        ev.wait(stream.cuda_stream)
 
     def dense_grid(self, rewrite=True):
         """The dense (D,H,W,64) VFE output; rewrite: fill it from the last forward's per-voxel values (the field form
@@ -483,11 +477,6 @@ class LisecNet:
         self.bparts = torch.empty(nparts, dtype=torch.float64, device=dev)
         self.head_db = torch.empty(16, dtype=f32, device=dev)
         self.wgrad_ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-        # LISEC_MID_WGRAD=main: the weight gradients of the 3D middle layers run on the main stream, after their data
-        # gradient, instead of beside it on the second stream (measurement knob; they need a workspace of their own)
-        self.mid_wgrad_main = os.environ.get("LISEC_MID_WGRAD", "side") == "main"
-        self.fork_every = max(1, int(os.environ.get("LISEC_FORK_EVERY", "1")))
-        self.wgrad_ws_main = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if self.mid_wgrad_main else None
         self._packed_t_version = -1
         self._train_ready = True
 
@@ -552,7 +541,6 @@ class LisecNet:
         events = self._fork_events
         nfork = [0]
 
-        fork_every = self.fork_every
         pending = []
 
         def flush_side():
@@ -580,11 +568,9 @@ class LisecNet:
         def on_side(fn, torch_ops=False):
             """Runs fn's launches on the second stream after everything issued so far on the main one.  C-ABI launches
             take the pinned handle; only a fn that also issues torch / torch.distributed work needs torch's (slow)
-            stream context.  With fork_every > 1 the closures are handed over in groups: one event record (a marker
-            packet in the main queue, ~6 us of it) per group instead of one per weight gradient."""
+            stream context."""
             pending.append((fn, torch_ops))
-            if len(pending) >= fork_every or torch_ops:
-                flush_side()
+            flush_side()
 
         kind = {"mse": 0, "smoothl1_ce": 1}[loss]
         ops.rpn_loss(a["head"], y_cls, y_reg, M, kind, d["head"], self.loss_out, grad_scale=grad_scale)
@@ -729,12 +715,8 @@ class LisecNet:
                                    mask=a[self.fold_src])
             else:   # mid layer: conv3d -> BN -> Dense(relu)
                 n, dn = L["name"], L["dense"]
-                if self.mid_wgrad_main:
-                    ops.conv_wgrad(dn.g, a[n + ".y"], d[n + ".u"], p.grad_view(G, dn.wname), self.wgrad_ws_main,
-                                   in_bn=self.bnstate[dn.in_bn])
-                else:
-                    on_side(lambda n=n, dn=dn: ops.conv_wgrad(dn.g, a[n + ".y"], d[n + ".u"], p.grad_view(G, dn.wname),
-                                                              self.wgrad_ws, in_bn=self.bnstate[dn.in_bn]))
+                on_side(lambda n=n, dn=dn: ops.conv_wgrad(dn.g, a[n + ".y"], d[n + ".u"], p.grad_view(G, dn.wname),
+                                                          self.wgrad_ws, in_bn=self.bnstate[dn.in_bn]))
                 # Dense data gradient; its store also reduces the statistics of the BatchNormalization under it
                 msink = self._bwd_sink(c.bn, 64, c.M)
                 ops.conv_forward(self.dgeom[dn.name], d[n + ".u"], self.packed_t[dn.name][0], d[n + ".z"],
@@ -763,13 +745,13 @@ class LisecNet:
                     ops.conv_forward(dg, d[n + ".z"], self.packed_t[c.name][0], self.dout_rows, rows=rows,
                                      queue=self.rows_queue)
                 else:
-                    if self.mid_wgrad_main:
-                        dgrad_into(c, d[n + ".z"], L["src"])
-                        ops.conv_wgrad(c.g, a[L["src"]], d[n + ".z"], p.grad_view(G, c.wname), self.wgrad_ws_main)
-                    else:
-                        on_side(lambda L=L, c=c, n=n: ops.conv_wgrad(c.g, a[L["src"]], d[n + ".z"],
-                                                                     p.grad_view(G, c.wname), self.wgrad_ws))
-                        dgrad_into(c, d[n + ".z"], L["src"])
+                    # the data gradient FIRST, the weight gradient behind it on the second stream: both fill the chip
+                    # on their own and run slower side by side than one after the other (mid2: 800 us together,
+                    # 333 + 358 alone); behind the data gradient the weight gradient shares the chip with the
+                    # short kernels of the rest of the chain instead
+                    dgrad_into(c, d[n + ".z"], L["src"])
+                    on_side(lambda L=L, c=c, n=n: ops.conv_wgrad(c.g, a[L["src"]], d[n + ".z"],
+                                                                 p.grad_view(G, c.wname), self.wgrad_ws))
         # ---- VFE -----------------------------------------------------------------------------------
         flush_side()
         self.vfe.backward(None, G, dout_rows=self.dout_rows, g_all=self.g_all)
@@ -785,7 +767,7 @@ class LisecNet:
         ops.sgd_nesterov_step_dev(self.params.theta, self.grad, self.velocity, lr, decay, momentum, self._iter_dev)
         self._iterations += 1
         self.params_version += 1
-        if self._train_ready and self.early_pack and not torch.cuda.is_current_stream_capturing():
+        if self._train_ready and self.early_pack:
             # both repacks (forward and transposed layouts, ~75 us) for the NEXT step go to the second stream now: they
             # only depend on this update, and the next sweep's voxeliser + VFE (~105 us) do not read them
             if getattr(self, "_pack_done", None) is None:
@@ -817,10 +799,13 @@ class LisecNet:
         return self.loss_out
 
 
-class CapturedStep:
-    """One whole fit() step -- voxelise, forward, backward (both streams, fork/join events included), SGD-Nesterov --
-    captured ONCE as a HIP graph and replayed: the ~250 launches of a step cost the host one graph launch instead of
-    ~2 ms of ctypes calls.  The schedule is static; what varies from sample to sample lives in device memory:
+class RecordedStep:
+    """One whole fit() step -- voxelise, forward, backward (both streams, fork / join events included), SGD-Nesterov, the
+    weight repack for the next step -- recorded ONCE as a step plan of the C ABI (lisec_step_plan_*, csrc/plan.hip) and
+    re-issued by one C call per step: the ~250 launches cost the host one ctypes call instead of ~1.5 ms of Python
+    (schedule, plan selection, argument marshalling).  It IS the eager schedule -- same kernels, same streams, same
+    events, bit-identical variables -- not a HIP graph (a captured graph of this two-stream step replays 2x slower than
+    the eager launches on ROCm 7.2).  The schedule is static; what varies from sample to sample lives in device memory:
 
       points   a fixed-capacity (capacity, 3) buffer; a sweep with fewer points is padded with points far outside
                the grid, which the voxeliser's range test (model_training.py:118-120) drops -- kept points, their
@@ -828,57 +813,72 @@ class CapturedStep:
       targets  (Ho,Wo,2) / (Ho,Wo,14) static buffers
       lr_t     derived by the SGD kernel from the device iteration counter (lisec_sgd_nesterov_step_dev)
 
-    Single-GPU only: the data-parallel step keeps the eager schedule (its RCCL exchange is not captured)."""
+    Record and replay on ONE torch stream (the current stream at construction).  Single-GPU: the data-parallel step keeps
+    the Python schedule (its gradient exchange is issued from torch hooks)."""
 
     PAD = 1.0e6          # metres: floor(1e6 / 0.5) is far beyond maxVoxelX, the point is dropped like any other outlier
 
     def __init__(self, net, voxelizer, capacity, dtype=torch.float32, loss="mse", lr=0.01, decay=1e-6, momentum=0.9,
                  warmup=2):
+        import ctypes
         self.net, self.vox, self.capacity, self.loss = net, voxelizer, int(capacity), loss
         dev = net.device
+        self.lib = _lib.load()
         self.points = torch.full((self.capacity, 3), self.PAD, dtype=dtype, device=dev)
         self.ycls = torch.zeros((net.Ho, net.Wo, 2), dtype=torch.float32, device=dev)
         self.yreg = torch.zeros((net.Ho, net.Wo, 14), dtype=torch.float32, device=dev)
         self.hyper = (lr, decay, momentum)
-        net.early_pack = False           # the repacks belong inside the captured step, on its own streams
+        self.sample = None
+        self.stream_handle = torch.cuda.current_stream().cuda_stream
         torch.cuda.synchronize(dev)
-        net._pack_pending = False
         net._prepare_training()
-        # torch's capture only knows the events torch made: the forks go back to torch.cuda.Event
-        net.device_events, net._fork_events, net._join_event, net._fwd_events = False, [], None, {}
         p = net.params
-        keep = (p.theta.clone(), p.state.clone(), net.velocity.clone(), net._iter_dev.clone(), net._iterations,
-                net.params_version, net.state_version)
-        # eager warm-up on a side stream (lazy workspaces, descriptor tables, events), then the capture itself
-        s = torch.cuda.Stream(device=dev)
-        s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):
-            for _ in range(max(1, warmup)):
-                self._enqueue()
-        torch.cuda.current_stream().wait_stream(s)
-        torch.cuda.synchronize(dev)
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        keep = (p.theta.clone(), p.state.clone(), net.velocity.clone(), net._iter_dev.clone(), net._iterations)
+        # eager warm-up (lazy workspaces, descriptor tables, events; it leaves the next step's repack pending, which is
+        # the state every recorded step starts from), then one more step that is recorded while it runs
+        for _ in range(max(1, warmup)):
             self._enqueue()
-        # the warm-up steps trained on the padding: put every variable back
+        torch.cuda.synchronize(dev)
+        self.plan = ctypes.c_void_p()
+        _lib.check(self.lib.lisec_step_plan_create(ctypes.byref(self.plan)))
+        _lib.check(self.lib.lisec_step_plan_begin(self.plan))
+        try:
+            self._enqueue()
+        finally:
+            _lib.check(self.lib.lisec_step_plan_end(self.plan))
+        torch.cuda.synchronize(dev)
+        self.launches = self.lib.lisec_step_plan_size(self.plan)
+        # those steps trained on the padding: put every variable back and repack the kernels from them
         p.theta.copy_(keep[0]); p.state.copy_(keep[1]); net.velocity.copy_(keep[2]); net._iter_dev.copy_(keep[3])
-        net._iterations, net.params_version, net.state_version = keep[4], keep[5] + 1000, keep[6] + 1000
+        net._iterations = keep[4]
+        net.params_version += 1
+        net.state_version += 1
         p.touch()
+        net._pack_pending = False
+        net._pack_all()
+        net._pack_all_t()
+        net._record(net._pack_done, torch.cuda.current_stream())   # what the recorded forward waits for
+        net._pack_pending = True
         torch.cuda.synchronize(dev)
 
     def _enqueue(self):
         net = self.net
-        self.sample = self.vox(self.points)
+        self.sample = self.vox(self.points, out=self.sample)
         net.forward(self.sample, training=True)
         net.backward(self.ycls, self.yreg, loss=self.loss)
         net.apply_gradients(*self.hyper)
 
+    def _check_stream(self):
+        if torch.cuda.current_stream().cuda_stream != self.stream_handle:
+            raise RuntimeError("a RecordedStep replays on the stream it was recorded on: make that stream current")
+
     def load(self, points, ycls, yreg):
         """Stage one sweep: points (n <= capacity, >= 3 columns; device or host tensor / numpy), targets (Ho,Wo,2|14)."""
+        self._check_stream()
         pts = torch.as_tensor(points)
         n = int(pts.shape[0])
         if n > self.capacity:
-            raise ValueError(f"sweep of {n} points exceeds the captured capacity {self.capacity}")
+            raise ValueError(f"sweep of {n} points exceeds the recorded capacity {self.capacity}")
         self.points[:n].copy_(pts[:, :3], non_blocking=True)
         if n < self.capacity:
             self.points[n:].fill_(self.PAD)
@@ -886,14 +886,30 @@ class CapturedStep:
         self.yreg.copy_(torch.as_tensor(yreg).reshape(self.yreg.shape), non_blocking=True)
 
     def replay(self):
-        """Runs the captured step on what load() staged; returns net.loss_out (device, [total, class, regression])."""
+        """Runs the recorded step on what load() staged; returns net.loss_out (device, [total, class, regression])."""
+        self._check_stream()
         net = self.net
-        self.graph.replay()
+        _lib.check(self.lib.lisec_step_plan_run(self.plan))
         net._iterations += 1
-        net.params_version += 1          # theta moved: an eager forward after this repacks / refolds
+        net.params_version += 1          # theta moved; the recorded step also repacked it for the next one
         net.state_version += 1
+        net._packed_version = net._packed_t_version = (net.params_version, net.params.version)
+        net._pack_pending = True
+        self.sample._host_info = None
         return net.loss_out
 
     def __call__(self, points, ycls, yreg):
         self.load(points, ycls, yreg)
         return self.replay()
+
+    def close(self):
+        if getattr(self, "plan", None):
+            torch.cuda.synchronize(self.net.device)
+            self.lib.lisec_step_plan_destroy(self.plan)
+            self.plan = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

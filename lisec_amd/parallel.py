@@ -83,22 +83,38 @@ class DataParallel:
                 raise RuntimeError(f"data-parallel ranks share a GPU: {everyone}; each rank must own cuda:LOCAL_RANK")
         self.comm = None                 # lisec_comm_t (RCCL communicator) of the data plane
         self.comm_stream = None
+        self._comm_ranks = 0
         if self.on_gpu and dist.get_backend() == "nccl" and os.environ.get("LISEC_ALLREDUCE", "rccl") != "torch":
-            try:
+            # lisec_comm_init is a COLLECTIVE (ncclCommInitRank): a rank that cannot load RCCL must be found BEFORE the
+            # others enter it, or they would wait in it for ever.  So every rank probes first (no collective, no device
+            # work), the answers are gathered over the control plane, and the communicator is only made when all of
+            # them can: otherwise EVERY rank takes torch.distributed for the exchange.  A failure after that point is
+            # an error (no silent fallback: the ranks could no longer agree on it).
+            if self.agree_on_data_plane(self._probe_rccl()):
                 self._init_comm()
-            except Exception as e:                     # noqa: BLE001 -- keep training: torch.distributed carries the exchange
-                import sys
-                print(f"[lisec_amd] rank {self.rank}: the C ABI's RCCL communicator could not be made ({e}); "
-                      "gradients go through torch.distributed.all_reduce", file=sys.stderr, flush=True)
-                self.comm = None
-            # every rank must agree on the data plane (a rank without a communicator cannot join the others' all-reduce)
-            if self.world > 1:
-                flags = [None] * self.world
-                dist.all_gather_object(flags, self.comm is not None)
-                if not all(flags) and self.comm is not None:
-                    from . import _lib
-                    _lib.load().lisec_comm_destroy(self.comm)
-                    self.comm = None
+
+    @staticmethod
+    def _probe_rccl():
+        try:
+            from . import _lib
+            return _lib.load().lisec_comm_probe() == 0
+        except Exception:                          # noqa: BLE001 -- a missing library is an answer, not a crash
+            return False
+
+    def agree_on_data_plane(self, mine_ok):
+        """True when EVERY rank reported that it can make the RCCL communicator (one all_gather over the control plane);
+        prints once per rank why the exchange goes through torch.distributed otherwise."""
+        flags = [bool(mine_ok)]
+        if self.world > 1:
+            flags = [None] * self.world
+            dist.all_gather_object(flags, bool(mine_ok))
+        if all(flags):
+            return True
+        import sys
+        bad = [r for r, ok in enumerate(flags) if not ok]
+        print(f"[lisec_amd] rank {self.rank}: RCCL cannot be loaded on rank(s) {bad}; every rank exchanges gradients through "
+              "torch.distributed.all_reduce", file=sys.stderr, flush=True)
+        return False
 
     def _init_comm(self):
         from . import _lib
@@ -119,6 +135,11 @@ class DataParallel:
         with torch.cuda.device(self.device):
             _lib.check(lib.lisec_comm_init(self.rank, self.world, box[0], ctypes.byref(comm)))
         self.comm = comm
+        count = ctypes.c_int(0)
+        _lib.check(lib.lisec_comm_count(comm, ctypes.byref(count)))
+        if count.value != self.world:
+            raise _lib.LisecError(f"the RCCL communicator has {count.value} ranks, torch.distributed {self.world}")
+        self._comm_ranks = count.value
         self.comm_stream = torch.cuda.Stream(device=self.device)
         self._comm_event = torch.cuda.Event()
 
@@ -130,7 +151,11 @@ class DataParallel:
         return dist.get_backend()
 
     def rccl_ranks(self):
-        """Ranks taking part in RCCL collectives (0 when the backend is gloo)."""
+        """Ranks of the communicator that MOVES the gradients: ncclCommCount of the C ABI's own communicator
+        (lisec_comm_count) when the exchange runs on it; with the exchange on torch.distributed, its world size under
+        the nccl backend and 0 under gloo."""
+        if self.comm is not None:
+            return self._comm_ranks
         return self.world if dist.get_backend() == "nccl" else 0
 
     def gather_floats(self, x):
@@ -156,8 +181,8 @@ class DataParallel:
             return tensor
         if self.comm is not None and tensor.is_cuda and tensor.dtype == torch.float32 and tensor.numel() % 4 == 0:
             from . import _lib
-            _lib.check(_lib.load().lisec_allreduce_grads(self.comm, _lib.ptr(tensor), tensor.numel(), self.world,
-                                                         _lib.current_stream()))
+            _lib.check(_lib.load().lisec_allreduce_grads(self.comm, _lib.ptr(tensor), tensor.numel(), 0,
+                                                         _lib.current_stream()))    # 0: mean over the communicator
             return tensor
         dist.all_reduce(tensor, op=dist.ReduceOp.SUM)
         if self.on_gpu:
@@ -212,8 +237,8 @@ class _BucketedAverage:
         ev = dp._comm_event
         ev.record(torch.cuda.ExternalStream(after, device=dp.device))
         dp.comm_stream.wait_event(ev)
-        _lib.check(_lib.load().lisec_allreduce_grads(dp.comm, grad.data_ptr() + 4 * lo, hi - lo, dp.world,
-                                                     dp.comm_stream.cuda_stream))
+        _lib.check(_lib.load().lisec_allreduce_grads(dp.comm, grad.data_ptr() + 4 * lo, hi - lo, 0,
+                                                     dp.comm_stream.cuda_stream))           # 0: mean over the communicator
 
     def start_tail(self, grad, lo, hi):
         if not self.active:

@@ -23,8 +23,8 @@ class VFEStack:
         self._saved = None
         self._sample = None
         # LISEC_VFE_BWD=valu: the row-by-row backward of layers 3 and 2 instead of the 32-row MFMA tiles
-        self.tiled = os.environ.get("LISEC_VFE_BWD", "tiled") != "valu"
-        self.tiled_min_points = int(os.environ.get("LISEC_VFE_TILED_MIN_POINTS", "65536"))
+        self.tiled = _lib.knob("vfe_bwd_tiled", True)
+        self.tiled_min_points = _lib.knob("vfe_tiled_min_points", 65536)
         self._saved_rows = 0
 
     def _cparams(self, theta=None):

@@ -107,8 +107,10 @@ class Voxelizer:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self._ws
 
-    def __call__(self, points):
-        """points: (N, >=3) float32/float64 numpy array or torch tensor (host or device)."""
+    def __call__(self, points, out=None):
+        """points: (N, >=3) float32/float64 numpy array or torch tensor (host or device).
+        out: a VoxelSample of an earlier call with the same number of points whose buffers are written again (a recorded
+        step plan points at fixed addresses)."""
         if isinstance(points, np.ndarray):
             if points.dtype not in (np.float32, np.float64):
                 points = points.astype(np.float64)
@@ -122,6 +124,16 @@ class Voxelizer:
         cap = min(n, self.ncells)
         dev, i32 = self.device, torch.int32
         ws = self._workspace(n)
+        if out is not None:
+            if out.n_points != n or out.cap != cap:
+                raise ValueError("out: a sample of another size")
+            _lib.check(self.lib.lisec_voxelize(
+                ctypes.byref(self.cfg), _lib.ptr(pts), 0 if pts.dtype == torch.float32 else 1, n, stride,
+                _lib.ptr(ws), ws.numel(), cap, _lib.ptr(out.info), _lib.ptr(out.cell_voxel), _lib.ptr(out.coords),
+                _lib.ptr(out.counts), _lib.ptr(out.npts), _lib.ptr(out.row_start), _lib.ptr(out.rows),
+                _lib.ptr(out.row_point), _lib.ptr(out.row_stats), _lib.current_stream()))
+            out._keepalive, out._host_info = pts, None
+            return out
         info = torch.empty(8, dtype=i32, device=dev)
         cell_voxel = torch.empty(self.ncells, dtype=i32, device=dev)
         coords = torch.empty((max(cap, 1), 3), dtype=i32, device=dev)

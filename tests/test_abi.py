@@ -25,6 +25,50 @@ def test_library_exports_every_declared_symbol():
     assert lib.lisec_abi_version() >= 1
 
 
+def test_every_exported_lisec_symbol_is_declared():
+    """exported <= declared: nothing the library exports under the lisec_ prefix is missing from the header (round 2's
+    undeclared lisec_debug_* entry points)."""
+    import subprocess
+    from lisec_amd import _lib
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted({line.split()[-1] for line in out.splitlines() if line.split() and line.split()[-1].startswith("lisec_")})
+    declared = set(_declared_functions())
+    assert exported and not [n for n in exported if n not in declared]
+
+
+def test_library_reads_no_environment_variables():
+    """Launch plans are tuned through the lisec_tuning record of the ABI, never through getenv inside the library."""
+    csrc = os.path.join(ROOT, "lisec_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".h")):
+            assert "getenv" not in open(os.path.join(csrc, f)).read(), f
+
+
+def test_tuning_record_round_trip():
+    from lisec_amd import _lib
+    before = _lib.get_tuning()
+    assert before["max_splitk"] == 12 and before["wgrad_blocks"] >= 1
+    prev = _lib.set_tuning(max_splitk=8)
+    try:
+        assert _lib.get_tuning()["max_splitk"] == 8 and prev == {"max_splitk": 12}
+    finally:
+        _lib.set_tuning(**prev)
+    import pytest
+    with pytest.raises(KeyError):
+        _lib.set_tuning(no_such_knob=1)
+
+
+def test_plan_query_needs_no_gpu():
+    """lisec_conv_plan_query answers on the host: the RPN block-2 layers are K-sliced, the mid2 data gradient pairs planes."""
+    from lisec_amd import ops
+    g = ops.geom(0, (1, 50, 100), (1, 50, 100), (1, 3, 3), (1, 1, 1), (0, 1, 1), 128, 128)
+    plan = ops.conv_plan(g, in_bn=True, flags=ops.IN_RELU)
+    assert plan["kernel"] == "halo3" and plan["k_slices"] >= 2 and plan["tail_tile0"] == 0 and plan["launches"] == 1
+    g = ops.geom(1, (2, 200, 400), (4, 200, 400), (3, 3, 3), (1, 1, 1), (0, 1, 1), 64, 64)
+    plan = ops.conv_plan(g)
+    assert plan["kernel"] == "halo2" and plan["plane_pair"] == 1 and plan["k_slices"] == 1 and plan["workgroups"] == 1250
+
+
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     from lisec_amd import _lib
     monkeypatch.setattr(_lib, "_lib", None)

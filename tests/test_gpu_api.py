@@ -179,12 +179,13 @@ def test_gpu_lidar_ingest_matches_oracle(tmp_path):
         assert len(a["coords"]) == len(b["coords"]) and np.array_equal(a["coords"], b["coords"])
 
 
-def test_captured_step_equals_eager_steps():
-    """lisec_amd.network.CapturedStep (the whole fit() step as one HIP graph: voxelise + forward + backward on both
-    streams + SGD with the device-side iteration counter) gives BIT-IDENTICAL variables to the eager schedule, with
-    sweeps of different sizes padded into the fixed-capacity point buffer."""
+def test_recorded_step_equals_eager_steps():
+    """lisec_amd.network.RecordedStep (the whole fit() step -- voxelise + forward + backward on both streams + SGD with
+    the device-side iteration counter + the repack for the next step -- recorded once as a step plan of the C ABI and
+    re-issued by lisec_step_plan_run) gives BIT-IDENTICAL variables to the Python schedule, with sweeps of different
+    sizes padded into the fixed-capacity point buffer."""
     import torch
-    from lisec_amd.network import CapturedStep, LisecNet
+    from lisec_amd.network import RecordedStep, LisecNet
     from lisec_amd.params import ParamStore
     from lisec_amd.voxelizer import Voxelizer
     cfg = dict(xSize=0.5, ySize=0.25, zSize=0.25, sampleSize=35, maxVoxelX=8, maxVoxelY=16, maxVoxelZ=8)
@@ -197,7 +198,7 @@ def test_captured_step_equals_eager_steps():
     init = ParamStore(dev).to_dict()
 
     def padded(pts, capacity=3000):
-        out = np.full((capacity, 3), CapturedStep.PAD, np.float32)
+        out = np.full((capacity, 3), RecordedStep.PAD, np.float32)
         out[:len(pts)] = pts
         return out
 
@@ -207,9 +208,10 @@ def test_captured_step_equals_eager_steps():
         net._prepare_training()
         net.iterations = 5                                   # a non-zero start: the decay term is live
         losses = []
-        step = CapturedStep(net, vox, 3000) if captured else None
+        step = RecordedStep(net, vox, 3000) if captured else None
         if captured:
-            assert net.iterations == 5                       # the warm-up steps of the capture left no trace
+            assert net.iterations == 5                       # the warm-up steps of the recording left no trace
+            assert step.launches > 100                       # the plan holds the step's launches and event edges
         for pts, (yc, yr) in zip(clouds, ys):
             d_pts, d_yc, d_yr = (torch.from_numpy(a).to(dev) for a in (pts, yc, yr))
             if captured:

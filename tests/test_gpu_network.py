@@ -1,6 +1,8 @@
 """End-to-end forward (voxeliser -> VFE -> 3D-conv middle -> RPN heads) through the C ABI vs the
 dense oracle (oracle/model_ref.py) on identical voxel grids.
 Tolerance: BASELINE north_star -- RPN outputs rtol 1e-3, paired with atol 1e-3*max|ref|."""
+import re
+
 import numpy as np
 import pytest
 import torch
@@ -25,6 +27,24 @@ def close(got, ref, rtol=1e-3, what=""):
     err = np.abs(got - ref)
     assert (err <= atol + rtol * np.abs(ref)).all(), f"{what}: max err {err.max():.3e}, atol {atol:.3e}"
     return err.max() / max(np.abs(ref).max(), 1e-30)
+
+
+def loose_names(taps, names, eps=5e-6):
+    """Parameters whose gradient a ReLU 'kink' can disturb.  A pre-activation of RPN layer (b, j) within fp32 noise of 0
+    (|z| < eps in the fp64 oracle) flips one gradient gate between the oracle and the fp32 GPU run; that reaches the
+    gradients of that layer and of every layer in FRONT of it, never the ones behind it.  So only the parameters up to and
+    including the last kinked layer (in forward order) are compared at the loose bound; everything behind keeps the tight
+    one (a kink anywhere used to loosen every tensor to 10 %)."""
+    last = None
+    for k, v in taps.items():
+        m = re.fullmatch(r"rpn(\d)\.z(\d)", k)
+        if m and float(v.abs().min()) < eps:
+            key = (int(m.group(1)), int(m.group(2)))
+            last = key if last is None or key > last else last
+    if last is None:
+        return set()
+    cut = max(i for i, n in enumerate(names) if n.startswith(f"rpn{last[0]}.bn{last[1]}."))
+    return set(names[:cut + 1])
 
 
 def oracle_forward(op, pts, cfg, training, dtype=torch.float64):
@@ -114,7 +134,8 @@ def test_train_steps_small_grid_vs_oracle_autograd(loss):
         yc, yr = torch.from_numpy(y_cls)[None].double(), torch.from_numpy(y_reg)[None].double()
         taps = {}
         M.forward(p64, dense, training=True, stats={}, taps=taps)
-        kink = min(float(v.abs().min()) for k, v in taps.items() if ".z" in k) < 5e-6
+        order = [n for n, _, k in M.param_specs() if M.is_trainable(k)]
+        loose = loose_names(taps, order)
         if loss == "mse":
             loss_r, grads_r, p64_new, vel_new, _ = M.train_step(p64, vel, dense, yc, yr, it)
         else:
@@ -129,7 +150,6 @@ def test_train_steps_small_grid_vs_oracle_autograd(loss):
         lo = net.train_step(sample, torch.from_numpy(y_cls).to(dev), torch.from_numpy(y_reg).to(dev), loss=loss)
         torch.cuda.synchronize()
         assert abs(lo[0].item() - loss_r.item()) <= 1e-5 * abs(loss_r.item())
-        gtol = 1e-1 if kink else 3e-3
         for name, g in grads_r.items():
             got = net.params.grad_view(net.grad, name).cpu().numpy()
             ref = g.numpy()
@@ -137,6 +157,7 @@ def test_train_steps_small_grid_vs_oracle_autograd(loss):
                 # bias feeding a training-mode BN: the exact gradient is 0; ours is rounding noise
                 assert np.abs(got).max() < 1e-5, name
                 continue
+            gtol = 1e-1 if name in loose else 3e-3
             tol = gtol * np.abs(ref).max() + 1e-7
             err = np.abs(got - ref).max()
             assert err <= tol, f"step {it} grad {name}: err {err:.3e} tol {tol:.3e} (max ref {np.abs(ref).max():.3e})"
@@ -144,13 +165,13 @@ def test_train_steps_small_grid_vs_oracle_autograd(loss):
             return
         got_p = net.params.to_dict()
         for name, v in p64_new.items():
-            close(got_p[name], v.numpy(), rtol=(1e-2 if kink else 1e-4), what=f"step {it} param {name}")
+            close(got_p[name], v.numpy(), rtol=(1e-2 if name in loose else 1e-4), what=f"step {it} param {name}")
         for n_, v_ in vel_new.items():
             gv = net.params.grad_view(net.velocity, n_).cpu().numpy()
             if np.abs(v_.numpy()).max() < 1e-12:          # velocity of an exactly-zero gradient (see above)
                 assert np.abs(gv).max() < 1e-6, n_
                 continue
-            close(gv, v_.numpy(), rtol=(1e-1 if kink else 3e-3), what=f"step {it} velocity {n_}")
+            close(gv, v_.numpy(), rtol=(1e-1 if n_ in loose else 3e-3), what=f"step {it} velocity {n_}")
         p64, vel = p64_new, vel_new
 
 
@@ -184,7 +205,7 @@ def test_train_step_fully_occupied_grid_vs_oracle():
     x = torch.from_numpy(dense)[None].double()
     taps = {}
     cls_r, reg_r = M.forward(p64, x, training=True, stats={}, taps=taps)
-    kink = min(float(v.abs().min()) for k, v in taps.items() if ".z" in k) < 5e-6
+    loose = loose_names(taps, [n for n, _, k in M.param_specs() if M.is_trainable(k)])
     loss_r, grads_r, _, _, _ = M.train_step(p64, vel, x, torch.from_numpy(y_cls)[None].double(),
                                             torch.from_numpy(y_reg)[None].double(), 0)
     lo = net.train_step(sample, torch.from_numpy(y_cls).to(dev), torch.from_numpy(y_reg).to(dev))
@@ -194,14 +215,13 @@ def test_train_step_fully_occupied_grid_vs_oracle():
     vout = net.vfe.saved_field("vout").cpu().numpy()
     assert (vout[D * H * W] == 0).all() and (net.vfe.saved_field("delta").cpu().numpy()[D * H * W] == 0).all()
     assert abs(lo[0].item() - loss_r.item()) <= 1e-5 * abs(loss_r.item())
-    gtol = 1e-1 if kink else 3e-3
     for name, g in grads_r.items():
         got = net.params.grad_view(net.grad, name).cpu().numpy()
         ref = g.numpy()
         if ".conv" in name and name.endswith(".bias") and np.abs(ref).max() < 1e-12:
             assert np.abs(got).max() < 1e-5, name
             continue
-        err, tol = np.abs(got - ref).max(), gtol * np.abs(ref).max() + 1e-7
+        err, tol = np.abs(got - ref).max(), (1e-1 if name in loose else 3e-3) * np.abs(ref).max() + 1e-7
         assert err <= tol, f"grad {name}: err {err:.3e} tol {tol:.3e}"
 
 
@@ -236,7 +256,7 @@ def test_depth_fold_nz12_forward_and_training_step(tmp_path):
         cls_r, reg_r = M.forward(p64, dense, training=training, stats={}, taps=taps)
         close(cls.cpu().numpy(), cls_r.numpy(), what=f"class map (nz=12, training={training})")
         close(reg.cpu().numpy(), reg_r.numpy(), what=f"regression map (nz=12, training={training})")
-    kink = min(float(v.abs().min()) for k, v in taps.items() if ".z" in k) < 5e-6
+    loose = loose_names(taps, [n for n, _, k in M.param_specs(2) if M.is_trainable(k)])
     y_cls = rng.integers(0, 3, (8, 16, 2)).astype(np.float32)
     y_reg = rng.normal(0, 1, (8, 16, 14)).astype(np.float32)
     vel = {n_: torch.zeros_like(p64[n_]) for n_, _, k in M.param_specs(2) if M.is_trainable(k)}
@@ -245,14 +265,13 @@ def test_depth_fold_nz12_forward_and_training_step(tmp_path):
     lo = net.train_step(sample, torch.from_numpy(y_cls).to(dev), torch.from_numpy(y_reg).to(dev))
     torch.cuda.synchronize()
     assert abs(lo[0].item() - loss_r.item()) <= 1e-5 * abs(loss_r.item())
-    gtol = 1e-1 if kink else 3e-3
     for name, g in grads_r.items():
         got = net.params.grad_view(net.grad, name).cpu().numpy()
         ref = g.numpy()
         if ".conv" in name and name.endswith(".bias") and np.abs(ref).max() < 1e-12:
             assert np.abs(got).max() < 1e-5, name
             continue
-        err, tol = np.abs(got - ref).max(), gtol * np.abs(ref).max() + 1e-7
+        err, tol = np.abs(got - ref).max(), (1e-1 if name in loose else 3e-3) * np.abs(ref).max() + 1e-7
         assert err <= tol, f"grad {name}: err {err:.3e} tol {tol:.3e}"
     # the drop-in surface with this nz: createModel -> predict -> save (Keras-layout .h5 and .npz) -> load_model
     from lisec_amd import model_training as mt

@@ -127,9 +127,19 @@ def test_rccl_allreduce_entry_one_rank():
     x = torch.from_numpy(host).to(dev)
     st = torch.cuda.Stream(device=dev)
     st.wait_stream(torch.cuda.current_stream())
-    _lib.check(lib.lisec_allreduce_grads(comm, x.data_ptr(), x.numel(), 4, st.cuda_stream))          # divisor 4
+    count = ctypes.c_int(0)
+    _lib.check(lib.lisec_comm_count(comm, ctypes.byref(count)))
+    assert count.value == 1
+    _lib.check(lib.lisec_comm_probe())
+    _lib.check(lib.lisec_allreduce_grads(comm, x.data_ptr(), x.numel(), -4, st.cuda_stream))         # explicit divisor 4
     lo = 1_000_000                                                                                    # a sub-range
-    _lib.check(lib.lisec_allreduce_grads(comm, x.data_ptr() + 4 * lo, x.numel() - lo, 1, st.cuda_stream))
+    _lib.check(lib.lisec_allreduce_grads(comm, x.data_ptr() + 4 * lo, x.numel() - lo, 1, st.cuda_stream))   # world == count
+    _lib.check(lib.lisec_allreduce_grads(comm, x.data_ptr() + 4 * lo, x.numel() - lo, 0, st.cuda_stream))   # 0: the count
+    st.synchronize()
+    assert np.array_equal(x.cpu().numpy(), host * np.float32(0.25))
+    # a caller-supplied world that is not the communicator's size would mis-scale every gradient: refused, nothing enqueued
+    assert lib.lisec_allreduce_grads(comm, x.data_ptr(), x.numel(), 4, st.cuda_stream) != 0
+    assert b"communicator has 1 ranks" in lib.lisec_last_error()
     st.synchronize()
     assert np.array_equal(x.cpu().numpy(), host * np.float32(0.25))
     assert lib.lisec_allreduce_grads(comm, x.data_ptr(), 6, 1, st.cuda_stream) != 0                   # n % 4 != 0: refused

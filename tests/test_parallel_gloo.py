@@ -55,6 +55,33 @@ def test_two_rank_gradient_averaging(tmp_path):
     assert np.allclose(t0, theta, rtol=1e-6)
 
 
+def _probe_worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from lisec_amd.parallel import DataParallel
+    dp = DataParallel("cpu")
+    # rank 1 cannot load RCCL (faked): NO rank may go on to the collective lisec_comm_init, all take torch.distributed
+    agreed = dp.agree_on_data_plane(rank != 1)
+    both_ok = dp.agree_on_data_plane(True)
+    grad = torch.full((8,), float(rank + 1))
+    dp.average_(grad)                                      # the exchange still works: through torch.distributed
+    np.save(os.path.join(out_dir, f"probe{rank}.npy"),
+            np.array([float(agreed), float(both_ok), float(dp.comm is None), float(grad[0]), float(dp.rccl_ranks())]))
+    dp.close()
+
+
+def test_rccl_probe_failing_on_one_rank_sends_every_rank_to_torch(tmp_path):
+    """ncclCommInitRank is a collective, so a rank without RCCL must be found BEFORE the others enter
+    it.  Every rank probes first and the answers are gathered; with rank 1's probe failing every rank must decide
+    `torch.distributed` -- nobody is left waiting in lisec_comm_init."""
+    port = _free_port()
+    mp.spawn(_probe_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        agreed, both_ok, no_comm, g, ranks = np.load(tmp_path / f"probe{r}.npy")
+        assert agreed == 0.0                               # one bad rank -> False on EVERY rank
+        assert both_ok == 1.0                              # and True when all report OK
+        assert no_comm == 1.0 and g == 1.5 and ranks == 0.0
+
+
 def test_device_index_per_local_rank():
     """every rank must resolve to its own GPU (cuda:LOCAL_RANK); sharing one card is only legal with gloo."""
     import pytest

@@ -34,24 +34,24 @@ print("forward   host/total ms", timed(lambda: net.forward(s, training=True)))
 print("backward  host/total ms", timed(lambda: net.backward(yc, yr)))
 print("update    host/total ms", timed(lambda: net.apply_gradients()))
 
-# the captured form of the same step (what Model.fit and bench.py use on one GPU)
-from lisec_amd.network import CapturedStep
-cap = CapturedStep(net, vox, pts.shape[0])
-cap.load(pts, yc, yr)
+# the recorded form of the same step (what Model.fit and bench.py use on one GPU): one C call per step
+from lisec_amd.network import RecordedStep
+rec = RecordedStep(net, vox, pts.shape[0])
+rec.load(pts, yc, yr)
 for _ in range(3):
-    cap.replay()
+    rec.replay()
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 for _ in range(K):
-    cap.replay()
+    rec.replay()
 t1 = time.perf_counter()
 torch.cuda.synchronize()
 t2 = time.perf_counter()
-print(f"hipGraph replay: host enqueue per step {1e3*(t1-t0)/K:.3f} ms; total per step {1e3*(t2-t0)/K:.2f} ms")
+print(f"step plan replay ({rec.launches} recorded operations): host enqueue per step {1e3*(t1-t0)/K:.3f} ms; total per step {1e3*(t2-t0)/K:.2f} ms")
 t0 = time.perf_counter()
 for _ in range(K):
-    cap(pts, yc, yr)
+    rec(pts, yc, yr)
 t1 = time.perf_counter()
 torch.cuda.synchronize()
 t2 = time.perf_counter()
-print(f"hipGraph load+replay: host per step {1e3*(t1-t0)/K:.3f} ms; total per step {1e3*(t2-t0)/K:.2f} ms")
+print(f"load + replay: host per step {1e3*(t1-t0)/K:.3f} ms; total per step {1e3*(t2-t0)/K:.2f} ms")
