@@ -343,6 +343,20 @@ int lisec_conv_forward(const lisec_conv_geom* g, const float* in, const float* p
  * is position row_coords[3m..], `in` is gathered there, dy row m is read at dy + m*out_stride.
  * Deterministic: partial slabs reduced in index order. */
 size_t lisec_conv_wgrad_workspace_bytes(const lisec_conv_geom* g, int row_capacity);
+/* The launch plan lisec_conv_wgrad WILL run (nothing is launched): tests pin the plans of the Lyft layer geometries. */
+typedef struct lisec_wgrad_plan {
+    int halo;            /* w-halo kernel (3 taps along w at stride 1 over every position): tiles follow the output lines */
+    int mirrored;        /* a unit-stride transposed gather run as the plain one with mirrored taps                       */
+    int taps_per_group;  /* taps that share one staged dy tile                                                           */
+    int groups;          /* tap groups that get workgroups (groups no output line can read are left out)                  */
+    int tile_rows;       /* rows per staged tile (halo: equal tiles per output line)                                      */
+    int staging_passes;  /* halo: 7 (tiles of <= 110 rows, three workgroups per CU) or 9                                  */
+    int tiles, slabs, tiles_per_slab;   /* M tiles, partial slabs (= ranges of tiles), tiles per range                   */
+    int workgroups;
+    int lane_reduce;     /* many slabs over a small kernel: the lane-strided slab sum                                     */
+} lisec_wgrad_plan;
+int lisec_conv_wgrad_plan_query(const lisec_conv_geom* g, int flags, int has_dy_bnstate, int has_row_list, int row_capacity,
+                                lisec_wgrad_plan* plan);
 int lisec_conv_wgrad(const lisec_conv_geom* g, const float* in, const float* in_bnstate, int flags,
                      const float* dy, const float* dy_bnstate, void* workspace, size_t workspace_bytes,
                      int transpose_out, float* dW, const int32_t* row_coords, const int32_t* row_count,

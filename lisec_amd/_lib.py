@@ -47,6 +47,11 @@ class ConvPlan(Structure):                     # lisec_conv_plan
                                      "workgroups", "launches")]
 
 
+class WgradPlan(Structure):                    # lisec_wgrad_plan
+    _fields_ = [(n, c_int) for n in ("halo", "mirrored", "taps_per_group", "groups", "tile_rows", "staging_passes", "tiles",
+                                     "slabs", "tiles_per_slab", "workgroups", "lane_reduce")]
+
+
 class Tuning(Structure):                       # lisec_tuning
     _fields_ = [(n, c_int) for n in ("struct_bytes", "max_splitk", "splitk_min_steps", "min_splitk", "plane_pair", "dense64",
                                      "half_n", "vfe_shape", "field_seg", "field_tpw", "wgrad_blocks", "debug_sync",
@@ -213,6 +218,8 @@ def _declare(lib):
     lib.lisec_conv_plan_query.restype = c_int
     lib.lisec_conv_plan_query.argtypes = [POINTER(ConvGeom), c_int, c_int, POINTER(ConvExtras), c_int, c_size_t, c_int, c_int,
                                           POINTER(ConvPlan)]
+    lib.lisec_conv_wgrad_plan_query.restype = c_int
+    lib.lisec_conv_wgrad_plan_query.argtypes = [POINTER(ConvGeom), c_int, c_int, c_int, c_int, POINTER(WgradPlan)]
     lib.lisec_tuning_get.restype = c_int
     lib.lisec_tuning_get.argtypes = [POINTER(Tuning)]
     lib.lisec_tuning_set.restype = c_int

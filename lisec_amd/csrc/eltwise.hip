@@ -355,10 +355,11 @@ extern "C" int lisec_bn_backward_apply_coef(const float* dA, int da_stride, cons
 // move between the Keras-shaped variables and the merged (768,16) head layout without one tiny launch per slice
 __global__ void k_copy2d_batched(const lisec_copy_desc* __restrict__ tab) {
     const lisec_copy_desc d = tab[blockIdx.x];
-    const int total = d.rows * d.cols;                      // small slices: 32-bit index arithmetic
-    for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < total; i += gridDim.y * blockDim.x) {
-        const int r = i / d.cols, c = i - r * d.cols;
-        d.dst[(long long)r * d.dst_stride + c] = d.src[(long long)r * d.src_stride + c];
+    const long long total = (long long)d.rows * d.cols;     // (public entry point: the product may exceed 2^31)
+    for (long long i = blockIdx.y * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.y * blockDim.x) {
+        const long long r = i / d.cols;
+        const int c = (int)(i - r * d.cols);
+        d.dst[r * d.dst_stride + c] = d.src[r * d.src_stride + c];
     }
 }
 

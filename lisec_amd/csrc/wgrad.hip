@@ -603,6 +603,35 @@ extern "C" size_t lisec_conv_wgrad_workspace_bytes(const lisec_conv_geom* c, int
     return a > b ? (a > m0 ? a : m0) : (b > m0 ? b : m0);
 }
 
+extern "C" int lisec_conv_wgrad_plan_query(const lisec_conv_geom* c, int flags, int has_dy_bnstate, int has_row_list,
+                                           int row_capacity, lisec_wgrad_plan* out) {
+    LISEC_CHECK_ARG(out, "NULL plan");
+    ConvGeom g;
+    if (int rc = conv_geom_check(c, &g)) return rc;
+    static const int32_t dummy[4] = {0, 0, 0, 0};
+    if (has_row_list) {
+        LISEC_CHECK_ARG(row_capacity > 0, "row list needs a capacity");
+        g.row_coords = dummy; g.row_count = dummy + 3; g.M = row_capacity; g.pointwise = 0;
+    }
+    const bool dy_xf = has_dy_bnstate || (flags & LISEC_CONV_DY_RELU);
+    const bool flip = c->mode == 1 && g.ls_d == 0 && g.ls_h == 0 && g.ls_w == 0 && g.KW == 3 && !has_row_list && !dy_xf;
+    if (flip) { g.pd = g.KD - 1 - g.pd; g.ph = g.KH - 1 - g.ph; g.pw = g.KW - 1 - g.pw; }
+    const WgradPlan p = make_plan(g, flip ? 0 : c->mode, dy_xf);
+    out->halo = p.halo ? 1 : 0;
+    out->mirrored = flip ? 1 : 0;
+    out->taps_per_group = p.TG;
+    out->groups = p.ngroups;
+    out->tile_rows = p.halo ? p.LT : BMW;
+    out->staging_passes = p.halo ? (p.LT + 2 <= 7 * 16 ? 7 : 9) : 8;
+    out->tiles = p.ntiles;
+    out->slabs = p.nsplit;
+    out->tiles_per_slab = p.tiles_per_split;
+    out->workgroups = p.nsplit * p.ngroups * cdiv(g.Cin, BC) * cdiv(g.Cout, BC);
+    const long long per = (long long)g.KD * g.KH * g.KW * g.Cin * g.Cout;
+    out->lane_reduce = (cdiv(per / 4, 256) < 64 && p.nsplit >= 128) ? 1 : 0;
+    return LISEC_OK;
+}
+
 extern "C" int lisec_conv_wgrad(const lisec_conv_geom* c, const float* in, const float* in_bnstate, int flags,
                                 const float* dy, const float* dy_bnstate, void* workspace,
                                 size_t workspace_bytes, int transpose_out, float* dW, const int32_t* row_coords,

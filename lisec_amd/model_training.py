@@ -184,6 +184,14 @@ def combine_lidar_data_gpu(sample, dataDir, level5Data, device=None):
 class RepeatLayer:
     """repeat_elements(x, maxPoints, axis=-2): (…,1,C) -> (…,35,C)."""
 
+    def __init__(self, **kwargs):
+        pass
+
+    def compute_output_shape(self, inputShape):
+        """(…, 1, C) -> (…, maxPoints, C) (reference model_training.py:36-37)."""
+        inputShape = tuple(inputShape)
+        return inputShape[:Constants.pointIndex] + (Constants.maxPoints,) + inputShape[Constants.pointIndex + 1:]
+
     def __call__(self, inputs):
         return torch.repeat_interleave(torch.as_tensor(inputs), Constants.maxPoints, dim=Constants.pointIndex)
 
@@ -195,6 +203,12 @@ class MaxPoolingVFELayer:
 
     def __init__(self, combine=False, **kwargs):
         self.combineDim = combine
+
+    def compute_output_shape(self, inputShape):
+        """(…, T, C) -> (…, 1, C), or (…, C) with combine=True (reference model_training.py:49-53)."""
+        inputShape = tuple(inputShape)
+        mid = () if self.combineDim else (1,)
+        return inputShape[:Constants.pointIndex] + mid + inputShape[Constants.pointIndex + 1:]
 
     def __call__(self, inputs):
         return torch.as_tensor(inputs).max(dim=Constants.pointIndex, keepdim=not self.combineDim).values

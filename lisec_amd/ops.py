@@ -212,6 +212,14 @@ def wgrad_workspace_bytes(g, row_capacity=0):
     return _lib.load().lisec_conv_wgrad_workspace_bytes(ctypes.byref(g), row_capacity)
 
 
+def wgrad_plan(g, flags=0, dy_bn=False, rows_capacity=0):
+    """The launch plan conv_wgrad(...) runs for these arguments (lisec_conv_wgrad_plan_query), as a dict."""
+    plan = _lib.WgradPlan()
+    _lib.check(_lib.load().lisec_conv_wgrad_plan_query(ctypes.byref(g), flags, 1 if dy_bn else 0,
+                                                       1 if rows_capacity > 0 else 0, rows_capacity, ctypes.byref(plan)))
+    return {n: getattr(plan, n) for n, _ in _lib.WgradPlan._fields_}
+
+
 def conv_wgrad(g, x, dy, dW, workspace, in_bn=None, flags=0, transpose_out=False, dy_bn=None, rows=None):
     rc, rn, cap = rows if rows is not None else (None, None, 0)
     _lib.check(_lib.load().lisec_conv_wgrad(ctypes.byref(g), _lib.ptr(x), _lib.ptr(in_bn), flags, _lib.ptr(dy),

@@ -119,6 +119,12 @@ def test_sparse_tensor_surface_and_dense_input():
     x = torch.arange(2 * 1 * 3, dtype=torch.float32).reshape(2, 1, 3)
     assert mt.RepeatLayer()(x).shape == (2, 35, 3)
     assert mt.MaxPoolingVFELayer(combine=True)(torch.rand(4, 35, 8)).shape == (4, 8)
+    # compute_output_shape as the reference's layers declare it (model_training.py:36-37, 49-53)
+    shape = (None, 8, 200, 400, 35, 16)
+    assert mt.MaxPoolingVFELayer().compute_output_shape(shape) == (None, 8, 200, 400, 1, 16)
+    assert mt.MaxPoolingVFELayer(combine=True).compute_output_shape(shape) == (None, 8, 200, 400, 16)
+    assert mt.RepeatLayer().compute_output_shape((None, 8, 200, 400, 1, 16)) == shape
+    assert mt.MaxPoolingVFELayer(combine=True).get_config() == {"combine": True}
     assert mt.get_voxel((-0.1, 0.3, 0.6), 0.5, 0.25, 0.25) == (-1, 1, 2)
 
 
