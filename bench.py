@@ -292,6 +292,7 @@ def main():
     # run, issue each step from the Python schedule.
     from lisec_amd import _lib
     use_plan = dp is None and _lib.knob("step_plan", True)
+
     if use_plan:
         from lisec_amd.network import RecordedStep
         captured = RecordedStep(net, vox, len(cloud), dtype=pts.dtype, loss=args.loss)

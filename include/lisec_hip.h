@@ -354,6 +354,7 @@ typedef struct lisec_wgrad_plan {
     int tiles, slabs, tiles_per_slab;   /* M tiles, partial slabs (= ranges of tiles), tiles per range                   */
     int workgroups;
     int lane_reduce;     /* many slabs over a small kernel: the lane-strided slab sum                                     */
+    int combine_in_kernel; /* few slabs per cell: summed by the last slice to arrive, no slab-sum launch                  */
 } lisec_wgrad_plan;
 int lisec_conv_wgrad_plan_query(const lisec_conv_geom* g, int flags, int has_dy_bnstate, int has_row_list, int row_capacity,
                                 lisec_wgrad_plan* plan);
@@ -361,6 +362,25 @@ int lisec_conv_wgrad(const lisec_conv_geom* g, const float* in, const float* in_
                      const float* dy, const float* dy_bnstate, void* workspace, size_t workspace_bytes,
                      int transpose_out, float* dW, const int32_t* row_coords, const int32_t* row_count,
                      int row_capacity, lisec_stream_t stream);
+/* The weight-gradient workspace must be ZERO-FILLED once before its first use, like the contraction workspace: contractions
+ * whose slabs are combined inside the kernel keep their arrival counters at its head (left at zero by every call).
+ *
+ * Several weight gradients in ONE launch: the stride-1 3x3 convolutions of an RPN block (:203, three to five layers whose
+ * maps hold 1 250 - 20 000 positions) fill a fraction of the chip each and are leaves of the backward pass, so they can wait
+ * for each other and share a launch.  Items that cannot share one (not all on the w-halo kernel with the same staging) run
+ * one after the other with the same results.  n <= 6. */
+typedef struct lisec_wgrad_item {
+    const lisec_conv_geom* g;
+    const float* in;
+    const float* in_bnstate;
+    int flags;
+    const float* dy;
+    int transpose_out;
+    float* dW;
+} lisec_wgrad_item;
+size_t lisec_conv_wgrad_batched_workspace_bytes(const lisec_wgrad_item* items, int n);
+int lisec_conv_wgrad_batched(const lisec_wgrad_item* items, int n, void* workspace, size_t workspace_bytes,
+                             lisec_stream_t stream);
 
 /* First middle layer, exact sparse backward (see csrc/sparse_grid.hip).
  *   lisec_conv_tap_sums: S[tap][n] = sum of dy[m][n] over the output positions m of the mode-0 conv `g` whose
@@ -380,6 +400,10 @@ int lisec_conv_tap_sums(const lisec_conv_geom* g, const float* dy, float* S, voi
 int lisec_conv_tap_sums_bn(const lisec_conv_geom* g, const float* dz, const float* y, const float* bnstate,
                            const float* coef, float* dy, float* S, void* workspace, size_t workspace_bytes,
                            lisec_stream_t stream);
+/* S == NULL in lisec_conv_tap_sums_bn stops after the per-line sums (left in `workspace`); lisec_conv_tap_sums_finish sums
+ * them into S later -- on another stream, beside the row-list data gradient that only needs the dy the first pass stored. */
+int lisec_conv_tap_sums_finish(const lisec_conv_geom* g, const void* workspace, size_t workspace_bytes, float* S,
+                               lisec_stream_t stream);
 int lisec_const_field_grads(const float* W, const float* S, const float* cvec, const int32_t* cvec_row,
                             int cvec_row_max, int ntaps, int Cin, int Cout, float* dW, float* g_all,
                             lisec_stream_t stream);
@@ -613,6 +637,8 @@ typedef struct lisec_tuning {
     int wgrad_blocks;       /* workgroups a weight-gradient launch aims for                        (1024)      */
     int debug_sync;         /* lisec_vfe_backward synchronises and reports after every launch      (0)         */
     int force_splitk;       /* > 0: every sliceable layer gets exactly this many K slices          (0)         */
+    int wgrad_combine_max;  /* weight gradients with at most this many slabs per cell sum them in-kernel (32)   */
+    int wgrad_batch_blocks; /* workgroups a batched weight-gradient launch aims for                (1024)      */
 } lisec_tuning;
 int lisec_tuning_get(lisec_tuning* t);        /* fills *t with the current record (t->struct_bytes set)          */
 int lisec_tuning_set(const lisec_tuning* t);  /* t->struct_bytes must be sizeof(lisec_tuning)                    */

@@ -49,13 +49,13 @@ class ConvPlan(Structure):                     # lisec_conv_plan
 
 class WgradPlan(Structure):                    # lisec_wgrad_plan
     _fields_ = [(n, c_int) for n in ("halo", "mirrored", "taps_per_group", "groups", "tile_rows", "staging_passes", "tiles",
-                                     "slabs", "tiles_per_slab", "workgroups", "lane_reduce")]
+                                     "slabs", "tiles_per_slab", "workgroups", "lane_reduce", "combine_in_kernel")]
 
 
 class Tuning(Structure):                       # lisec_tuning
     _fields_ = [(n, c_int) for n in ("struct_bytes", "max_splitk", "splitk_min_steps", "min_splitk", "plane_pair", "dense64",
                                      "half_n", "vfe_shape", "field_seg", "field_tpw", "wgrad_blocks", "debug_sync",
-                                     "force_splitk")]
+                                     "force_splitk", "wgrad_combine_max", "wgrad_batch_blocks")]
 
 
 KERNEL_NAMES = {0: "igemm", 1: "halo2", 2: "halo3", 3: "dense64", 4: "queue"}
@@ -76,6 +76,11 @@ class ConvGeom(Structure):
     _fields_ = [(n, c_int) for n in ("mode", "Di", "Hi", "Wi", "Do", "Ho", "Wo", "KD", "KH", "KW",
                                      "sd", "sh", "sw", "pd", "ph", "pw", "Cin", "in_stride", "Cout",
                                      "out_stride", "ps", "ps_channels")]
+
+
+class WgradItem(Structure):                    # lisec_wgrad_item
+    _fields_ = [("g", POINTER(ConvGeom)), ("in_", c_void_p), ("in_bnstate", c_void_p), ("flags", c_int), ("dy", c_void_p),
+                ("transpose_out", c_int), ("dW", c_void_p)]
 
 
 ROW_STATS_REPLICAS = 16                       # LISEC_ROW_STATS_* of include/lisec_hip.h
@@ -129,6 +134,8 @@ def _declare(lib):
     lib.lisec_conv_tap_sums.argtypes = [POINTER(ConvGeom), P, P, P, c_size_t, P]
     lib.lisec_conv_tap_sums_bn.restype = c_int
     lib.lisec_conv_tap_sums_bn.argtypes = [POINTER(ConvGeom), P, P, P, P, P, P, P, c_size_t, P]
+    lib.lisec_conv_tap_sums_finish.restype = c_int
+    lib.lisec_conv_tap_sums_finish.argtypes = [POINTER(ConvGeom), P, c_size_t, P, P]
     lib.lisec_conv_field_forward_workspace_bytes.restype = c_size_t
     lib.lisec_conv_field_forward_workspace_bytes.argtypes = [POINTER(ConvGeom), c_int]
     lib.lisec_conv_field_forward.restype = c_int
@@ -218,6 +225,10 @@ def _declare(lib):
     lib.lisec_conv_plan_query.restype = c_int
     lib.lisec_conv_plan_query.argtypes = [POINTER(ConvGeom), c_int, c_int, POINTER(ConvExtras), c_int, c_size_t, c_int, c_int,
                                           POINTER(ConvPlan)]
+    lib.lisec_conv_wgrad_batched_workspace_bytes.restype = c_size_t
+    lib.lisec_conv_wgrad_batched_workspace_bytes.argtypes = [POINTER(WgradItem), c_int]
+    lib.lisec_conv_wgrad_batched.restype = c_int
+    lib.lisec_conv_wgrad_batched.argtypes = [POINTER(WgradItem), c_int, P, c_size_t, P]
     lib.lisec_conv_wgrad_plan_query.restype = c_int
     lib.lisec_conv_wgrad_plan_query.argtypes = [POINTER(ConvGeom), c_int, c_int, c_int, c_int, POINTER(WgradPlan)]
     lib.lisec_tuning_get.restype = c_int

@@ -13,7 +13,7 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-static lisec_tuning g_tuning = {(int)sizeof(lisec_tuning), 12, 3, 2, 1, 1, 1, -1, 0, 0, 1024, 0, 0};
+static lisec_tuning g_tuning = {(int)sizeof(lisec_tuning), 12, 3, 2, 1, 1, 1, -1, 0, 0, 1024, 0, 0, 32, 1024};
 const lisec_tuning& tuning() { return g_tuning; }
 }  // namespace lisec
 
@@ -25,7 +25,7 @@ extern "C" int lisec_tuning_get(lisec_tuning* t) {
 
 extern "C" int lisec_tuning_set(const lisec_tuning* t) {
     LISEC_CHECK_ARG(t && t->struct_bytes == (int)sizeof(lisec_tuning), "tuning record of another ABI version");
-    LISEC_CHECK_ARG(t->max_splitk >= 1 && t->splitk_min_steps >= 1 && t->min_splitk >= 2 && t->wgrad_blocks >= 1,
+    LISEC_CHECK_ARG(t->max_splitk >= 1 && t->splitk_min_steps >= 1 && t->min_splitk >= 2 && t->wgrad_blocks >= 1 && t->wgrad_batch_blocks >= 1,
                     "tuning: max_splitk, splitk_min_steps, wgrad_blocks >= 1, min_splitk >= 2");
     lisec::g_tuning = *t;
     return LISEC_OK;

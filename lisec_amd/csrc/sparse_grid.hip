@@ -167,7 +167,7 @@ extern "C" int lisec_conv_tap_sums_bn(const lisec_conv_geom* c, const float* dz,
                                       lisec_stream_t stream_) {
     ConvGeom g;
     if (int rc = conv_geom_check(c, &g)) return rc;
-    LISEC_CHECK_ARG(c->mode == 0 && dz && S && workspace, "tap sums: mode-0 geometry and non-NULL pointers required");
+    LISEC_CHECK_ARG(c->mode == 0 && dz && workspace, "tap sums: mode-0 geometry and non-NULL pointers required");
     LISEC_CHECK_ARG(g.Cout % 4 == 0 && g.Cout <= 256 && 256 % (g.Cout / 4) == 0 && g.out_stride % 4 == 0,
                     "tap sums: Cout/4 must divide 256");
     const bool apply = y != nullptr;
@@ -185,7 +185,19 @@ extern "C" int lisec_conv_tap_sums_bn(const lisec_conv_geom* c, const float* dz,
     else
         LISEC_LAUNCH(k_line_sums<false>, dim3(g.Do * g.Ho), dim3(256), 0, st, g, dz, line_s, (const float*)nullptr,
                            (const float*)nullptr, (const float*)nullptr, (float*)nullptr);
-    LISEC_LAUNCH(k_tap_sums, dim3(g.KD * g.KH * g.KW), dim3(1024), 0, st, g, line_s, S);
+    if (S) LISEC_LAUNCH(k_tap_sums, dim3(g.KD * g.KH * g.KW), dim3(1024), 0, st, g, line_s, S);
+    LISEC_LAUNCH_CHECK();
+    return LISEC_OK;
+}
+
+extern "C" int lisec_conv_tap_sums_finish(const lisec_conv_geom* c, const void* workspace, size_t workspace_bytes, float* S,
+                                          lisec_stream_t stream_) {
+    ConvGeom g;
+    if (int rc = conv_geom_check(c, &g)) return rc;
+    LISEC_CHECK_ARG(c->mode == 0 && S && workspace && workspace_bytes >= lisec_conv_tap_sums_workspace_bytes(c),
+                    "tap sums: mode-0 geometry, S and the line-sum workspace of lisec_conv_tap_sums_bn");
+    LISEC_LAUNCH(k_tap_sums, dim3(g.KD * g.KH * g.KW), dim3(1024), 0, static_cast<hipStream_t>(stream_), g,
+                 static_cast<const float*>(workspace), S);
     LISEC_LAUNCH_CHECK();
     return LISEC_OK;
 }

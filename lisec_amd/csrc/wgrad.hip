@@ -252,19 +252,39 @@ k_wgrad(ConvGeom g, const float* __restrict__ in, const float* __restrict__ in_b
 // them) get no workgroups at all.
 struct LiveGroups { int n; unsigned char id[16]; };
 
+// One weight-gradient contraction as the halo kernel sees it: single launches pass one, batched launches a table of them.
+struct WgradItem {
+    ConvGeom g;
+    const float* in; const float* in_bn; const float* dy;
+    float* partial;          // slabs (combine: in the accumulator register layout, behind the arrival counters)
+    float* dW;               // combine: the finished kernel gradient is written by the last slice to arrive
+    int* counters;           // combine: one arrival counter per (group, c block, n block), zero between calls
+    int flags, nsplit, tiles_per_split, flip, LT, transpose, combine;
+    int gx, gy, gz;          // grid of this item: gx = nsplit * groups
+    LiveGroups live;
+};
+
+// Slab of one (slice, cell) in the register layout: [wave 4][q 12 = 3 taps x 4 float4][lane 64] float4 = 48 KB.
+constexpr int kWSlabF4 = 4 * 12 * 64;
+constexpr int kWgradCounters = 4096;
+
 // NP: staging passes of 16 rows.  7 (tiles of <= 110 rows: the 400-wide middle layers run 4 x 100) needs 12 registers
 // fewer than 9 and, with the fragment reads software-pipelined by hand, fits three workgroups per CU.
 template <bool XF, int NP>
-__global__ void __launch_bounds__(kThreads, NP == 7 ? 3 : 2)
-k_wgrad_halo(ConvGeom g, const float* __restrict__ in, const float* __restrict__ in_bn, int flags,
-             const float* __restrict__ dy, int nsplit, int tiles_per_split, float* __restrict__ partial, int flip,
-             int LT, LiveGroups live) {
+__device__ __forceinline__ void
+wgrad_halo_body(const WgradItem& it, const int bx, const int by, const int bz, float* smem, unsigned long long* stamps,
+                const unsigned stamp_wg) {
     constexpr int PA = NP, PD = NP == 7 ? 7 : 8;
+    const ConvGeom& g = it.g;
+    const float* __restrict__ in = it.in;
+    const float* __restrict__ in_bn = it.in_bn;
+    const float* __restrict__ dy = it.dy;
+    float* __restrict__ partial = it.partial;
+    const int flags = it.flags, nsplit = it.nsplit, tiles_per_split = it.tiles_per_split, flip = it.flip, LT = it.LT;
+    const LiveGroups& live = it.live;
+    (void)nsplit;
     // LT <= 128: rows per tile, chosen by the host so that the tiles of one line are equal (W' = 400 -> 4 x 100) and,
     // with DR = LT rounded up to 8, the workgroup's LDS is (2 DR + 2) x 256 B: 53 760 B at LT = 100, three per CU
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    unsigned long long* stamps = g_wgrad_stamps;
-    const unsigned stamp_wg = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
     WGRAD_STAMP(0);
     const int DR = (LT + 7) & ~7;
     float* sA = smem;                                  // [DR + 2][64]: halo rows, zero beyond len + 2
@@ -272,9 +292,9 @@ k_wgrad_halo(ConvGeom g, const float* __restrict__ in, const float* __restrict__
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ngroups = live.n;
-    const int split = blockIdx.x / ngroups, group = live.id[blockIdx.x - split * ngroups];
+    const int split = bx / ngroups, gslot = bx - split * ngroups, group = live.id[gslot];
     const int kd = group / g.KH, kh = group - kd * g.KH;
-    const int c0 = blockIdx.y * BC, n0 = blockIdx.z * BC;
+    const int c0 = by * BC, n0 = bz * BC;
     const int tpl = (g.Wo + LT - 1) / LT;              // tiles per output line
     const int ntiles = g.Do * g.Ho * tpl;
     const int t_begin = split * tiles_per_split;
@@ -425,19 +445,94 @@ k_wgrad_halo(ConvGeom g, const float* __restrict__ in, const float* __restrict__
     const int ntaps = g.KD * g.KH * g.KW;
     const int tap0 = (kd * g.KH + kh) * g.KW;
     const int n = n0 + (wave & 1) * 32 + (lane & 31);
+    float* out_base = partial;
+    size_t out_split = (size_t)split;
+    bool transpose = false;
+    if (it.combine) {
+        // The slices of a cell (group, c block, n block) meet here, as the K slices of a tile do in igemm.hip: slab stores in
+        // the register layout (write-through), every wave waits for its stores, barrier, ONE lane's agent-scope ticket; the
+        // last slice to arrive adds the slabs in slice order (deterministic) and writes the finished gradient -- no slab-sum
+        // launch.  Used when a cell has few slices (the RPN maps); many slices (the middle layers) keep the slab-sum kernel.
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+        __shared__ int wg_last;
+        const int ncell = ngroups * it.gy * it.gz, cell = (gslot * it.gy + by) * it.gz + bz;
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(partial, 0, (int)((size_t)it.nsplit * ncell * kWSlabF4 * 16),
+                                                                      0x00020000);
+        const unsigned lane_off = (unsigned)((wave * 12) * 64 + lane) * 16u;
+        const unsigned mine = (unsigned)(((size_t)split * ncell + cell) * kWSlabF4 * 16) + lane_off;
+#pragma unroll
+        for (int q = 0; q < 12; ++q) {
+            const f32x16& a = q < 4 ? acc0 : (q < 8 ? acc1 : acc2);
+            const int r = (q & 3) * 4;
+            u32x4 v;
+            v.x = __float_as_uint(a[r]); v.y = __float_as_uint(a[r + 1]); v.z = __float_as_uint(a[r + 2]); v.w = __float_as_uint(a[r + 3]);
+            __builtin_amdgcn_raw_buffer_store_b128(v, rs, mine + q * 64 * 16, 0, 16);          // aux 16 = sc1
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0)
+            wg_last = __hip_atomic_fetch_add(it.counters + cell, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == it.nsplit - 1;
+        __syncthreads();
+        if (!wg_last) { WGRAD_STAMP(3); return; }
+        if (threadIdx.x == 0) __hip_atomic_store(it.counters + cell, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        f32x16 s0 = {0}, s1 = {0}, s2 = {0};
+        const unsigned zstride = (unsigned)((size_t)ncell * kWSlabF4 * 16);
+        unsigned off = (unsigned)((size_t)cell * kWSlabF4 * 16) + lane_off;
+        for (int z = 0; z < it.nsplit; ++z, off += zstride) {
+            u32x4 v[12];
+#pragma unroll
+            for (int q = 0; q < 12; ++q) v[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, off + q * 64 * 16, 0, 16);
+#pragma unroll
+            for (int q = 0; q < 12; ++q) {
+                f32x16& a = q < 4 ? s0 : (q < 8 ? s1 : s2);
+                const int r = (q & 3) * 4;
+                a[r] += __uint_as_float(v[q].x); a[r + 1] += __uint_as_float(v[q].y);
+                a[r + 2] += __uint_as_float(v[q].z); a[r + 3] += __uint_as_float(v[q].w);
+            }
+        }
+        acc0 = s0; acc1 = s1; acc2 = s2;
+        out_base = it.dW; out_split = 0; transpose = it.transpose != 0;
+    }
 #pragma unroll
     for (int tt = 0; tt < 3; ++tt) {
         // flip: a stride-1 transposed gather (o + p - k) run as the plain one (o - (K-1-p) + k') with k' = K-1-k
         const int tap = flip ? ((g.KD - 1 - kd) * g.KH + (g.KH - 1 - kh)) * g.KW + (2 - tt) : tap0 + tt;
-        float* base = partial + ((size_t)split * ntaps + tap) * g.Cin * g.Cout;
+        float* base = out_base + (out_split * ntaps + tap) * g.Cin * g.Cout;
         const f32x16& acc = tt == 0 ? acc0 : (tt == 1 ? acc1 : acc2);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int c = c0 + (wave >> 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            if (c < g.Cin && n < g.Cout) base[(size_t)c * g.Cout + n] = acc[r];
+            if (c < g.Cin && n < g.Cout) {
+                if (transpose) base[(size_t)n * g.Cin + c] = acc[r];          // (taps, Cout, Cin): the Conv2DTranspose layout
+                else base[(size_t)c * g.Cout + n] = acc[r];
+            }
         }
     }
     WGRAD_STAMP(3);
+}
+
+template <bool XF, int NP>
+__global__ void __launch_bounds__(kThreads, NP == 7 ? 3 : 2)
+k_wgrad_halo(WgradItem it) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    wgrad_halo_body<XF, NP>(it, blockIdx.x, blockIdx.y, blockIdx.z, smem, g_wgrad_stamps,
+                            (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
+}
+
+// Several contractions in ONE launch (the stride-1 convolutions of an RPN block: up to five layers whose maps hold 1 250 -
+// 20 000 positions and fill a fraction of the chip each): workgroup -> (item, block of that item's grid).
+constexpr int kBatchMax = 6;
+struct WgradBatch { int n; int first[kBatchMax + 1]; WgradItem item[kBatchMax]; };
+template <bool XF, int NP>
+__global__ void __launch_bounds__(kThreads, NP == 7 ? 3 : 2)
+k_wgrad_halo_batch(WgradBatch b) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    int i = 0;
+    while (i + 1 < b.n && (int)blockIdx.x >= b.first[i + 1]) ++i;
+    const WgradItem& it = b.item[i];
+    const int local = blockIdx.x - b.first[i];
+    const int bx = local % it.gx, by = (local / it.gx) % it.gy, bz = local / (it.gx * it.gy);
+    wgrad_halo_body<XF, NP>(it, bx, by, bz, smem, g_wgrad_stamps, blockIdx.x);
 }
 
 // dW = sum over splits (index order).  transpose: write [tap][n][c] (Conv2DTranspose kernels are (kh,kw,out,in)).
@@ -525,12 +620,14 @@ struct WgradPlan {
     int TG, ngroups, nsplit, tiles_per_split, ntiles;
     int LT;              // halo kernel: rows per tile
     bool halo;
-    size_t ws_bytes;
-    LiveGroups live;     // halo kernel: the (kd, kh) groups that read inside the input for at least one output line
+    bool combine;        // halo kernel: few slices per cell -> the last one to arrive sums the slabs and writes dW
+    size_t ws_bytes, slab_bytes;
+    LiveGroups live;     // halo kernel: the (kd, kh) groups that get workgroups
 };
 
-WgradPlan make_plan(const ConvGeom& g, int mode = 0, bool dy_xf = false) {
+WgradPlan make_plan(const ConvGeom& g, int mode = 0, bool dy_xf = false, int blocks_target = 0) {
     WgradPlan p;
+    p.combine = false;
     p.TG = g.KW <= 4 ? g.KW : 1;
     if (g.KW % p.TG) p.TG = 1;
     p.ngroups = g.KD * g.KH * (g.KW / p.TG);
@@ -555,13 +652,28 @@ WgradPlan make_plan(const ConvGeom& g, int mode = 0, bool dy_xf = false) {
     }
     int cb = cdiv(g.Cin, BC), nb = cdiv(g.Cout, BC);
     int base = p.ngroups * cb * nb;
-    int want = cdiv(tuning().wgrad_blocks, base);   // 1024: ~2 rounds of the 512 resident workgroups (measured: 512-1024 blocks
+    const int target = blocks_target > 0 ? blocks_target : tuning().wgrad_blocks;
+    int want = cdiv(target, base);              // 1024: ~2 rounds of the 512 resident workgroups (measured: 512-1024 blocks
                                                 // beat 1536+, whose extra slabs cost more in the reduce than they balance)
     if (want < 1) want = 1;
     if (want > p.ntiles) want = p.ntiles;
     p.tiles_per_split = cdiv(p.ntiles, want);
     p.nsplit = cdiv(p.ntiles, p.tiles_per_split);
-    p.ws_bytes = align_up(sizeof(float) * (size_t)p.nsplit * g.KD * g.KH * g.KW * g.Cin * g.Cout, 256);
+    // every plan keeps the head of the workspace (kWgradCounters arrival counters) free, so that the counters of the
+    // combining plans stay zero whatever else shares the workspace; p.slab_bytes = what follows the head
+    p.slab_bytes = align_up(sizeof(float) * (size_t)p.nsplit * g.KD * g.KH * g.KW * g.Cin * g.Cout, 256);
+    p.ws_bytes = sizeof(int) * kWgradCounters + p.slab_bytes;
+    if (p.halo && p.nsplit <= tuning().wgrad_combine_max && g.KD * g.KH <= 16 &&
+        (long long)g.KD * g.KH * cb * nb <= kWgradCounters) {
+        // few slices per cell: combined inside the kernel (every group gets workgroups: the cells of a group that reads
+        // nothing must still be written, as zeros)
+        p.combine = true;
+        p.live.n = g.KD * g.KH;
+        for (int i = 0; i < p.live.n; ++i) p.live.id[i] = (unsigned char)i;
+        p.ngroups = p.live.n;
+        p.slab_bytes = align_up((size_t)p.nsplit * p.ngroups * cb * nb * kWSlabF4 * 16, 256);
+        p.ws_bytes = sizeof(int) * kWgradCounters + p.slab_bytes;
+    }
     return p;
 }
 
@@ -628,66 +740,62 @@ extern "C" int lisec_conv_wgrad_plan_query(const lisec_conv_geom* c, int flags, 
     out->tiles_per_slab = p.tiles_per_split;
     out->workgroups = p.nsplit * p.ngroups * cdiv(g.Cin, BC) * cdiv(g.Cout, BC);
     const long long per = (long long)g.KD * g.KH * g.KW * g.Cin * g.Cout;
-    out->lane_reduce = (cdiv(per / 4, 256) < 64 && p.nsplit >= 128) ? 1 : 0;
+    out->lane_reduce = (!p.combine && cdiv(per / 4, 256) < 64 && p.nsplit >= 128) ? 1 : 0;
+    out->combine_in_kernel = p.combine ? 1 : 0;
     return LISEC_OK;
 }
 
-extern "C" int lisec_conv_wgrad(const lisec_conv_geom* c, const float* in, const float* in_bnstate, int flags,
-                                const float* dy, const float* dy_bnstate, void* workspace,
-                                size_t workspace_bytes, int transpose_out, float* dW, const int32_t* row_coords,
-                                const int32_t* row_count, int row_capacity, lisec_stream_t stream_) {
-    ConvGeom g;
+namespace {
+// A halo-kernel call made ready: geometry (mirrored if need be), plan, the item the kernel takes.
+struct HaloCall { WgradItem it; WgradPlan p; bool xf; int np; unsigned long long dead_taps; };
+
+// returns 0 and fills `hc` when the contraction runs on the halo kernel; 1 when it does not; < 0 on error
+int prepare_halo(const lisec_conv_geom* c, const float* in, const float* in_bnstate, int flags, const float* dy,
+                 const float* dy_bnstate, int transpose_out, float* dW, bool has_rows, int blocks_target, HaloCall* hc) {
+    ConvGeom& g = hc->it.g;
     if (int rc = conv_geom_check(c, &g)) return rc;
-    if (row_coords) {
-        LISEC_CHECK_ARG(row_count && row_capacity > 0, "row list needs a device count and a capacity");
-        g.row_coords = row_coords; g.row_count = row_count; g.M = row_capacity; g.pointwise = 0;
-    }
-    LISEC_CHECK_ARG(in && dy && workspace && dW, "NULL pointer");
-    LISEC_CHECK_ARG(g.out_stride % 4 == 0 && g.Cout % 4 == 0, "dY channels/stride must be multiples of 4");
-    LISEC_CHECK_ARG(((uintptr_t)in & 15) == 0 && ((uintptr_t)dy & 15) == 0, "in/dy must be 16-byte aligned");
     const bool dy_xf = dy_bnstate != nullptr || (flags & LISEC_CONV_DY_RELU);
     // a transposed gather with unit strides is the plain gather with mirrored taps and pads K-1-p: the halo kernel
     // serves it (first deconv: kernel 3, stride 1, 'same')
-    const bool flip = c->mode == 1 && g.ls_d == 0 && g.ls_h == 0 && g.ls_w == 0 && g.KW == 3 && !row_coords && !dy_xf;
+    const bool flip = c->mode == 1 && g.ls_d == 0 && g.ls_h == 0 && g.ls_w == 0 && g.KW == 3 && !has_rows && !dy_xf;
     if (flip) { g.pd = g.KD - 1 - g.pd; g.ph = g.KH - 1 - g.ph; g.pw = g.KW - 1 - g.pw; }
-    WgradPlan p = make_plan(g, flip ? 0 : c->mode, dy_xf);
-    if (workspace_bytes < p.ws_bytes) {
-        set_error("wgrad workspace too small: %zu < %zu", workspace_bytes, p.ws_bytes);
-        return LISEC_ENOSPC;
-    }
-    hipStream_t st = static_cast<hipStream_t>(stream_);
-    float* partial = static_cast<float*>(workspace);
-    int rc = 0;
-    if (p.halo) {
-        dim3 grid(p.nsplit * p.ngroups, cdiv(g.Cin, BC), cdiv(g.Cout, BC));
-        const int DR = (p.LT + 7) & ~7;
-        const size_t lds = (size_t)(2 * DR + 2) * BC * sizeof(float);
-        const bool xf = in_bnstate || (flags & LISEC_CONV_IN_RELU);
-#define LISEC_WH(X_, NP_) LISEC_LAUNCH((k_wgrad_halo<X_, NP_>), grid, dim3(kThreads), lds, st, g, in, in_bnstate, flags, dy, \
-        p.nsplit, p.tiles_per_split, partial, flip ? 1 : 0, p.LT, p.live)
-        if (p.LT + 2 <= 7 * 16) { if (xf) LISEC_WH(true, 7); else LISEC_WH(false, 7); }
-        else                    { if (xf) LISEC_WH(true, 9); else LISEC_WH(false, 9); }
-#undef LISEC_WH
-        LISEC_LAUNCH_CHECK();
-    } else {
-        rc = c->mode == 0 ? launch_wgrad<0>(g, p, in, in_bnstate, flags, dy, dy_bnstate, partial, st)
-                          : launch_wgrad<1>(g, p, in, in_bnstate, flags, dy, dy_bnstate, partial, st);
-    }
-    if (rc) return rc;
-    const int ntaps = g.KD * g.KH * g.KW;
-    unsigned long long dead_taps = 0;           // taps of the (kd, kh) groups the halo launch left out: written as zeros
-    if (p.halo) {
-        unsigned ran = 0;
-        for (int i = 0; i < p.live.n; ++i) ran |= 1u << p.live.id[i];
-        for (int gi = 0; gi < g.KD * g.KH; ++gi) {
-            if ((ran >> gi) & 1) continue;
-            const int kd = gi / g.KH, kh = gi - kd * g.KH;
-            for (int tt = 0; tt < 3; ++tt) {
-                const int tap = flip ? ((g.KD - 1 - kd) * g.KH + (g.KH - 1 - kh)) * g.KW + (2 - tt) : gi * g.KW + tt;
-                dead_taps |= 1ULL << tap;
-            }
+    if (has_rows) return 1;
+    hc->p = make_plan(g, flip ? 0 : c->mode, dy_xf, blocks_target);
+    if (!hc->p.halo) return 1;
+    const WgradPlan& p = hc->p;
+    WgradItem& it = hc->it;
+    it.in = in; it.in_bn = in_bnstate; it.dy = dy; it.dW = dW;
+    it.flags = flags; it.nsplit = p.nsplit; it.tiles_per_split = p.tiles_per_split; it.flip = flip ? 1 : 0; it.LT = p.LT;
+    it.transpose = transpose_out; it.combine = p.combine ? 1 : 0;
+    it.gx = p.nsplit * p.ngroups; it.gy = cdiv(g.Cin, BC); it.gz = cdiv(g.Cout, BC);
+    it.live = p.live;
+    hc->xf = in_bnstate || (flags & LISEC_CONV_IN_RELU);
+    hc->np = p.LT + 2 <= 7 * 16 ? 7 : 9;
+    hc->dead_taps = 0;
+    unsigned ran = 0;
+    for (int i = 0; i < p.live.n; ++i) ran |= 1u << p.live.id[i];
+    for (int gi = 0; gi < g.KD * g.KH; ++gi) {
+        if ((ran >> gi) & 1) continue;
+        const int kd = gi / g.KH, kh = gi - kd * g.KH;
+        for (int tt = 0; tt < 3; ++tt) {
+            const int tap = flip ? ((g.KD - 1 - kd) * g.KH + (g.KH - 1 - kh)) * g.KW + (2 - tt) : gi * g.KW + tt;
+            hc->dead_taps |= 1ULL << tap;
         }
     }
+    return 0;
+}
+
+// workspace = [kWgradCounters arrival counters][slabs]; counter0: first counter of this call, slab_off: bytes into the slabs
+void place_workspace(HaloCall* hc, void* workspace, int counter0, size_t slab_off) {
+    hc->it.counters = static_cast<int*>(workspace) + counter0;
+    hc->it.partial = reinterpret_cast<float*>(static_cast<char*>(workspace) + sizeof(int) * kWgradCounters + slab_off);
+}
+
+size_t halo_lds(const HaloCall& hc) { const int DR = (hc.p.LT + 7) & ~7; return (size_t)(2 * DR + 2) * BC * sizeof(float); }
+
+int launch_slab_sum(const ConvGeom& g, const WgradPlan& p, const float* partial, int transpose_out, float* dW,
+                    unsigned long long dead_taps, hipStream_t st) {
+    const int ntaps = g.KD * g.KH * g.KW;
     long long per = (long long)ntaps * g.Cin * g.Cout;
     int gb = cdiv(per / 4, 256);
     if (gb > 4096) gb = 4096;
@@ -698,6 +806,149 @@ extern "C" int lisec_conv_wgrad(const lisec_conv_geom* c, const float* in, const
         LISEC_LAUNCH(k_wgrad_reduce, dim3(gb), dim3(256), 0, st, partial, p.nsplit, ntaps, g.Cin, g.Cout,
                            transpose_out, dW, dead_taps);
     LISEC_LAUNCH_CHECK();
+    return LISEC_OK;
+}
+}  // namespace
+
+extern "C" int lisec_conv_wgrad(const lisec_conv_geom* c, const float* in, const float* in_bnstate, int flags,
+                                const float* dy, const float* dy_bnstate, void* workspace,
+                                size_t workspace_bytes, int transpose_out, float* dW, const int32_t* row_coords,
+                                const int32_t* row_count, int row_capacity, lisec_stream_t stream_) {
+    LISEC_CHECK_ARG(in && dy && workspace && dW, "NULL pointer");
+    LISEC_CHECK_ARG(((uintptr_t)in & 15) == 0 && ((uintptr_t)dy & 15) == 0, "in/dy must be 16-byte aligned");
+    hipStream_t st = static_cast<hipStream_t>(stream_);
+    HaloCall hc;
+    const int kind = prepare_halo(c, in, in_bnstate, flags, dy, dy_bnstate, transpose_out, dW, row_coords != nullptr, 0, &hc);
+    if (kind < 0) return kind;
+    ConvGeom& g = hc.it.g;                      // checked (and mirrored, for a unit-stride transposed gather) by prepare_halo
+    LISEC_CHECK_ARG(g.out_stride % 4 == 0 && g.Cout % 4 == 0, "dY channels/stride must be multiples of 4");
+    if (kind == 0) {
+        if (workspace_bytes < hc.p.ws_bytes) {
+            set_error("wgrad workspace too small: %zu < %zu", workspace_bytes, hc.p.ws_bytes);
+            return LISEC_ENOSPC;
+        }
+        place_workspace(&hc, workspace, 0, 0);
+        dim3 grid(hc.it.gx, hc.it.gy, hc.it.gz);
+        const size_t lds = halo_lds(hc);
+#define LISEC_WH(X_, NP_) LISEC_LAUNCH((k_wgrad_halo<X_, NP_>), grid, dim3(kThreads), lds, st, hc.it)
+        if (hc.np == 7) { if (hc.xf) LISEC_WH(true, 7); else LISEC_WH(false, 7); }
+        else            { if (hc.xf) LISEC_WH(true, 9); else LISEC_WH(false, 9); }
+#undef LISEC_WH
+        LISEC_LAUNCH_CHECK();
+        if (hc.p.combine) return LISEC_OK;
+        return launch_slab_sum(g, hc.p, hc.it.partial, transpose_out, dW, hc.dead_taps, st);
+    }
+    if (row_coords) {
+        LISEC_CHECK_ARG(row_count && row_capacity > 0, "row list needs a device count and a capacity");
+        g.row_coords = row_coords; g.row_count = row_count; g.M = row_capacity; g.pointwise = 0;
+    }
+    const bool dy_xf = dy_bnstate != nullptr || (flags & LISEC_CONV_DY_RELU);
+    WgradPlan p = make_plan(g, c->mode, dy_xf);
+    if (workspace_bytes < p.ws_bytes) {
+        set_error("wgrad workspace too small: %zu < %zu", workspace_bytes, p.ws_bytes);
+        return LISEC_ENOSPC;
+    }
+    float* partial = reinterpret_cast<float*>(static_cast<char*>(workspace) + sizeof(int) * kWgradCounters);
+    const int rc = c->mode == 0 ? launch_wgrad<0>(g, p, in, in_bnstate, flags, dy, dy_bnstate, partial, st)
+                                : launch_wgrad<1>(g, p, in, in_bnstate, flags, dy, dy_bnstate, partial, st);
+    if (rc) return rc;
+    return launch_slab_sum(g, p, partial, transpose_out, dW, 0, st);
+}
+
+// Several weight gradients in one launch (see k_wgrad_halo_batch): every item must take the halo kernel with the same
+// staging variant -- the stride-1 3x3 convolutions of one RPN block do -- otherwise the items run one after the other.
+// The launch aims for tuning.wgrad_blocks workgroups over ALL items, in proportion to their rows.
+namespace {
+int plan_batch(const lisec_wgrad_item* items, int n, HaloCall* hcs, size_t* offsets, size_t* total) {
+    // first pass: rows of work per item at one slice, to share the block target
+    long long work[kBatchMax], all = 0;
+    for (int i = 0; i < n; ++i) {
+        HaloCall probe;
+        const int kind = prepare_halo(items[i].g, items[i].in, items[i].in_bnstate, items[i].flags, items[i].dy, nullptr,
+                                      items[i].transpose_out, items[i].dW, false, 0, &probe);
+        if (kind != 0) return kind < 0 ? kind : 1;
+        const ConvGeom& g = probe.it.g;
+        work[i] = (long long)g.Do * g.Ho * g.Wo * g.KD * g.KH * cdiv(g.Cin, BC) * cdiv(g.Cout, BC);
+        all += work[i];
+    }
+    size_t off = 0;
+    for (int i = 0; i < n; ++i) {
+        int target = (int)((double)tuning().wgrad_batch_blocks * (double)work[i] / (double)all + 0.5);
+        if (target < 1) target = 1;
+        const int kind = prepare_halo(items[i].g, items[i].in, items[i].in_bnstate, items[i].flags, items[i].dy, nullptr,
+                                      items[i].transpose_out, items[i].dW, false, target, &hcs[i]);
+        if (kind != 0) return kind < 0 ? kind : 1;
+        if (hcs[i].xf != hcs[0].xf || hcs[i].np != hcs[0].np) return 1;
+        offsets[i] = off;
+        off += hcs[i].p.slab_bytes;
+    }
+    *total = sizeof(int) * kWgradCounters + off;
+    int cells = 0;
+    for (int i = 0; i < n; ++i) cells += hcs[i].p.ngroups * hcs[i].it.gy * hcs[i].it.gz;
+    if (cells > kWgradCounters) return 1;
+    return 0;
+}
+}  // namespace
+
+extern "C" size_t lisec_conv_wgrad_batched_workspace_bytes(const lisec_wgrad_item* items, int n) {
+    if (!items || n < 1 || n > kBatchMax) return 0;
+    HaloCall hcs[kBatchMax];
+    size_t offsets[kBatchMax], total = 0;
+    if (plan_batch(items, n, hcs, offsets, &total) == 0) return total;
+    size_t worst = 0;                               // not batchable: the items run one by one in the same workspace
+    for (int i = 0; i < n; ++i) {
+        const size_t w = lisec_conv_wgrad_workspace_bytes(items[i].g, 0);
+        worst = w > worst ? w : worst;
+    }
+    return worst;
+}
+
+extern "C" int lisec_conv_wgrad_batched(const lisec_wgrad_item* items, int n, void* workspace, size_t workspace_bytes,
+                                        lisec_stream_t stream_) {
+    LISEC_CHECK_ARG(items && n >= 1 && n <= kBatchMax && workspace, "1 .. 6 items and a workspace");
+    hipStream_t st = static_cast<hipStream_t>(stream_);
+    HaloCall hcs[kBatchMax];
+    size_t offsets[kBatchMax], total = 0;
+    const int kind = plan_batch(items, n, hcs, offsets, &total);
+    if (kind < 0) return kind;
+    if (kind != 0) {                                // one by one (same stream: they may share the workspace)
+        for (int i = 0; i < n; ++i)
+            if (int rc = lisec_conv_wgrad(items[i].g, items[i].in, items[i].in_bnstate, items[i].flags, items[i].dy, nullptr,
+                                          workspace, workspace_bytes, items[i].transpose_out, items[i].dW, nullptr, nullptr, 0,
+                                          stream_))
+                return rc;
+        return LISEC_OK;
+    }
+    if (workspace_bytes < total) {
+        set_error("batched wgrad workspace too small: %zu < %zu", workspace_bytes, total);
+        return LISEC_ENOSPC;
+    }
+    WgradBatch b;
+    b.n = n;
+    size_t lds = 0;
+    int blocks = 0, cells = 0;
+    for (int i = 0; i < n; ++i) {
+        LISEC_CHECK_ARG(items[i].in && items[i].dy && items[i].dW && ((uintptr_t)items[i].in & 15) == 0 &&
+                        ((uintptr_t)items[i].dy & 15) == 0, "item %d: NULL or unaligned tensor", i);
+        place_workspace(&hcs[i], workspace, cells, offsets[i]);
+        cells += hcs[i].p.ngroups * hcs[i].it.gy * hcs[i].it.gz;
+        b.first[i] = blocks;
+        b.item[i] = hcs[i].it;
+        blocks += hcs[i].it.gx * hcs[i].it.gy * hcs[i].it.gz;
+        const size_t l = halo_lds(hcs[i]);
+        lds = l > lds ? l : lds;
+    }
+    b.first[n] = blocks;
+#define LISEC_WB(X_, NP_) LISEC_LAUNCH((k_wgrad_halo_batch<X_, NP_>), dim3(blocks), dim3(kThreads), lds, st, b)
+    if (hcs[0].np == 7) { if (hcs[0].xf) LISEC_WB(true, 7); else LISEC_WB(false, 7); }
+    else                { if (hcs[0].xf) LISEC_WB(true, 9); else LISEC_WB(false, 9); }
+#undef LISEC_WB
+    LISEC_LAUNCH_CHECK();
+    for (int i = 0; i < n; ++i)
+        if (!hcs[i].p.combine)
+            if (int rc = launch_slab_sum(hcs[i].it.g, hcs[i].p, hcs[i].it.partial, items[i].transpose_out, items[i].dW,
+                                         hcs[i].dead_taps, st))
+                return rc;
     return LISEC_OK;
 }
 

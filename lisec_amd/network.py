@@ -173,6 +173,7 @@ class LisecNet:
         # can land on the main stream's queue (it does once RCCL has made its own streams) and then nothing
         # overlaps; a different priority level always gets its own hardware queue.
         self.side = torch.cuda.Stream(device=dev, priority=_lib.knob("side_priority", -1))
+
         self.branch_overlap = _lib.knob("branch_overlap", True)
         self._fwd_events = {}
         self._packed_version = -1
@@ -476,7 +477,22 @@ class LisecNet:
                 nparts = max(nparts, ops.num_mblocks_bwd(self.dgeom[L["dense"].name]) * 2 * 64)
         self.bparts = torch.empty(nparts, dtype=torch.float64, device=dev)
         self.head_db = torch.empty(16, dtype=f32, device=dev)
-        self.wgrad_ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        # the stride-1 convolutions of an RPN block (model_training.py:210-214) share ONE weight-gradient launch: maps of
+        # 1 250 - 20 000 positions fill a fraction of the chip each, and as leaves of the backward pass they can wait for each
+        # other (lisec_conv_wgrad_batched)
+        self.wgrad_batches = {}
+        if _lib.knob("wgrad_batch", True):
+            for b in range(len(RPN_BLOCKS)):
+                convs = [L for L in self.layers if L["kind"] == "conv" and L["name"].startswith(f"rpn{b+1}.conv")
+                         and L["name"] != f"rpn{b+1}.conv0"]
+                items = [(L["conv"].g, self.act[L["src"]], self.dact[L["dst"]], p.grad_view(self.grad, L["conv"].wname),
+                          self.bnstate[L["conv"].in_bn], ops.IN_RELU, False) for L in convs]
+                if 2 <= len(items) <= 6:
+                    batch = ops.WgradBatch(items)
+                    ws_bytes = max(ws_bytes, batch.workspace_bytes())
+                    self.wgrad_batches[convs[0]["name"]] = (batch, {L["name"] for L in convs})
+        # zero-filled: the head of the workspace holds the arrival counters of the slab-combining kernels
+        self.wgrad_ws = torch.zeros(ws_bytes, dtype=torch.uint8, device=dev)
         self._packed_t_version = -1
         self._train_ready = True
 
@@ -533,7 +549,7 @@ class LisecNet:
         if need > self.wgrad_ws.numel() or self.dout_rows is None or self.dout_rows.shape[0] < sample.cap + 1:
             torch.cuda.synchronize()               # (re)size scratch that depends on the cloud's capacity
             if need > self.wgrad_ws.numel():
-                self.wgrad_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+                self.wgrad_ws = torch.zeros(need, dtype=torch.uint8, device=self.device)
             self.dout_rows = torch.empty((sample.cap + 1, 64), dtype=torch.float32, device=self.device)
         main = torch.cuda.current_stream()
 
@@ -608,6 +624,7 @@ class LisecNet:
             on_side(concat_leaves)
         layers = self.layers
         branches_left = [len(DECONVS)]
+        batched_convs = set().union(*[names for _, names in self.wgrad_batches.values()]) if self.wgrad_batches else set()
         first_write = set()                    # gradient buffers that already hold a contribution
 
         # ---- RPN blocks, last to first -------------------------------------------------------------
@@ -702,9 +719,15 @@ class LisecNet:
                                     p.grad_view(G, c.bn + ".gamma"), p.grad_view(G, c.bn + ".beta"), d[dst])
                 # the bias of a conv feeding a training-mode BN has gradient sum(dy) == 0 identically (BN removes
                 # the mean); Keras' autograd returns rounding noise there -- the exact 0 stays in self.grad
-                on_side(lambda L=L, c=c, dst=dst: ops.conv_wgrad(
-                    c.g, a[L["src"]], d[dst], p.grad_view(G, c.wname), self.wgrad_ws,
-                    in_bn=self.bnstate[c.in_bn] if c.in_bn else None, flags=ops.IN_RELU if c.in_relu else 0))
+                if L["name"] in batched_convs:
+                    # one launch for the block's stride-1 convolutions, issued when the LAST of their output gradients
+                    # (conv1's: the layers are walked back to front) is final
+                    if L["name"] in self.wgrad_batches:
+                        on_side(lambda batch=self.wgrad_batches[L["name"]][0]: batch.run(self.wgrad_ws))
+                else:
+                    on_side(lambda L=L, c=c, dst=dst: ops.conv_wgrad(
+                        c.g, a[L["src"]], d[dst], p.grad_view(G, c.wname), self.wgrad_ws,
+                        in_bn=self.bnstate[c.in_bn] if c.in_bn else None, flags=ops.IN_RELU if c.in_relu else 0))
                 if is_first_rpn and rpn_grads_ready is not None:
                     lo = p.offsets["rpn1.conv0.kernel"][1]
                     on_side(lambda lo=lo: rpn_grads_ready(lo, p.n_theta), torch_ops=True)

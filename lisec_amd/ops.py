@@ -220,6 +220,28 @@ def wgrad_plan(g, flags=0, dy_bn=False, rows_capacity=0):
     return {n: getattr(plan, n) for n, _ in _lib.WgradPlan._fields_}
 
 
+class WgradBatch:
+    """lisec_conv_wgrad_batched over fixed tensors: items = [(geom, x, dy, dW, in_bn or None, flags, transpose_out), ...]
+    (at most 6).  The stride-1 convolutions of one RPN block share one launch."""
+
+    def __init__(self, items):
+        self.n = len(items)
+        self.keep = items
+        self.arr = (_lib.WgradItem * self.n)()
+        for a, (g, x, dy, dW, in_bn, flags, transpose_out) in zip(self.arr, items):
+            a.g = ctypes.pointer(g)
+            a.in_, a.in_bnstate, a.flags = x.data_ptr(), _lib.ptr(in_bn), flags
+            a.dy, a.transpose_out, a.dW = dy.data_ptr(), 1 if transpose_out else 0, dW.data_ptr()
+
+    def workspace_bytes(self):
+        return _lib.load().lisec_conv_wgrad_batched_workspace_bytes(self.arr, self.n)
+
+    def run(self, workspace):
+        _lib.check(_lib.load().lisec_conv_wgrad_batched(self.arr, self.n, _lib.ptr(workspace),
+                                                        workspace.numel() * workspace.element_size(),
+                                                        _lib.current_stream()))
+
+
 def conv_wgrad(g, x, dy, dW, workspace, in_bn=None, flags=0, transpose_out=False, dy_bn=None, rows=None):
     rc, rn, cap = rows if rows is not None else (None, None, 0)
     _lib.check(_lib.load().lisec_conv_wgrad(ctypes.byref(g), _lib.ptr(x), _lib.ptr(in_bn), flags, _lib.ptr(dy),
@@ -313,6 +335,13 @@ def tap_sums_bn(g, dz, y, bnstate, coef, dy, S, workspace):
     _lib.check(_lib.load().lisec_conv_tap_sums_bn(ctypes.byref(g), _lib.ptr(dz), _lib.ptr(y), _lib.ptr(bnstate),
                                                   _lib.ptr(coef), _lib.ptr(dy), _lib.ptr(S), _lib.ptr(workspace),
                                                   workspace.numel() * workspace.element_size(), _lib.current_stream()))
+
+
+def tap_sums_finish(g, workspace, S):
+    """Second half of tap_sums_bn(..., S=None): the per-line sums left in `workspace` summed into S."""
+    _lib.check(_lib.load().lisec_conv_tap_sums_finish(ctypes.byref(g), _lib.ptr(workspace),
+                                                      workspace.numel() * workspace.element_size(), _lib.ptr(S),
+                                                      _lib.current_stream()))
 
 
 def tap_sums_workspace_bytes(g):

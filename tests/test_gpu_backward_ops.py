@@ -33,7 +33,7 @@ def _wgrad_case(D, H, W, Cin, Cout, k, stride, pad, in_bn, in_relu, seed):
     y.backward(dy)
     Do, Ho, Wo = y.shape[:3]
     geo = ops.geom(0, (D, H, W), (Do, Ho, Wo), k, stride, pad, Cin, Cout)
-    ws = torch.empty(ops.wgrad_workspace_bytes(geo), dtype=torch.uint8, device=DEV)
+    ws = torch.zeros(ops.wgrad_workspace_bytes(geo), dtype=torch.uint8, device=DEV)   # zero-filled once (arrival counters)
     dW = torch.full(w.shape, float("nan"), device=DEV)
     ops.conv_wgrad(geo, x.to(DEV), dy.to(DEV), dW, ws, in_bn=bn, flags=ops.IN_RELU if in_relu else 0)
     _close(dW, w.grad)
@@ -65,7 +65,7 @@ def test_wgrad_and_dgrad_conv2d_transpose(k, s, cin):
     dcat = torch.randn(Ho, Wo, 768, generator=g)
     y.backward(dcat[:, :, 512:])
     geo = ops.geom(1, (1, H, W), (1, Ho, Wo), (1, k, k), (1, s, s), (0, pad, pad), cin, cout, out_stride=768)
-    ws = torch.empty(ops.wgrad_workspace_bytes(geo), dtype=torch.uint8, device=DEV)
+    ws = torch.zeros(ops.wgrad_workspace_bytes(geo), dtype=torch.uint8, device=DEV)   # zero-filled once (arrival counters)
     dW = torch.full(w.shape, float("nan"), device=DEV)
     bn = torch.cat([sc, sh, torch.zeros(2 * cin)]).to(DEV)
     dcat_d = dcat.to(DEV)
@@ -75,7 +75,7 @@ def test_wgrad_and_dgrad_conv2d_transpose(k, s, cin):
     geo_d = ops.geom(0, (1, Ho, Wo), (1, H, W), (1, k, k), (1, s, s), (0, pad, pad), cout, cin, in_stride=768)
     if k == s:
         # kernel == stride: weight gradient with swapped roles (gather dY, contract against relu(bn(x)))
-        ws2 = torch.empty(ops.wgrad_workspace_bytes(geo_d), dtype=torch.uint8, device=DEV)
+        ws2 = torch.zeros(ops.wgrad_workspace_bytes(geo_d), dtype=torch.uint8, device=DEV)
         dW2 = torch.full(w.shape, float("nan"), device=DEV)
         ops.conv_wgrad(geo_d, dcat_d[:, :, 512:], x.detach().to(DEV), dW2, ws2, flags=ops.DY_RELU, dy_bn=bn)
         _close(dW2, w.grad)

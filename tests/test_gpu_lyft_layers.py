@@ -349,3 +349,37 @@ def test_collapsed_branch_contractions():
         torch.cuda.synchronize()
         ref_dx = conv_ref.conv_forward(dy, np.transpose(Wt, (0, 2, 1)), ind, k, s, p, mode=1 - mode if ntaps > 1 else 0)
         assert rel_l2(dx.cpu().numpy(), ref_dx) <= TOL, name + " data gradient"
+
+
+@pytest.mark.parametrize("block", ["rpn3", "rpn2", "rpn1"])
+def test_batched_weight_gradients_of_an_rpn_block(block):
+    """lisec_conv_wgrad_batched: the stride-1 convolutions of one RPN block in ONE launch (slabs summed in-kernel by the last
+    slice of every cell) must give what the one-by-one launches give -- compared against the fp64 reference, each layer."""
+    from lisec_amd import ops
+    from oracle import conv_ref
+    dev = torch.device("cuda")
+    n, hw, ch = {"rpn3": (5, (25, 50), 256), "rpn2": (5, (50, 100), 128), "rpn1": (3, (100, 200), 128)}[block]
+    rng = np.random.default_rng(seed_of("batch" + block))
+    dims = (1, *hw)
+    g = ops.geom(0, dims, dims, (1, 3, 3), (1, 1, 1), (0, 1, 1), ch, ch)
+    items, host = [], []
+    for _ in range(n):
+        x = rng.normal(0, 1, (*dims, ch)).astype(np.float32)
+        dy = rng.normal(0, 1, (*dims, ch)).astype(np.float32)
+        bn_dev, bn_ref = make_bn(rng, ch, dev)
+        dW = torch.full((9, ch, ch), float("nan"), device=dev)
+        items.append((g, torch.from_numpy(x).to(dev), torch.from_numpy(dy).to(dev), dW, bn_dev, ops.IN_RELU, False))
+        host.append((x, dy, bn_ref))
+    batch = ops.WgradBatch(items)
+    ws = torch.zeros(batch.workspace_bytes(), dtype=torch.uint8, device=dev)
+    for rep in range(2):                                   # twice: the arrival counters must come back to zero
+        for it in items:
+            it[3].fill_(float("nan"))
+        batch.run(ws)
+        torch.cuda.synchronize()
+        for i, (x, dy, bn_ref) in enumerate(host):
+            ref = conv_ref.conv_wgrad(x, dy, dims, (1, 3, 3), (1, 1, 1), (0, 1, 1), in_bn=bn_ref, relu=True)
+            e = rel_l2(items[i][3].cpu().numpy(), ref, note=f"batched weight gradient {block} layer {i} run {rep}")
+            assert e <= TOL_W, f"{block} layer {i} run {rep}: relative L2 {e:.2e}"
+    head = ws[:4096 * 4].view(torch.int32)
+    assert int(head.abs().sum().item()) == 0

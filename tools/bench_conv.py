@@ -37,7 +37,7 @@ def run_wgrad(name, mode, ind, outd, k, s, p, cin, cout, iters=10, in_bn=False):
     dy = torch.randn(*outd, cout, device=DEV)
     ntaps = k[0] * k[1] * k[2]
     g = ops.geom(mode, ind, outd, k, s, p, cin, cout)
-    ws = torch.empty(ops.wgrad_workspace_bytes(g), dtype=torch.uint8, device=DEV)
+    ws = torch.zeros(ops.wgrad_workspace_bytes(g), dtype=torch.uint8, device=DEV)
     dW = torch.empty(ntaps, cin, cout, device=DEV)
     bn = torch.randn(4 * cin, device=DEV) if in_bn else None
     fl_ = ops.IN_RELU if in_bn else 0

@@ -22,7 +22,7 @@ torch.cuda.synchronize()
 c = net.layers[0]["conv"]
 sparse = net.params.grad_view(net.grad, c.wname).clone().reshape(27, 64, 64)
 dz = net.dact["mid1.z"]
-ws = torch.empty(ops.wgrad_workspace_bytes(c.g), dtype=torch.uint8, device=dev)
+ws = torch.zeros(ops.wgrad_workspace_bytes(c.g), dtype=torch.uint8, device=dev)
 dense = torch.empty(27, 64, 64, device=dev)
 ops.conv_wgrad(c.g, net.dense_grid(), dz, dense, ws)
 torch.cuda.synchronize()
