@@ -581,10 +581,14 @@ class LisecNet:
                 _lib.pin_stream(pin)
                 del pending[:]
 
+        skip_leaves = _lib.knob("skip_leaves", False)      # measurement aid (WRONG gradients): the chain alone
+
         def on_side(fn, torch_ops=False):
             """Runs fn's launches on the second stream after everything issued so far on the main one.  C-ABI launches
             take the pinned handle; only a fn that also issues torch / torch.distributed work needs torch's (slow)
             stream context."""
+            if skip_leaves and not torch_ops:
+                return
             pending.append((fn, torch_ops))
             flush_side()
 
