@@ -311,6 +311,7 @@ typedef struct lisec_conv_plan {
     int plane_pair;      /* one workgroup per pair of depth planes                                            */
     int parity_classes;  /* rows visited in (h & 1, w & 1) classes (data gradient of a stride-2 Conv2D)       */
     int workgroups, launches;
+    int double_buffered; /* the K-sliced launch runs the two-image kernels, one workgroup per CU              */
 } lisec_conv_plan;
 int lisec_conv_plan_query(const lisec_conv_geom* g, int has_in_bnstate, int flags, const lisec_conv_extras* extras,
                           int has_stats_table, size_t workspace_bytes, int has_row_list, int row_capacity,
@@ -639,6 +640,7 @@ typedef struct lisec_tuning {
     int force_splitk;       /* > 0: every sliceable layer gets exactly this many K slices          (0)         */
     int wgrad_combine_max;  /* weight gradients with at most this many slabs per cell sum them in-kernel (32)   */
     int wgrad_batch_blocks; /* workgroups a batched weight-gradient launch aims for                (1024)      */
+    int lone_db;            /* small K-sliced layers: one workgroup per CU on the two-image kernels (1)         */
 } lisec_tuning;
 int lisec_tuning_get(lisec_tuning* t);        /* fills *t with the current record (t->struct_bytes set)          */
 int lisec_tuning_set(const lisec_tuning* t);  /* t->struct_bytes must be sizeof(lisec_tuning)                    */

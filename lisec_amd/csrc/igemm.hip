@@ -209,7 +209,12 @@ __device__ __forceinline__ void store_tile(const ConvGeom& g, const f32x16& acc0
 
 // NW: columns per workgroup, 64 or 32.  32 (one accumulator per wave, half a W slab) is what a layer of 160-380 tiles
 // runs instead of two K slices + a combine launch: twice the workgroups, every one over the whole K.
-template <int MODE, bool XF, int NW = 64>
+// DB: two LDS images (A tile + W slab each, 102 KB together: one workgroup per CU).  The loads of step s + 2 are in flight
+// and the image of step s + 1 is written while the MFMAs of step s read the other image: ONE barrier per step and nothing
+// between the MFMA runs but the stores' issue slots.  For launches of at most one workgroup per CU (the K-sliced 1 250- and
+// 5 000-position RPN maps), where no second workgroup covers the store -> barrier -> fragment-read sequence of the
+// single-image loop (2.65-2.9 us per step against 1.7 us of MFMA time, tools/rpn_stamps.py).
+template <int MODE, bool XF, int NW = 64, bool DB = false>
 __device__ __forceinline__ void
 igemm_tile(const ConvGeom& g, const float* __restrict__ in, const float* __restrict__ wp,
            const float* __restrict__ bias, const float* __restrict__ in_bn, int flags,
@@ -269,21 +274,21 @@ igemm_tile(const ConvGeom& g, const float* __restrict__ in, const float* __restr
     const int KpQ = ncc * (BK / 4);              // packed K quads per tap
 
     const int pclass = g.pc_span ? m0 / g.pc_span : 0;           // tile-uniform parity class (h & 1) * 2 + (w & 1)
-    auto live = [&](int s) -> bool {
-        if (g.pc_span) {                                         // stride 2 along h and w: only taps of the right parity divide
-            const int tap = s / ncc, kw = tap % g.KW, kh = (tap / g.KW) % g.KH;
-            return (((pclass >> 1) + g.ph - kh) & 1) == 0 && (((pclass & 1) + g.pw - kw) & 1) == 0;
-        }
+    // A K step is (tap, channel slab); the walk over the step list is kept as (kd, kh, kw, cc) counters that advance by
+    // increments -- a lone wave per SIMD pays every scalar instruction of a step in full, and the integer divisions of a
+    // step number (no hardware divide: ~25 instructions each) were half of the non-MFMA work of a step.
+    struct TStep { int s, kd, kh, kw, cc; };
+    auto tap_live = [&](const TStep& t) -> bool {
+        if (g.pc_span)                                           // stride 2 along h and w: only taps of the right parity divide
+            return (((pclass >> 1) + g.ph - t.kh) & 1) == 0 && (((pclass & 1) + g.pw - t.kw) & 1) == 0;
         if (g.row_coords) {
             // row list (voxels sorted by cell, so a tile mostly shares z and its parity): a tap none of whose axis bits
             // is set in ANY row of the tile reads nothing -- conservative (per-axis OR), never skips a live tap
-            const int tap = s / ncc, kw = tap % g.KW, kh = (tap / g.KW) % g.KH, kd = tap / (g.KW * g.KH);
-            const int tb = tap_bits(kd, kh, kw);
+            const int tb = tap_bits(t.kd, t.kh, t.kw);
             return (tile_mask & tb) == tb;
         }
         if (d_first != d_last) return true;
-        const int kd = (s / ncc) / (g.KH * g.KW);
-        return (dmask_first >> kd) & 1;
+        return (dmask_first >> t.kd) & 1;
     };
 
     float4 ra[8];
@@ -291,9 +296,9 @@ igemm_tile(const ConvGeom& g, const float* __restrict__ in, const float* __restr
     float4 tsc = make_float4(1, 1, 1, 1), tsh = make_float4(0, 0, 0, 0);
     unsigned valid_mask = 0;
 
-    auto issue_loads = [&](int s) {
-        const int tap = s / ncc, cc = s - tap * ncc;
-        const int kw = tap % g.KW, kh = (tap / g.KW) % g.KH, kd = tap / (g.KW * g.KH);
+    auto issue_loads = [&](const TStep& t) {
+        const int kd = t.kd, kh = t.kh, kw = t.kw, cc = t.cc;
+        const int tap = (kd * g.KH + kh) * g.KW + kw;
         const int c = cc * BK + piece * 4;
         const bool cok = c < g.Cin;
         const int soff = tap_delta(g, kd, kh, kw, MODE) + cc * BK;     // wave-uniform
@@ -358,32 +363,82 @@ igemm_tile(const ConvGeom& g, const float* __restrict__ in, const float* __restr
     };
 
     f32x16 acc0 = {0}, acc1 = {0};
-    const float* aRow = sA + (wave * 32 + (lane & 31)) * LDA + 4 * (lane >> 5);
-    const float* bCol = sB + ((lane >> 5) * NW + (lane & 31)) * 4;
+    const int aoff = (wave * 32 + (lane & 31)) * LDA + 4 * (lane >> 5), boff = ((lane >> 5) * NW + (lane & 31)) * 4;
+    const float* aRow = sA + aoff;
+    const float* bCol = sB + boff;
 
     // split-K: slice z of the (tap, channel-slab) step list; slices write raw partial tiles
     const int s_end = nsplit > 1 ? (int)(((long long)(blockIdx.z + 1) * nsteps) / nsplit) : nsteps;
     const int s_begin = nsplit > 1 ? (int)(((long long)blockIdx.z * nsteps) / nsplit) : 0;
-    auto advance_to = [&](int s) -> int {
-        while (s < s_end && !live(s)) ++s;
-        return s < s_end ? s : nsteps;
+    auto next_tap = [&](TStep& t) {
+        if (++t.kw == g.KW) {
+            t.kw = 0;
+            if (++t.kh == g.KH) { t.kh = 0; ++t.kd; }
+        }
     };
-    int s = advance_to(s_begin);
+    auto settle = [&](TStep t) -> TStep {           // the first live step at or after t, nsteps when the slice has none left
+        while (t.s < s_end && !tap_live(t)) {        // a dead tap goes with all its channel slabs
+            t.s += ncc - t.cc; t.cc = 0;
+            next_tap(t);
+        }
+        if (t.s >= s_end) t.s = nsteps;
+        return t;
+    };
+    auto next_of = [&](TStep t) -> TStep {
+        ++t.s;
+        if (++t.cc < ncc) {                          // same tap: live
+            if (t.s >= s_end) t.s = nsteps;
+            return t;
+        }
+        t.cc = 0;
+        next_tap(t);
+        return settle(t);
+    };
+    TStep cur;
+    {
+        const int tap = s_begin / ncc, hw = tap / g.KW;          // the only divisions of a step number: once per tile
+        cur.s = s_begin; cur.cc = s_begin - tap * ncc; cur.kw = tap - hw * g.KW; cur.kd = hw / g.KH; cur.kh = hw - cur.kd * g.KH;
+        cur = settle(cur);
+    }
     IGEMM_STAMP(1);
-    if (s < nsteps) {
-        issue_loads(s);
+    TStep nxt = cur;
+    nxt.s = nsteps;
+    if (cur.s < nsteps) {
+        issue_loads(cur);
         store_lds();
+        if (DB) {
+            nxt = next_of(cur);
+            if (nxt.s < nsteps) issue_loads(nxt);
+        }
     }
     __syncthreads();
     IGEMM_STAMP(2);
-    int stamp_steps = 0;
-    while (s < nsteps) {
+    int stamp_steps = 0, img = 0;
+    constexpr int IMG = A_FLOATS + B_FLOATS;
+    while (cur.s < nsteps) {
         ++stamp_steps;
-        const int snext = advance_to(s + 1);
-        if (snext < nsteps) issue_loads(snext);
+        if (DB) {
+            // image of step nxt -> the OTHER image (its loads went out a step ago); then the loads of the step after it
+            sA = smem + (img ^ 1) * IMG; sB = sA + A_FLOATS;
+            TStep nn = nxt;
+            if (nxt.s < nsteps) {
+                store_lds();
+                nn = next_of(nxt);
+                if (nn.s < nsteps) issue_loads(nn);
+            }
+            aRow = smem + img * IMG + aoff; bCol = smem + img * IMG + A_FLOATS + boff;
+            img ^= 1;
+            cur = nxt; nxt = nn;
+        } else {
+            nxt = next_of(cur);
+            if (nxt.s < nsteps) issue_loads(nxt);
+        }
         // software-pipelined fragment reads: the ds_reads of chunk kc+1 are issued BEFORE the 8 MFMAs of chunk kc
         // (sched_barrier pins that order; left alone hipcc reuses the fragment registers and issues the reads
         // after the MFMAs, exposing ~100 cycles of LDS latency per 512 MFMA cycles)
+        // no scalar load may be pending when the fragment reads start: LDS returns in order, scalar memory does not, and with
+        // an s_load in flight (the geometry lives in the kernel-argument segment) the compiler must wait for EVERY LDS read
+        // -- lgkmcnt(0), the reads of the NEXT chunk included -- before each group of MFMAs instead of the older ones only
         float4 a = *reinterpret_cast<const float4*>(aRow);
         float4 b0 = *reinterpret_cast<const float4*>(bCol);
         float4 b1 = NW == 64 ? *reinterpret_cast<const float4*>(bCol + 32 * 4) : b0;
@@ -408,9 +463,11 @@ igemm_tile(const ConvGeom& g, const float* __restrict__ in, const float* __restr
             a = an; b0 = b0n; b1 = b1n;
         }
         __syncthreads();
-        if (snext < nsteps) store_lds();
-        __syncthreads();
-        s = snext;
+        if (!DB) {
+            if (nxt.s < nsteps) store_lds();
+            __syncthreads();
+            cur = nxt;
+        }
     }
     IGEMM_STAMP(3);
     if (stamps && threadIdx.x == 0 && stamp_wg < 8192) stamps[(size_t)stamp_wg * 8 + 5] = (unsigned long long)stamp_steps;
@@ -431,7 +488,7 @@ igemm_tile(const ConvGeom& g, const float* __restrict__ in, const float* __restr
 // parity of the voxels) and the dispatcher waits for the CU whose turn it is, so one workgroup per tile kept 3/4 of the
 // slots empty (84 000 voxels: starts spread over 183 us, 278 us for 82 us of work).  queue[0] = next tile, queue[1] =
 // workgroups that have drawn past the end; the last of those leaves both zero for the next call.
-template <int MODE, bool XF, int TAG = 0, int NW = 64>
+template <int MODE, bool XF, int TAG = 0, int NW = 64, bool DB = false>
 __global__ void __launch_bounds__(kThreads)
 k_igemm(ConvGeom g, const float* __restrict__ in, const float* __restrict__ wp,
         const float* __restrict__ bias, const float* __restrict__ in_bn, int flags,
@@ -441,8 +498,8 @@ k_igemm(ConvGeom g, const float* __restrict__ in, const float* __restrict__ wp,
     const unsigned stamp_wg = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
     IGEMM_STAMP(0);
     // XCD-aware tile order: consecutive M tiles (which share halo rows) stay on one XCD's L2
-    igemm_tile<MODE, XF, NW>(g, in, wp, bias, in_bn, flags, out, stats, nsplit, partial, tile0,
-                             tile0 + xcd_remap(blockIdx.x, gridDim.x), smem, stamps, stamp_wg);
+    igemm_tile<MODE, XF, NW, DB>(g, in, wp, bias, in_bn, flags, out, stats, nsplit, partial, tile0,
+                                 tile0 + xcd_remap(blockIdx.x, gridDim.x), smem, stamps, stamp_wg);
 }
 
 // The same tiles DRAWN from a counter by 768 resident workgroups (a kernel of its own: wrapped in the loop the tile code
@@ -487,7 +544,7 @@ k_igemm_queue(ConvGeom g, const float* __restrict__ in, const float* __restrict_
 constexpr int halo_rows(int nseg) { return BM + 2 * nseg; }     // segments + two halo columns each
 constexpr size_t halo_lds_bytes(int nseg) { return (size_t)(halo_rows(nseg) * LDA + B_FLOATS) * sizeof(float); }   // <= 52 832 B: 3 per CU
 
-template <int MODE, bool XF, int NSEG, int NW = 64>
+template <int MODE, bool XF, int NSEG, int NW = 64, bool DB = false>
 __device__ __forceinline__ void
 halo_tile(const ConvGeom& g, const float* __restrict__ in, const float* __restrict__ wp,
           const float* __restrict__ bias, const float* __restrict__ in_bn, int flags,
@@ -540,23 +597,24 @@ halo_tile(const ConvGeom& g, const float* __restrict__ in, const float* __restri
         const int hin = src_coord(h, kh, g.ls_h, g.ph, g.Hi, MODE, ok);
         return ok ? ((din * g.Hi + hin) * g.Wi) * g.in_stride : -1;
     };
-    auto group_of = [&](int s, int& kd, int& kh, int& cc, int& kw) {
-        kw = s % 3;
-        const int t = s / 3;
-        cc = t % ncc;
-        const int gi = t / ncc;
-        kh = gi % g.KH; kd = gi / g.KH;
-    };
+    // the lines of the tile, once (a line number -> (d, h) is a division)
+    int seg_d[NSEG], seg_h[NSEG];
+    bool seg_ok[NSEG];
+#pragma unroll
+    for (int k = 0; k < NSEG; ++k) {
+        const int L = L0 + k;
+        seg_d[k] = L / g.Ho; seg_h[k] = L - seg_d[k] * g.Ho;
+        seg_ok[k] = k < nseg && L < nlines;
+    }
     auto seg_base = [&](int k, int kd, int kh) -> int {          // source line of segment k, or -1
-        const int L = L0 + k, d = L / g.Ho, h = L - d * g.Ho;
-        return line_base(d, h, kd, kh, k < nseg && L < nlines);
+        return line_base(seg_d[k], seg_h[k], kd, kh, seg_ok[k]);
     };
-    auto live = [&](int s) -> bool {
-        int kd, kh, cc, kw;
-        group_of(s, kd, kh, cc, kw);
+    // A K step is (kd, kh, channel slab, kw); the walk keeps those four as counters (see igemm_tile)
+    struct HStep { int s, kd, kh, cc, kw; };
+    auto group_live = [&](const HStep& t) -> bool {
         bool any = false;
 #pragma unroll
-        for (int k = 0; k < NSEG; ++k) any = any || seg_base(k, kd, kh) >= 0;
+        for (int k = 0; k < NSEG; ++k) any = any || seg_base(k, t.kd, t.kh) >= 0;
         return any;
     };
 
@@ -566,9 +624,8 @@ halo_tile(const ConvGeom& g, const float* __restrict__ in, const float* __restri
     unsigned valid_mask = 0;
     bool staged_a = false;
 
-    auto issue_loads = [&](int s) {
-        int kd, kh, cc, kw;
-        group_of(s, kd, kh, cc, kw);
+    auto issue_loads = [&](const HStep& t) {
+        const int kd = t.kd, kh = t.kh, cc = t.cc, kw = t.kw;
         staged_a = kw == 0;
         if (staged_a) {
             const int c = cc * BK + piece * 4;
@@ -640,31 +697,80 @@ halo_tile(const ConvGeom& g, const float* __restrict__ in, const float* __restri
     f32x16 acc0 = {0}, acc1 = {0};
     const int r_lane = wave * 32 + (lane & 31);
     const int seg_lane = r_lane < a ? 0 : 1 + (r_lane - a) / g.Wo;
-    const float* aLane = sA + (r_lane + 2 * seg_lane) * LDA + 4 * (lane >> 5);
-    const float* bCol = sB + ((lane >> 5) * NW + (lane & 31)) * 4;
+    const int aoff = (r_lane + 2 * seg_lane) * LDA + 4 * (lane >> 5), boff = ((lane >> 5) * NW + (lane & 31)) * 4;
+    const float* aLane = sA + aoff;
+    const float* bCol = sB + boff;
 
     // split-K: slice z of the (kd, kh, channel slab) list -- whole A tiles, three taps each
     const int nstage = ngroups * ncc;
     const int s_end = nsplit > 1 ? 3 * (int)(((long long)(blockIdx.z + 1) * nstage) / nsplit) : nsteps;
     const int s_begin = nsplit > 1 ? 3 * (int)(((long long)blockIdx.z * nstage) / nsplit) : 0;
-    auto advance_to = [&](int s) -> int {
-        while (s < s_end && !live(s)) s += 3 - s % 3;            // a dead (kd, kh) pair: skip its three taps
-        return s < s_end ? s : nsteps;
+    auto next_group = [&](HStep& t) {
+        if (++t.kh == g.KH) { t.kh = 0; ++t.kd; }
     };
-    int s = advance_to(s_begin);
+    auto settle = [&](HStep t) -> HStep {           // the first live step at or after t (t.kw == 0), nsteps when none is left
+        while (t.s < s_end && !group_live(t)) {      // a dead (kd, kh) pair goes with all its slabs and taps
+            t.s += 3 * (ncc - t.cc); t.cc = 0;
+            next_group(t);
+        }
+        if (t.s >= s_end) t.s = nsteps;
+        return t;
+    };
+    auto next_of = [&](HStep t) -> HStep {
+        ++t.s;
+        if (++t.kw < 3) return t;                    // same A tile (slices end on whole tiles)
+        t.kw = 0;
+        if (++t.cc < ncc) {                          // same (kd, kh): live
+            if (t.s >= s_end) t.s = nsteps;
+            return t;
+        }
+        t.cc = 0;
+        next_group(t);
+        return settle(t);
+    };
+    HStep cur;
+    {
+        const int st = s_begin / 3, gi = st / ncc;                // the only divisions of a step number: once per tile
+        cur.s = s_begin; cur.kw = 0; cur.cc = st - gi * ncc; cur.kd = gi / g.KH; cur.kh = gi - cur.kd * g.KH;
+        cur = settle(cur);
+    }
     IGEMM_STAMP(1);
-    if (s < nsteps) {
-        issue_loads(s);
+    HStep nxt = cur;
+    nxt.s = nsteps;
+    bool next_staged = false;                       // DB: the registers hold step nxt, and its A tile is among them
+    if (cur.s < nsteps) {
+        issue_loads(cur);
         store_lds();
+        if (DB) {
+            nxt = next_of(cur);
+            if (nxt.s < nsteps) { issue_loads(nxt); next_staged = staged_a; }
+        }
     }
     __syncthreads();
     IGEMM_STAMP(2);
-    int stamp_steps = 0;
-    while (s < nsteps) {
+    int stamp_steps = 0, imgA = 0, imgW = 0;        // DB: the image holding the current A tile / the current W slab
+    constexpr int IMG = HALO_MAX_ROWS * LDA + B_FLOATS;
+    while (cur.s < nsteps) {
         ++stamp_steps;
-        const int snext = advance_to(s + 1);
-        if (snext < nsteps) issue_loads(snext);
-        const int kw = s % 3;
+        const int kw = cur.kw;
+        if (DB) {
+            // step nxt goes to the other image: its W slab always, its A tile when it opens a new (kd, kh, slab) group
+            // (an A tile serves three steps; the image it leaves was last read a group ago); then the loads of the step after
+            sA = smem + (imgA ^ 1) * IMG; sB = smem + (imgW ^ 1) * IMG + HALO_MAX_ROWS * LDA;
+            aLane = smem + imgA * IMG + aoff; bCol = smem + imgW * IMG + HALO_MAX_ROWS * LDA + boff;
+            HStep nn = nxt;
+            if (nxt.s < nsteps) {
+                store_lds();
+                imgW ^= 1;
+                if (next_staged) imgA ^= 1;
+                nn = next_of(nxt);
+                if (nn.s < nsteps) { issue_loads(nn); next_staged = staged_a; }
+            }
+            cur = nxt; nxt = nn;                    // (only kw, taken above, is read below)
+        } else {
+            nxt = next_of(cur);
+            if (nxt.s < nsteps) issue_loads(nxt);
+        }
         const float* aRow = aLane + (MODE == 0 ? kw : 2 - kw) * LDA;
         float4 av = *reinterpret_cast<const float4*>(aRow);
         float4 b0 = *reinterpret_cast<const float4*>(bCol);
@@ -690,9 +796,11 @@ halo_tile(const ConvGeom& g, const float* __restrict__ in, const float* __restri
             av = an; b0 = b0n; b1 = b1n;
         }
         __syncthreads();
-        if (snext < nsteps) store_lds();
-        __syncthreads();
-        s = snext;
+        if (!DB) {
+            if (nxt.s < nsteps) store_lds();
+            __syncthreads();
+            cur = nxt;
+        }
     }
     IGEMM_STAMP(3);
     if (stamps && threadIdx.x == 0 && stamp_wg < 8192) stamps[(size_t)stamp_wg * 8 + 5] = (unsigned long long)stamp_steps;
@@ -711,7 +819,7 @@ halo_tile(const ConvGeom& g, const float* __restrict__ in, const float* __restri
 // gradient of the second middle block: 9 / 18 / 18 / 9 of 27 per plane); the hardware hands workgroups to the CUs in a
 // fixed rotation and waits for a slot on the CU whose turn it is, so a launch of mixed 9- and 18-step workgroups left
 // 40 % of the slots empty (tools/igemm_stamps.py).  Paired, every workgroup runs 27 steps.
-template <int MODE, bool XF, int TAG = 0, int NSEG = 2, int NW = 64>
+template <int MODE, bool XF, int TAG = 0, int NSEG = 2, int NW = 64, bool DB = false>
 __global__ void __launch_bounds__(kThreads)
 k_igemm_halo(ConvGeom g, const float* __restrict__ in, const float* __restrict__ wp,
              const float* __restrict__ bias, const float* __restrict__ in_bn, int flags,
@@ -721,8 +829,9 @@ k_igemm_halo(ConvGeom g, const float* __restrict__ in, const float* __restrict__
     const unsigned stamp_wg = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
     IGEMM_STAMP(0);
     const int v = tile0 + xcd_remap(blockIdx.x, gridDim.x);
-    if (!g.plane_pair) {
-        halo_tile<MODE, XF, NSEG, NW>(g, in, wp, bias, in_bn, flags, out, stats, nsplit, partial, tile0, v, smem, stamps, stamp_wg);
+    if (DB || !g.plane_pair) {
+        halo_tile<MODE, XF, NSEG, NW, DB>(g, in, wp, bias, in_bn, flags, out, stats, nsplit, partial, tile0, v, smem, stamps,
+                                          stamp_wg);
         return;
     }
     const int q = v / g.plane_tiles, i = v - q * g.plane_tiles;
@@ -1059,6 +1168,7 @@ struct ConvCall {
     int tile0_tail, nsplit;      // first tile of the K-sliced tail (== ntiles: none); slices
     size_t ws_bytes;
     bool xf, halo, halo3, dense64, half_n, roofline;
+    bool db;                     // the K-sliced launch runs the two-image (double-buffered) kernels, one workgroup per CU
     int kernel;                  // KERN_*
     int launch_tiles;            // workgroups along x of an every-tile launch (half the tiles with plane_pair)
     double* stats;               // per-tile table (or the dummy that keeps the statistics paths on under a sink)
@@ -1068,7 +1178,7 @@ struct ConvCall {
 void plan_slices(const ConvGeom& g, ConvCall* p) {
     const lisec_tuning& tn = tuning();
     const int ntiles = cdiv(g.M, BM), nnb = g.CoutP / BN;
-    p->tile0_tail = ntiles; p->nsplit = 1; p->ws_bytes = 0;
+    p->tile0_tail = ntiles; p->nsplit = 1; p->ws_bytes = 0; p->db = false;
     const int nsteps = g.KD * g.KH * g.KW * cdiv(g.Cin, BK);
     if (g.ps || g.Cout % 4 != 0 || g.out_stride % 4 != 0 || nsteps < 6) return;
     const int slots = resident_slots();
@@ -1089,7 +1199,15 @@ void plan_slices(const ConvGeom& g, ConvCall* p) {
     if (ns > nsteps / tn.splitk_min_steps) ns = nsteps / tn.splitk_min_steps;
     if (ns > tn.max_splitk) ns = tn.max_splitk;
     if (tn.force_splitk > 0) ns = tn.force_splitk < nsteps ? tn.force_splitk : nsteps;     // measurement aid
-    if (ns < 2 || ns < tn.min_splitk) return;
+    if (tn.lone_db && tail_tiles == ntiles && blocks < slots / 4 && !g.row_coords) {
+        // a small layer, sliced as a whole: ONE workgroup per CU on the two-image kernels instead of two or three per CU on
+        // the single-image ones -- half the slices (and slabs) for the same number of MFMA steps per CU
+        int nd = (int)((slots / 3) / tail_blocks);
+        if (nd > nsteps / tn.splitk_min_steps) nd = nsteps / tn.splitk_min_steps;
+        if (nd > tn.max_splitk) nd = tn.max_splitk;
+        if (nd >= 2) { ns = nd; p->db = true; }
+    }
+    if (ns < 2 || ns < tn.min_splitk) { p->db = false; return; }
     p->tile0_tail = ntiles - tail_tiles;
     p->nsplit = ns;
     p->ws_bytes = align_up(sizeof(int) * kSplitCounters + sizeof(float) * (size_t)ns * tail_tiles * nnb * BM * BN, 256);
@@ -1135,7 +1253,7 @@ int plan_conv(const lisec_conv_geom* c, bool has_in_bn, int flags, const lisec_c
     }
     plan_slices(g, p);
     const int ntiles = p->ntiles = cdiv(g.M, BM), nnb = p->nnb = g.CoutP / BN;
-    if (!workspace || workspace_bytes < p->ws_bytes) { p->tile0_tail = ntiles; p->nsplit = 1; }
+    if (!workspace || workspace_bytes < p->ws_bytes) { p->tile0_tail = ntiles; p->nsplit = 1; p->db = false; }
     p->roofline = (flags & LISEC_CONV_TAG_ROOFLINE) != 0;
     if (row_coords && extras && extras->queue && nnb == 1 && ntiles >= resident_slots() && !stats_partials && !g.out_mask &&
         !p->roofline) {
@@ -1199,7 +1317,7 @@ int plan_conv(const lisec_conv_geom* c, bool has_in_bn, int flags, const lisec_c
     p->kernel = g.queue ? KERN_QUEUE : (p->halo ? (p->halo3 ? KERN_HALO3 : KERN_HALO2) : KERN_IGEMM);
     // a layer that would run as two K slices (160-380 tiles): 32-column workgroups over the whole K instead -- as many
     // workgroups, no slabs
-    if (tn.half_n && p->nsplit == 2 && p->tile0_tail == 0 && !g.queue) {
+    if (tn.half_n && p->nsplit == 2 && p->tile0_tail == 0 && !g.queue && !p->db) {
         p->half_n = true;
         p->nsplit = 1; p->tile0_tail = ntiles;
         if (sk) g.sink.total = (unsigned)ntiles * (unsigned)cdiv(g.Cout, 32);
@@ -1244,6 +1362,7 @@ extern "C" int lisec_conv_plan_query(const lisec_conv_geom* c, int has_in_bnstat
     out->k_slices = p.nsplit;
     out->plane_pair = p.g.plane_pair;
     out->parity_classes = p.g.pc_span ? 1 : 0;
+    out->double_buffered = p.db && p.nsplit > 1 ? 1 : 0;
     const int ycols = p.half_n ? cdiv(p.g.Cout, 32) : p.nnb;
     int wgs = 0, launches = 0;
     if (p.kernel == KERN_DENSE64 || p.kernel == KERN_QUEUE) { wgs = resident_slots(); launches = 1; }
@@ -1385,7 +1504,23 @@ extern "C" int lisec_conv_forward_ex(const lisec_conv_geom* c, const float* in, 
         LISEC_CHECK_ARG(((uintptr_t)workspace & 15) == 0, "split-K needs a 16-byte aligned workspace");
         float* partial = static_cast<float*>(workspace);
         dim3 grid(ntiles - p.tile0_tail, nnb, p.nsplit);
-        LISEC_IG_ANY(grid, p.nsplit, partial, p.tile0_tail);
+        if (p.db) {
+            // two LDS images per workgroup (one workgroup per CU)
+#define LISEC_DBL(KERNEL_, LDS_) LISEC_LAUNCH(KERNEL_, grid, dim3(kThreads), 2 * (LDS_), st, g, in, packed_w, bias, in_bnstate, \
+        flags, out, stats_partials, p.nsplit, partial, p.tile0_tail)
+#define LISEC_DBL_MX(M_, X_)                                                                           \
+            do {                                                                                       \
+                if (!halo) LISEC_DBL((k_igemm<M_, X_, 0, 64, true>), lds);                             \
+                else if (halo3) LISEC_DBL((k_igemm_halo<M_, X_, 0, 3, 64, true>), lds_halo);           \
+                else LISEC_DBL((k_igemm_halo<M_, X_, 0, 2, 64, true>), lds_halo);                      \
+            } while (0)
+            if (c->mode == 0) { if (xf) LISEC_DBL_MX(0, true); else LISEC_DBL_MX(0, false); }
+            else              { if (xf) LISEC_DBL_MX(1, true); else LISEC_DBL_MX(1, false); }
+#undef LISEC_DBL_MX
+#undef LISEC_DBL
+        } else {
+            LISEC_IG_ANY(grid, p.nsplit, partial, p.tile0_tail);
+        }
     }
 #undef LISEC_IG_ANY
 #undef LISEC_IH

@@ -63,13 +63,13 @@ FORWARD = [
     ("rpn1.conv1", 0, (1, 100, 200), (1, 100, 200), (1, 3, 3), (1, 1, 1), (0, 1, 1), 128, 128, True,
      dict(kernel="halo2", cols=32, k_slices=1, workgroups=628)),
     ("rpn2.conv0", 0, (1, 100, 200), (1, 50, 100), (1, 3, 3), (1, 2, 2), (0, 1, 1), 128, 128, True,
-     dict(kernel="igemm", cols=64, k_slices=6, tail_tile0=0, workgroups=480)),
+     dict(kernel="igemm", cols=64, k_slices=3, tail_tile0=0, workgroups=240, double_buffered=1)),
     ("rpn2.conv1", 0, (1, 50, 100), (1, 50, 100), (1, 3, 3), (1, 1, 1), (0, 1, 1), 128, 128, True,
-     dict(kernel="halo3", cols=64, k_slices=6, tail_tile0=0, workgroups=480)),
+     dict(kernel="halo3", cols=64, k_slices=3, tail_tile0=0, workgroups=240, double_buffered=1)),
     ("rpn3.conv0", 0, (1, 50, 100), (1, 25, 50), (1, 3, 3), (1, 2, 2), (0, 1, 1), 128, 256, True,
-     dict(kernel="igemm", cols=64, k_slices=6, tail_tile0=0, workgroups=240)),
+     dict(kernel="igemm", cols=64, k_slices=6, tail_tile0=0, workgroups=240, double_buffered=1)),
     ("rpn3.conv1", 0, (1, 25, 50), (1, 25, 50), (1, 3, 3), (1, 1, 1), (0, 1, 1), 256, 256, True,
-     dict(kernel="igemm", cols=64, k_slices=12, tail_tile0=0, workgroups=480)),
+     dict(kernel="igemm", cols=64, k_slices=6, tail_tile0=0, workgroups=240, double_buffered=1)),
 ]
 
 
@@ -129,11 +129,11 @@ DGRAD = [
     ("rpn2.conv0", 1, (1, 50, 100), (1, 100, 200), (1, 3, 3), (1, 2, 2), (0, 1, 1), 128, 128, "bn",
      dict(kernel="igemm", parity_classes=1)),
     ("rpn2.conv1", 1, (1, 50, 100), (1, 50, 100), (1, 3, 3), (1, 1, 1), (0, 1, 1), 128, 128, "bn",
-     dict(kernel="halo3", cols=64, k_slices=6, workgroups=480)),
+     dict(kernel="halo3", cols=64, k_slices=3, workgroups=240, double_buffered=1)),
     ("rpn3.conv0", 1, (1, 25, 50), (1, 50, 100), (1, 3, 3), (1, 2, 2), (0, 1, 1), 256, 128, "bn",
      dict(kernel="igemm", parity_classes=1)),
     ("rpn3.conv1", 1, (1, 25, 50), (1, 25, 50), (1, 3, 3), (1, 1, 1), (0, 1, 1), 256, 256, "bn",
-     dict(kernel="igemm", cols=64, k_slices=12, workgroups=480)),
+     dict(kernel="igemm", cols=64, k_slices=6, workgroups=240, double_buffered=1)),
 ]
 
 
