@@ -588,6 +588,7 @@ class LisecNet:
             take the pinned handle; only a fn that also issues torch / torch.distributed work needs torch's (slow)
             stream context."""
             if skip_leaves and not torch_ops:
+                flush_side()
                 return
             pending.append((fn, torch_ops))
             flush_side()
@@ -621,7 +622,10 @@ class LisecNet:
             # collapsed branches + heads: the head gradient feeds the three 16-channel contractions directly; its column
             # sums (the heads' bias gradient, and through H the branch biases) are the only pass over it
             self._dshuffle.run(d["head"], backward=True)
-            on_side(lambda: ops.colsum(d["head"], 16, M, 16, self.head_db, ws_tag="side"))
+            # (queued, not flushed: the leaves and branches that hang off the head gradient cross to the second stream
+            # behind ONE event, with the first of them that is issued through on_side below)
+            if not skip_leaves:
+                pending.append((lambda: ops.colsum(d["head"], 16, M, 16, self.head_db, ws_tag="side"), False))
         else:
             on_side(head_leaves)
             ops.conv_forward(self.head_dgeom, d["head"], self.packed_t["head"][0], d["concat"])
@@ -693,13 +697,15 @@ class LisecNet:
         if self.branch_overlap:
             for L in layers:
                 if L["kind"] == "deconv" and L["slot"] < len(DECONVS) - 1:
-                    def branch(L=L):
+                    ev = self._event("bwd_branch%d" % L["slot"])
+
+                    def branch(L=L, ev=ev):
                         deconv_wgrad(L)
                         dgrad_into(L["conv"], branch_dy(L), L["src"], ws_tag="side")
-                    on_side(branch)
-                    flush_side()
-                    ev = self._event("bwd_branch%d" % L["slot"])
-                    self._record(ev, self.side)
+                        self._record(ev, self.side)
+                    pending.append((branch, False))
+                    if not self.compose_head:
+                        flush_side()
                     early_dst[L["src"]] = ev
                     early_layers.add(L["name"])
 
