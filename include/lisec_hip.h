@@ -641,6 +641,8 @@ typedef struct lisec_tuning {
     int wgrad_combine_max;  /* weight gradients with at most this many slabs per cell sum them in-kernel (32)   */
     int wgrad_batch_blocks; /* workgroups a batched weight-gradient launch aims for                (1024)      */
     int lone_db;            /* small K-sliced layers: one workgroup per CU on the two-image kernels (1)         */
+    int wgrad_per_cu;       /* weight-gradient workgroups per CU: 2 leaves 53 KB of LDS for a workgroup of the   */
+                            /* data-gradient chain on the other stream (default), 3 = as many as fit            */
 } lisec_tuning;
 int lisec_tuning_get(lisec_tuning* t);        /* fills *t with the current record (t->struct_bytes set)          */
 int lisec_tuning_set(const lisec_tuning* t);  /* t->struct_bytes must be sizeof(lisec_tuning)                    */

@@ -55,7 +55,7 @@ class WgradPlan(Structure):                    # lisec_wgrad_plan
 class Tuning(Structure):                       # lisec_tuning
     _fields_ = [(n, c_int) for n in ("struct_bytes", "max_splitk", "splitk_min_steps", "min_splitk", "plane_pair", "dense64",
                                      "half_n", "vfe_shape", "field_seg", "field_tpw", "wgrad_blocks", "debug_sync",
-                                     "force_splitk", "wgrad_combine_max", "wgrad_batch_blocks", "lone_db")]
+                                     "force_splitk", "wgrad_combine_max", "wgrad_batch_blocks", "lone_db", "wgrad_per_cu")]
 
 
 KERNEL_NAMES = {0: "igemm", 1: "halo2", 2: "halo3", 3: "dense64", 4: "queue"}

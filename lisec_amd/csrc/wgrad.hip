@@ -454,7 +454,9 @@ wgrad_halo_body(const WgradItem& it, const int bx, const int by, const int bz, f
         // last slice to arrive adds the slabs in slice order (deterministic) and writes the finished gradient -- no slab-sum
         // launch.  Used when a cell has few slices (the RPN maps); many slices (the middle layers) keep the slab-sum kernel.
         typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-        __shared__ int wg_last;
+        // (in the dynamic LDS, free by now: a static word on top of LT = 100's 53 760 B rounds the allocation past a third
+        // of the CU's 160 KB and the kernel drops from three to two workgroups per CU)
+        volatile int* wg_last_p = reinterpret_cast<volatile int*>(smem);
         const int ncell = ngroups * it.gy * it.gz, cell = (gslot * it.gy + by) * it.gz + bz;
         __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(partial, 0, (int)((size_t)it.nsplit * ncell * kWSlabF4 * 16),
                                                                       0x00020000);
@@ -471,9 +473,9 @@ wgrad_halo_body(const WgradItem& it, const int bx, const int by, const int bz, f
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (threadIdx.x == 0)
-            wg_last = __hip_atomic_fetch_add(it.counters + cell, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == it.nsplit - 1;
+            *wg_last_p = __hip_atomic_fetch_add(it.counters + cell, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == it.nsplit - 1;
         __syncthreads();
-        if (!wg_last) { WGRAD_STAMP(3); return; }
+        if (!*wg_last_p) { WGRAD_STAMP(3); return; }
         if (threadIdx.x == 0) __hip_atomic_store(it.counters + cell, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         f32x16 s0 = {0}, s1 = {0}, s2 = {0};
         const unsigned zstride = (unsigned)((size_t)ncell * kWSlabF4 * 16);
@@ -791,7 +793,17 @@ void place_workspace(HaloCall* hc, void* workspace, int counter0, size_t slab_of
     hc->it.partial = reinterpret_cast<float*>(static_cast<char*>(workspace) + sizeof(int) * kWgradCounters + slab_off);
 }
 
-size_t halo_lds(const HaloCall& hc) { const int DR = (hc.p.LT + 7) & ~7; return (size_t)(2 * DR + 2) * BC * sizeof(float); }
+// LDS of a halo workgroup.  At LT = 100 that is 53 760 B and three fit a CU's 160 KB exactly -- which starves the
+// data-gradient chain running beside the weight gradients on the other stream of its 51 KB (measured in the step: 227.7
+// samples/s with three per CU against 232 with two; alone the three-per-CU launch is 5 % faster).  tuning().wgrad_per_cu
+// == 2 (default) therefore asks for just over a third of the CU.
+size_t halo_lds(const HaloCall& hc) {
+    const int DR = (hc.p.LT + 7) & ~7;
+    size_t lds = (size_t)(2 * DR + 2) * BC * sizeof(float);
+    const size_t third = 160 * 1024 / 3 + 1024;
+    if (tuning().wgrad_per_cu == 2 && lds < third) lds = third;
+    return lds;
+}
 
 int launch_slab_sum(const ConvGeom& g, const WgradPlan& p, const float* partial, int transpose_out, float* dW,
                     unsigned long long dead_taps, hipStream_t st) {
