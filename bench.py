@@ -333,7 +333,7 @@ def main():
         dz2, du1 = net.dact["mid2.z"], net.dact["mid1.u"]
 
         def run_mid2_dgrad():
-            # TAG_ROOFLINE: one un-sliced launch under its own symbol (k_igemm_halo<1,false,1,2,64>), so the row of that
+            # TAG_ROOFLINE: one un-sliced launch under its own symbol (k_igemm_halo<1,false,1,2,64,false>), so the row of that
             # symbol in the rocprofv3 --stats summary of this command is this layer alone
             ops.conv_forward(dg2, dz2, net.packed_t[c2.name][0], du1, flags=ops.TAG_ROOFLINE)
         ms = event_time_ms(run_mid2_dgrad, 20)
@@ -344,7 +344,7 @@ def main():
         # fall outside are skipped per tile), so executed == algorithmic here
         flops = 2.0 * c2.M * 27 * 64 * 64
         tf = flops / (ms * 1e-3) / 1e12
-        roofline = dict(bound="mfma", kernel="k_igemm_halo<1,false,1,2,64> mid2 Conv3D 64->64 k3 s1 data gradient", achieved=tf,
+        roofline = dict(bound="mfma", kernel="k_igemm_halo<1,false,1,2,64,false> mid2 Conv3D 64->64 k3 s1 data gradient", achieved=tf,
                         peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s", frac=tf / PEAK_F32_MFMA_TFLOPS,
                         frac_executed=tf / PEAK_F32_MFMA_TFLOPS, executed_share=1.0,
                         clock_ghz=pmc.get("clock_ghz"), clock_note="GRBM_GUI_ACTIVE/8/duration, " + pmc_src,

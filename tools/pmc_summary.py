@@ -45,7 +45,7 @@ for d in args:
                         dom.setdefault("__dur_by_pass", {})[os.path.basename(d)] = dom[c]
 if dominant_out:
     import json
-    out = {"kernel": "k_igemm_halo<1,false,1,2,64> (mid2 Conv3D data gradient, bench.py's roofline launch)",
+    out = {"kernel": "k_igemm_halo<1,false,1,2,64,false> (mid2 Conv3D data gradient, bench.py's roofline launch)",
            "source": "rocprofv3 --pmc passes of `python bench.py --steps 3 --warmup 2 --no-cpu-baseline`, one counter set per pass "
                      "(tools/profile_round.sh), summarised by tools/pmc_summary.py"}
     if "FETCH_SIZE" in dom and "WRITE_SIZE" in dom:
