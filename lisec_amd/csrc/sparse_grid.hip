@@ -70,46 +70,58 @@ k_line_sums(ConvGeom g, const float* dy, float* __restrict__ line_s, const float
     }
 }
 
-// S[tap][c] = sum over the lines (d', h') for which (kd, kh) read inside the grid (fixed order, fp64):
-// 16 line groups x 64 channels per block, loads batched 4 deep (a line outside the tap's range counts as 0)
-constexpr int kTapLanes = 16;
-__global__ void __launch_bounds__(1024)
+// S[tap][c] = sum over the lines (d', h') for which (kd, kh) read inside the grid, in fp64 and in a FIXED order: lane group
+// lg of 16 adds lines lg, lg + 16, ... one after the other, then the 16 partial sums are added in index order (the order
+// this kernel has always used -- results are bit-identical to the 27-workgroup form it replaces).
+// One workgroup per (tap, 16 channels): 16 lane groups x 16 channels, up to 64 loads in flight per thread, the (d, h) of a line
+// advanced by increments (a division per line was most of the kernel's instructions).
+constexpr int kTapLanes = 16, kTapCh = 16, kTapDepth = 64;
+__global__ void __launch_bounds__(kTapLanes * kTapCh)
 k_tap_sums(ConvGeom g, const float* __restrict__ line_s, float* __restrict__ S) {
-    __shared__ double red[kTapLanes][64];
+    __shared__ double red[kTapLanes][kTapCh];
     const int C = g.Cout;
     const int tap = blockIdx.x, kw = tap % g.KW, kh = (tap / g.KW) % g.KH, kd = tap / (g.KW * g.KH);
     const int nlines = g.Do * g.Ho;
-    const int cl = threadIdx.x & 63, lg = threadIdx.x >> 6;
-    auto inside = [&](int line) -> bool {
-        const int d = line / g.Ho, h = line - d * g.Ho;
-        const int bd = (d << g.ls_d) - g.pd + kd, bh = (h << g.ls_h) - g.ph + kh;
-        return bd >= 0 && bd < g.Di && bh >= 0 && bh < g.Hi;
-    };
-    for (int c0 = 0; c0 < C; c0 += 64) {
-        const int c = c0 + cl;
-        double a = 0.0;
-        if (c < C) {
-            const float* src = line_s + (size_t)kw * C + c;
-            const size_t ld = (size_t)g.KW * C;
-            int line = lg;
-            for (; line + 3 * kTapLanes < nlines; line += 4 * kTapLanes) {
-                float v[4];
+    const int cl = threadIdx.x % kTapCh, lg = threadIdx.x / kTapCh;
+    const int c = blockIdx.y * kTapCh + cl;
+    double a = 0.0;
+    if (c < C) {
+        const float* src = line_s + (size_t)kw * C + c;
+        const size_t ld = (size_t)g.KW * C;
+        int d = lg / g.Ho, h = lg - d * g.Ho;                    // line = lg, then + kTapLanes per step
+        const int dstep = kTapLanes / g.Ho, hstep = kTapLanes - dstep * g.Ho;
+        auto inside = [&]() -> bool {
+            const int bd = (d << g.ls_d) - g.pd + kd, bh = (h << g.ls_h) - g.ph + kh;
+            return bd >= 0 && bd < g.Di && bh >= 0 && bh < g.Hi;
+        };
+        auto advance = [&]() {
+            d += dstep; h += hstep;
+            if (h >= g.Ho) { h -= g.Ho; ++d; }
+        };
+        // every load of a pass is issued before the first add: ONE memory round trip for the 800 lines of the Lyft grid (the
+        // kernel runs beside a weight gradient that keeps HBM busy; each dependent round trip costs microseconds there)
+        for (int line = lg; line < nlines; line += kTapDepth * kTapLanes) {
+            float v[kTapDepth];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) v[u] = src[(size_t)(line + u * kTapLanes) * ld];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) a += inside(line + u * kTapLanes) ? (double)v[u] : 0.0;
+            for (int u = 0; u < kTapDepth; ++u) {
+                const int l = line + u * kTapLanes;
+                v[u] = src[(size_t)(l < nlines ? l : nlines - 1) * ld];      // (unconditional: clamped, not predicated)
             }
-            for (; line < nlines; line += kTapLanes)
-                if (inside(line)) a += (double)src[(size_t)line * ld];
+#pragma unroll
+            for (int u = 0; u < kTapDepth; ++u) {
+                if (line + u * kTapLanes < nlines) {
+                    a += inside() ? (double)v[u] : 0.0;
+                    advance();
+                }
+            }
         }
-        red[lg][cl] = a;
-        __syncthreads();
-        if (lg == 0 && c < C) {
-            double t = red[0][cl];
-            for (int l = 1; l < kTapLanes; ++l) t += red[l][cl];
-            S[(size_t)tap * C + c] = (float)t;
-        }
-        __syncthreads();
+    }
+    red[lg][cl] = a;
+    __syncthreads();
+    if (lg == 0 && c < C) {
+        double t = red[0][cl];
+        for (int l = 1; l < kTapLanes; ++l) t += red[l][cl];
+        S[(size_t)tap * C + c] = (float)t;
     }
 }
 
@@ -185,7 +197,7 @@ extern "C" int lisec_conv_tap_sums_bn(const lisec_conv_geom* c, const float* dz,
     else
         LISEC_LAUNCH(k_line_sums<false>, dim3(g.Do * g.Ho), dim3(256), 0, st, g, dz, line_s, (const float*)nullptr,
                            (const float*)nullptr, (const float*)nullptr, (float*)nullptr);
-    if (S) LISEC_LAUNCH(k_tap_sums, dim3(g.KD * g.KH * g.KW), dim3(1024), 0, st, g, line_s, S);
+    if (S) LISEC_LAUNCH(k_tap_sums, dim3(g.KD * g.KH * g.KW, cdiv(g.Cout, kTapCh)), dim3(kTapLanes * kTapCh), 0, st, g, line_s, S);
     LISEC_LAUNCH_CHECK();
     return LISEC_OK;
 }
@@ -196,8 +208,8 @@ extern "C" int lisec_conv_tap_sums_finish(const lisec_conv_geom* c, const void* 
     if (int rc = conv_geom_check(c, &g)) return rc;
     LISEC_CHECK_ARG(c->mode == 0 && S && workspace && workspace_bytes >= lisec_conv_tap_sums_workspace_bytes(c),
                     "tap sums: mode-0 geometry, S and the line-sum workspace of lisec_conv_tap_sums_bn");
-    LISEC_LAUNCH(k_tap_sums, dim3(g.KD * g.KH * g.KW), dim3(1024), 0, static_cast<hipStream_t>(stream_), g,
-                 static_cast<const float*>(workspace), S);
+    LISEC_LAUNCH(k_tap_sums, dim3(g.KD * g.KH * g.KW, cdiv(g.Cout, kTapCh)), dim3(kTapLanes * kTapCh), 0,
+                 static_cast<hipStream_t>(stream_), g, static_cast<const float*>(workspace), S);
     LISEC_LAUNCH_CHECK();
     return LISEC_OK;
 }
