@@ -36,6 +36,11 @@ int launch_bn_fold(const float* gamma, const float* beta, const float* moving_me
 int launch_reduce_parts(const double* parts, int nparts, int C, double scale, float* out_f, double* out_d,
                         hipStream_t st);
 
+// launch_reduce_parts(rparts -> out_f) and launch_bn_bwd_finalize(parts -> dgamma, dbeta, coef) in ONE launch
+int launch_reduce_and_bwd_finalize(const double* rparts, int rnparts, int rC, double scale, float* out_f,
+                                   const double* parts, int nparts, int C, double N, float* dgamma, float* dbeta,
+                                   float* coef, hipStream_t st);
+
 // BN backward finalisation: parts double[nparts][2][C] = (sum dz, sum dz*yhat) ->
 // dbeta, dgamma (fp32 gradients) and coef float[2][C] = (mean dz, mean dz*yhat) over N dense rows
 int launch_bn_bwd_finalize(const double* parts, int nparts, int C, double N, float* dgamma, float* dbeta,

@@ -119,7 +119,45 @@ k_bn_bwd_finalize(const double* __restrict__ parts, int nparts, int C, double N,
     coef[C + c] = (float)(s2 / N);      // mean(dz * yhat)
 }
 
+// k_reduce_parts and k_bn_bwd_finalize of ONE producer in one launch (they read different partial tables of the same
+// kernel and nothing of each other): blocks [0, nb_red) run the first, the rest the second -- the same blocks, the same
+// summation order, one dependent launch less on the VFE backward's chain of small kernels.
+__global__ void __launch_bounds__(1024)
+k_reduce_and_bwd_finalize(const double* __restrict__ rparts, int rnparts, int rC, double scale, float* __restrict__ out_f,
+                          int nb_red, const double* __restrict__ parts, int nparts, int C, double N,
+                          float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ coef) {
+    __shared__ double red[2 * kRedRows][kRedCols];
+    if ((int)blockIdx.x < nb_red) {
+        const int c = blockIdx.x * kRedCols + threadIdx.x % kRedCols;
+        const bool ok = c < rC;
+        double s, unused;
+        column_sum2(rparts, rnparts, (size_t)rC, c, 0, false, ok, red, s, unused);
+        if (!ok || threadIdx.x >= kRedCols) return;
+        out_f[c] = (float)(s * scale);
+        return;
+    }
+    const int c = (blockIdx.x - nb_red) * kRedCols + threadIdx.x % kRedCols;
+    const bool ok = c < C;
+    double s1, s2;
+    column_sum2(parts, nparts, (size_t)2 * C, c, (size_t)C, true, ok, red, s1, s2);
+    if (!ok || threadIdx.x >= kRedCols) return;
+    dbeta[c] = (float)s1;
+    dgamma[c] = (float)s2;
+    coef[c] = (float)(s1 / N);
+    coef[C + c] = (float)(s2 / N);
+}
+
 }  // namespace
+
+int launch_reduce_and_bwd_finalize(const double* rparts, int rnparts, int rC, double scale, float* out_f,
+                                   const double* parts, int nparts, int C, double N, float* dgamma, float* dbeta,
+                                   float* coef, hipStream_t st) {
+    const int nb_red = cdiv(rC, kRedCols);
+    LISEC_LAUNCH(k_reduce_and_bwd_finalize, dim3(nb_red + cdiv(C, kRedCols)), dim3(1024), 0, st, rparts, rnparts, rC, scale,
+                 out_f, nb_red, parts, nparts, C, N, dgamma, dbeta, coef);
+    LISEC_LAUNCH_CHECK();
+    return 0;
+}
 
 int launch_bn_bwd_finalize(const double* parts, int nparts, int C, double N, float* dgamma, float* dbeta,
                            float* coef, hipStream_t st) {

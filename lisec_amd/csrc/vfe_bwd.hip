@@ -860,38 +860,40 @@ extern "C" int lisec_vfe_backward(const lisec_vfe_params* p, const int32_t* info
                            sv.bn2, sv.bn3, ws.coef, sv.y2rows, ws.dout, ws.gh, ws.parts_dw);
         LISEC_LAUNCH_CHECK();
         LISEC_DBG("k_bwd_tile<3>");
-        if (int rc = launch_reduce_parts(ws.parts_dw, kTileBlocks, 64 * 64, 1.0, g->kernel[2], nullptr, st)) return rc;
         LISEC_LAUNCH(k_post<3>, dim3(vblocks), dim3(256), 0, st, in, p->kernel[0], sv.bn2, ws.aw2, sv.y2rows,
                            ws.gh, ws.gz2, ws.parts_a);
         LISEC_LAUNCH_CHECK();
         LISEC_DBG("k_post<3>");
-        if (int rc = launch_bn_bwd_finalize(ws.parts_a, vblocks, 32, N, g->gamma[1], g->beta[1], ws.coef, st)) return rc;
+        // (the tile kernel's weight-gradient partials and k_post's BatchNormalization partials: one launch)
+        if (int rc = launch_reduce_and_bwd_finalize(ws.parts_dw, kTileBlocks, 64 * 64, 1.0, g->kernel[2], ws.parts_a, vblocks, 32,
+                                                    N, g->gamma[1], g->beta[1], ws.coef, st)) return rc;
         const size_t ldsT2 = (size_t)(4 * 2 * 32 * kLdT + 2 * 32 * 32 + 6 * 32 + 2 * 16 + 96) * sizeof(float);
         LISEC_LAUNCH(k_bwd_tile<2>, dim3(kTileBlocks), dim3(256), ldsT2, st, in, cx, p->kernel[1], p->kernel[0],
                            sv.bn1, sv.bn2, ws.coef, sv.y2rows, ws.gz2, ws.gh, ws.parts_dw);
         LISEC_LAUNCH_CHECK();
         LISEC_DBG("k_bwd_tile<2>");
-        if (int rc = launch_reduce_parts(ws.parts_dw, kTileBlocks, 32 * 32, 1.0, g->kernel[1], nullptr, st)) return rc;
         LISEC_LAUNCH(k_post<2>, dim3(vblocks), dim3(256), 0, st, in, p->kernel[0], sv.bn1, ws.aw1, sv.y2rows,
                            ws.gh, ws.gz1, ws.parts_a);
         LISEC_LAUNCH_CHECK();
         LISEC_DBG("k_post<2>");
-        if (int rc = launch_bn_bwd_finalize(ws.parts_a, vblocks, 16, N, g->gamma[0], g->beta[0], ws.coef, st)) return rc;
+        if (int rc = launch_reduce_and_bwd_finalize(ws.parts_dw, kTileBlocks, 32 * 32, 1.0, g->kernel[1], ws.parts_a, vblocks, 16,
+                                                    N, g->gamma[0], g->beta[0], ws.coef, st)) return rc;
     } else {
         size_t lds3 = (size_t)(4 * 2 * kMaxRows * 32 + 64 * 64) * sizeof(float);
         LISEC_LAUNCH(k_l3, dim3(kL3Blocks), dim3(256), lds3, st, in, p->kernel[0], p->kernel[1], p->kernel[2],
                            sv.bn1, sv.bn2, sv.bn3, ws.coef, sv.ymm1, sv.ymm2, sv.ymm3, ws.dout, ws.gz2, ws.parts_dw,
                            ws.parts_a);
         LISEC_LAUNCH_CHECK();
-        if (int rc = launch_reduce_parts(ws.parts_dw, kL3Blocks, 64 * 64, 1.0, g->kernel[2], nullptr, st)) return rc;
-        if (int rc = launch_bn_bwd_finalize(ws.parts_a, kL3Blocks, 32, N, g->gamma[1], g->beta[1], ws.coef, st)) return rc;
+        // (weight-gradient partial sums and the BatchNormalization finaliser of the same producer: one launch)
+        if (int rc = launch_reduce_and_bwd_finalize(ws.parts_dw, kL3Blocks, 64 * 64, 1.0, g->kernel[2], ws.parts_a, kL3Blocks,
+                                                    32, N, g->gamma[1], g->beta[1], ws.coef, st)) return rc;
         // 3. layer 2
         size_t lds2 = (size_t)(4 * 2 * kMaxRows * 16 + 32 * 32) * sizeof(float);
         LISEC_LAUNCH(k_l2, dim3(kBwdBlocks), dim3(256), lds2, st, in, p->kernel[0], p->kernel[1], sv.bn1, sv.bn2,
                            ws.coef, sv.ymm1, ws.gz2, ws.gz1, ws.parts_dw, ws.parts_a);
         LISEC_LAUNCH_CHECK();
-        if (int rc = launch_reduce_parts(ws.parts_dw, kBwdBlocks, 32 * 32, 1.0, g->kernel[1], nullptr, st)) return rc;
-        if (int rc = launch_bn_bwd_finalize(ws.parts_a, kBwdBlocks, 16, N, g->gamma[0], g->beta[0], ws.coef, st)) return rc;
+        if (int rc = launch_reduce_and_bwd_finalize(ws.parts_dw, kBwdBlocks, 32 * 32, 1.0, g->kernel[1], ws.parts_a, kBwdBlocks,
+                                                    16, N, g->gamma[0], g->beta[0], ws.coef, st)) return rc;
     }
     // 4. layer 1
     LISEC_LAUNCH(k_l1, dim3(kBwdBlocks), dim3(256), 0, st, in, p->kernel[0], sv.bn1, ws.coef, ws.gz1,
