@@ -293,7 +293,17 @@ def main():
     from lisec_amd import _lib
     use_plan = dp is None and _lib.knob("step_plan", True)
 
-    if use_plan:
+    if use_plan and _lib.knob("pipeline_voxels", True):
+        # ... with the NEXT sweep's voxelisation inside the step (second stream, under the backward pass): every step still
+        # voxelises one sweep and trains on one
+        from lisec_amd.network import PipelinedStep
+        captured = PipelinedStep(net, vox, len(cloud), dtype=pts.dtype, loss=args.loss)
+        captured.prime(pts, ycls, yreg)         # inputs resident in HBM before the timed region, as in the eager path
+        captured.stage_next(pts, ycls, yreg)
+        captured.step()
+        captured.stage_next(pts, ycls, yreg)    # both buffer sets hold the sweep
+        step = captured.step
+    elif use_plan:
         from lisec_amd.network import RecordedStep
         captured = RecordedStep(net, vox, len(cloud), dtype=pts.dtype, loss=args.loss)
         captured.load(pts, ycls, yreg)          # inputs resident in HBM before the timed region, as in the eager path

@@ -325,7 +325,16 @@ class Model:
             for st in range(steps):
                 i = int(order[st % len(order)])
                 yc, yr = target(i)
-                if captured is not None:
+                if captured is not None and hasattr(captured, "prime"):
+                    # ... pipelined: this step also voxelises the sweep of the next one (second stream, under the backward)
+                    if st == 0:
+                        captured.prime(samples[i]._keepalive, yc, yr)
+                    if st + 1 < steps:
+                        j = int(order[(st + 1) % len(order)])
+                        captured.step(samples[j]._keepalive, *target(j))
+                    else:
+                        captured.step()               # (the next epoch draws its own order and primes its first sweep)
+                elif captured is not None:
                     # the whole step (voxelise + forward + backward + update) re-issued from its recorded plan: one C call
                     captured(samples[i]._keepalive, yc, yr)
                 else:
@@ -372,9 +381,9 @@ class Model:
             return cur[1]
         if cur is not None:
             cur[1].close()                    # another grid / optimizer / network: the old plan points at dead buffers
-        from .network import RecordedStep
+        from .network import RecordedStep, PipelinedStep
         capacity = max(1024, -(-need // 4096) * 4096)        # a little head-room: later fits reuse the plan
-        step = RecordedStep(self.net, Voxelizer(*key0[:3], key0[3], *key0[4:], device=self.net.device), capacity,
+        step = (PipelinedStep if _lib.knob("pipeline_voxels", True) else RecordedStep)(self.net, Voxelizer(*key0[:3], key0[3], *key0[4:], device=self.net.device), capacity,
                             dtype=dtype, loss=self.loss, lr=o.lr, decay=o.decay, momentum=o.momentum)
         self._captured = (key, step)
         return step

@@ -197,9 +197,11 @@ class LisecNet:
         self._iter_dev.copy_(torch.tensor([int(k), 0], dtype=torch.int64))
 
     # ------------------------------------------------------------------------------------------------
-    def _pack_all(self):
+    def _pack_all(self, after_main=None):
         """Repack theta into the kernels' [tap][K/4][N][4] layout (after every optimizer step)."""
         if self._packed_version == (self.params_version, self.params.version):
+            if after_main is not None:
+                after_main()
             return
         p = self.params
         if getattr(self, "_head_merge", None) is None:     # Keras-shaped head variables -> the merged (768,16) layout
@@ -208,18 +210,26 @@ class LisecNet:
                                               (p.view("cls.bias"), self.head_b[:2]),
                                               (p.view("reg.bias"), self.head_b[2:])], self.device)
         self._head_merge.run()
-        if self.compose_head:
-            self._compose_all()
         if getattr(self, "_pack_table", None) is None:
-            entries = []
+            entries, late = [], []
             for L in self.layers:
                 for key in ("conv", "dense"):
                     if key in L:
                         c = L[key]
-                        src = p.view(c.wname) if c.wname else L["Wc"]
-                        entries.append((src, self.packed[c.name]) + tuple(c.pack))
+                        (entries if c.wname else late).append(
+                            ((p.view(c.wname) if c.wname else L["Wc"]), self.packed[c.name]) + tuple(c.pack))
             self._pack_table = ops.PackTable(entries, self.device)
+            self._pack_table_wc = ops.PackTable(late, self.device) if late else None
+        # the kernels that are variables first: the first contraction of the forward pass waits for these only
+        # (after_main records that point when the repack runs early on the second stream); the composite kernels of the
+        # collapsed heads -- three compose launches in front of their pack -- are not read before the first branch
         self._pack_table.run()
+        if after_main is not None:
+            after_main()
+        if self.compose_head:
+            self._compose_all()
+        if self._pack_table_wc is not None:
+            self._pack_table_wc.run()
         if not self.compose_head:
             ops.pack_weights(self.head_w, 1, 768, 16, 0, 16, 1, out=self.packed["head"])
         self._packed_version = (self.params_version, self.params.version)
@@ -309,8 +319,9 @@ class LisecNet:
     def _forward(self, sample, training):
         pending = getattr(self, "_pack_pending", False)
         if pending and (self._packed_version != (self.params_version, self.params.version)):
-            self._wait(self._pack_done, torch.cuda.current_stream())     # variables changed since the early repack
+            self._wait(self._pack_late, torch.cuda.current_stream())     # variables changed since the early repack
             self._pack_pending = pending = False
+            self._late_pending = False
         if not pending:
             self._pack_all()
         a = self.act
@@ -360,6 +371,11 @@ class LisecNet:
                 else:
                     def run(ws_tag, L=L, b=b):
                         self._run_conv(L["conv"], a[L["src"]], a["concat"][:, :, 256 * b:], training, ws_tag=ws_tag)
+                if getattr(self, "_late_pending", False) and not (self.branch_overlap and b < len(DECONVS) - 1):
+                    # first reader on THIS stream of a kernel repacked late on the second one (composite kernels, and the
+                    # transposed set the backward reads)
+                    self._wait(self._pack_late, torch.cuda.current_stream())
+                    self._late_pending = False
                 if self.branch_overlap and b < len(DECONVS) - 1:
                     # an upsampling branch that is not the last: beside the next block, on the second stream
                     main = torch.cuda.current_stream()
@@ -374,6 +390,9 @@ class LisecNet:
                     side_used = True
                 else:
                     run("main")
+        if getattr(self, "_late_pending", False):
+            self._wait(self._pack_late, torch.cuda.current_stream())
+            self._late_pending = False
         if side_used:
             join = self._event("fwd_join")
             self._record(join, self.side)
@@ -525,19 +544,22 @@ class LisecNet:
         self._pack_table_t.run()
         self._packed_t_version = (self.params_version, self.params.version)
 
-    def backward(self, y_cls, y_reg, loss="mse", grad_scale=1.0, rpn_grads_ready=None):
+    def backward(self, y_cls, y_reg, loss="mse", grad_scale=1.0, rpn_grads_ready=None, side_filler=None):
         """y_cls (Ho,Wo,2), y_reg (Ho,Wo,14): float32 device tensors.  Fills self.grad (layout of theta)
         and self.loss_out = [total, class, regression].  Must follow forward(training=True).
+        side_filler: optional callable issued on the second stream behind the head-phase leaves, where that stream has
+        nothing to do for ~200 us (the weight gradients of the last RPN block wait for its chain): independent work such as
+        the NEXT sweep's voxelisation (PipelinedStep).
         rpn_grads_ready(lo, hi): optional hook, called (inside the second stream's context) as soon as the
         gradients of every RPN/head variable -- theta[lo:hi], 94 % of the parameters -- are final, while the
         middle layers and the VFE are still being differentiated: data parallelism starts its all-reduce there."""
         prev_pin = _lib.pin_stream(torch.cuda.current_stream().cuda_stream)
         try:
-            return self._backward(y_cls, y_reg, loss, grad_scale, rpn_grads_ready)
+            return self._backward(y_cls, y_reg, loss, grad_scale, rpn_grads_ready, side_filler)
         finally:
             _lib.pin_stream(prev_pin)
 
-    def _backward(self, y_cls, y_reg, loss, grad_scale, rpn_grads_ready):
+    def _backward(self, y_cls, y_reg, loss, grad_scale, rpn_grads_ready, side_filler=None):
         self._prepare_training()
         self._pack_all_t()
         p, a, d, G = self.params, self.act, self.dact, self.grad
@@ -715,6 +737,10 @@ class LisecNet:
                 if L["name"] in early_layers:
                     continue
                 on_side(lambda L=L: deconv_wgrad(L))
+                if side_filler is not None:
+                    pending.append((side_filler, False))
+                    flush_side()
+                    side_filler = None
                 dgrad_into(c, branch_dy(L), L["src"])
             elif L["kind"] == "conv":
                 dst = L["dst"]
@@ -804,17 +830,18 @@ class LisecNet:
             # both repacks (forward and transposed layouts, ~75 us) for the NEXT step go to the second stream now: they
             # only depend on this update, and the next sweep's voxeliser + VFE (~105 us) do not read them
             if getattr(self, "_pack_done", None) is None:
-                self._pack_fork, self._pack_done = self._new_event(), self._new_event()
+                self._pack_fork, self._pack_done, self._pack_late = self._new_event(), self._new_event(), self._new_event()
             self._record(self._pack_fork, torch.cuda.current_stream())
             self._wait(self._pack_fork, self.side)
             pin = _lib.pin_stream(self.side.cuda_stream)
             try:
-                self._pack_all()
+                self._pack_all(after_main=lambda: self._record(self._pack_done, self.side))
                 self._pack_all_t()
             finally:
                 _lib.pin_stream(pin)
-            self._record(self._pack_done, self.side)
+            self._record(self._pack_late, self.side)
             self._pack_pending = True
+            self._late_pending = True
 
     def train_step(self, sample, y_cls, y_reg, loss="mse", allreduce=None):
         """One fit() step at batch_size=1: forward (batch statistics) + backward + SGD-Nesterov.
@@ -891,7 +918,9 @@ class RecordedStep:
         net._pack_all()
         net._pack_all_t()
         net._record(net._pack_done, torch.cuda.current_stream())   # what the recorded forward waits for
+        net._record(net._pack_late, torch.cuda.current_stream())
         net._pack_pending = True
+        net._late_pending = True
         torch.cuda.synchronize(dev)
 
     def _enqueue(self):
@@ -928,6 +957,7 @@ class RecordedStep:
         net.state_version += 1
         net._packed_version = net._packed_t_version = (net.params_version, net.params.version)
         net._pack_pending = True
+        net._late_pending = True
         self.sample._host_info = None
         return net.loss_out
 
@@ -940,6 +970,132 @@ class RecordedStep:
             torch.cuda.synchronize(self.net.device)
             self.lib.lisec_step_plan_destroy(self.plan)
             self.plan = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class PipelinedStep:
+    """RecordedStep with the input pipeline folded in: step k voxelises the sweep of step k + 1 on the second stream, in the
+    ~200 us that stream idles at the start of the backward pass, instead of step k + 1 starting with 90 us of seven small
+    dependent launches in front of its first contraction.  Two sets of (points, targets, voxel sample) buffers alternate,
+    so there are two recorded plans; the variables after every step are bit-identical to the eager schedule's (a sweep's
+    voxels do not depend on when they are computed).
+
+        step = PipelinedStep(net, voxelizer, capacity)
+        step.prime(points0, ycls0, yreg0)                    # stage + voxelise the first sweep
+        for k in range(n):
+            loss = step.step(points[k + 1], ycls[k + 1], yreg[k + 1])     # trains on sweep k, prepares sweep k + 1
+                                                                          # (no arguments: the staged buffers are reused)
+    """
+    PAD = RecordedStep.PAD
+
+    def __init__(self, net, voxelizer, capacity, dtype=torch.float32, loss="mse", lr=0.01, decay=1e-6, momentum=0.9,
+                 warmup=2):
+        import ctypes
+        self.net, self.vox, self.capacity, self.loss = net, voxelizer, int(capacity), loss
+        dev = net.device
+        self.lib = _lib.load()
+        self.points = [torch.full((self.capacity, 3), self.PAD, dtype=dtype, device=dev) for _ in range(2)]
+        self.ycls = [torch.zeros((net.Ho, net.Wo, 2), dtype=torch.float32, device=dev) for _ in range(2)]
+        self.yreg = [torch.zeros((net.Ho, net.Wo, 14), dtype=torch.float32, device=dev) for _ in range(2)]
+        self.hyper = (lr, decay, momentum)
+        self.stream_handle = torch.cuda.current_stream().cuda_stream
+        torch.cuda.synchronize(dev)
+        net._prepare_training()
+        p = net.params
+        keep = (p.theta.clone(), p.state.clone(), net.velocity.clone(), net._iter_dev.clone(), net._iterations)
+        self.samples = [self.vox(self.points[j]) for j in range(2)]
+        for k in range(2 * max(1, warmup)):
+            self._enqueue(k & 1)
+        torch.cuda.synchronize(dev)
+        self.plans = []
+        for j in range(2):
+            plan = ctypes.c_void_p()
+            _lib.check(self.lib.lisec_step_plan_create(ctypes.byref(plan)))
+            _lib.check(self.lib.lisec_step_plan_begin(plan))
+            try:
+                self._enqueue(j)
+            finally:
+                _lib.check(self.lib.lisec_step_plan_end(plan))
+            self.plans.append(plan)
+        torch.cuda.synchronize(dev)
+        self.launches = self.lib.lisec_step_plan_size(self.plans[0])
+        p.theta.copy_(keep[0]); p.state.copy_(keep[1]); net.velocity.copy_(keep[2]); net._iter_dev.copy_(keep[3])
+        net._iterations = keep[4]
+        net.params_version += 1
+        net.state_version += 1
+        p.touch()
+        net._pack_pending = False
+        net._pack_all()
+        net._pack_all_t()
+        net._record(net._pack_done, torch.cuda.current_stream())   # what the recorded forward waits for
+        net._record(net._pack_late, torch.cuda.current_stream())
+        net._pack_pending = True
+        net._late_pending = True
+        self.cur = 0
+        torch.cuda.synchronize(dev)
+
+    def _enqueue(self, j):
+        net = self.net
+        net.forward(self.samples[j], training=True)
+        net.backward(self.ycls[j], self.yreg[j], loss=self.loss,
+                     side_filler=lambda: self.vox(self.points[1 - j], out=self.samples[1 - j]))
+        net.apply_gradients(*self.hyper)
+
+    def _check_stream(self):
+        if torch.cuda.current_stream().cuda_stream != self.stream_handle:
+            raise RuntimeError("a PipelinedStep replays on the stream it was recorded on: make that stream current")
+
+    def _load(self, j, points, ycls, yreg):
+        pts = torch.as_tensor(points)
+        n = int(pts.shape[0])
+        if n > self.capacity:
+            raise ValueError(f"sweep of {n} points exceeds the recorded capacity {self.capacity}")
+        self.points[j][:n].copy_(pts[:, :3], non_blocking=True)
+        if n < self.capacity:
+            self.points[j][n:].fill_(self.PAD)
+        self.ycls[j].copy_(torch.as_tensor(ycls).reshape(self.ycls[j].shape), non_blocking=True)
+        self.yreg[j].copy_(torch.as_tensor(yreg).reshape(self.yreg[j].shape), non_blocking=True)
+
+    def prime(self, points, ycls, yreg):
+        """Stages the FIRST sweep and voxelises it (outside the plans); the next step() trains on it."""
+        self._check_stream()
+        self._load(self.cur, points, ycls, yreg)
+        self.vox(self.points[self.cur], out=self.samples[self.cur])
+
+    def stage_next(self, points, ycls, yreg):
+        """Stages the sweep the next step() voxelises (and the step() after it trains on)."""
+        self._check_stream()
+        self._load(1 - self.cur, points, ycls, yreg)
+
+    def step(self, next_points=None, next_ycls=None, next_yreg=None):
+        """Trains on the current sweep and voxelises the staged next one; returns net.loss_out (device)."""
+        self._check_stream()
+        if next_points is not None:
+            self._load(1 - self.cur, next_points, next_ycls, next_yreg)
+        net = self.net
+        _lib.check(self.lib.lisec_step_plan_run(self.plans[self.cur]))
+        net._iterations += 1
+        net.params_version += 1
+        net.state_version += 1
+        net._packed_version = net._packed_t_version = (net.params_version, net.params.version)
+        net._pack_pending = True
+        net._late_pending = True
+        for s_ in self.samples:
+            s_._host_info = None
+        self.cur ^= 1
+        return net.loss_out
+
+    def close(self):
+        if getattr(self, "plans", None):
+            torch.cuda.synchronize(self.net.device)
+            for plan in self.plans:
+                self.lib.lisec_step_plan_destroy(plan)
+            self.plans = None
 
     def __del__(self):
         try:

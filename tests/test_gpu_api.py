@@ -191,7 +191,7 @@ def test_recorded_step_equals_eager_steps():
     re-issued by lisec_step_plan_run) gives BIT-IDENTICAL variables to the Python schedule, with sweeps of different
     sizes padded into the fixed-capacity point buffer."""
     import torch
-    from lisec_amd.network import RecordedStep, LisecNet
+    from lisec_amd.network import RecordedStep, PipelinedStep, LisecNet
     from lisec_amd.params import ParamStore
     from lisec_amd.voxelizer import Voxelizer
     cfg = dict(xSize=0.5, ySize=0.25, zSize=0.25, sampleSize=35, maxVoxelX=8, maxVoxelY=16, maxVoxelZ=8)
@@ -214,13 +214,19 @@ def test_recorded_step_equals_eager_steps():
         net._prepare_training()
         net.iterations = 5                                   # a non-zero start: the decay term is live
         losses = []
-        step = RecordedStep(net, vox, 3000) if captured else None
+        step = (PipelinedStep if captured == "pipelined" else RecordedStep)(net, vox, 3000) if captured else None
         if captured:
             assert net.iterations == 5                       # the warm-up steps of the recording left no trace
             assert step.launches > 100                       # the plan holds the step's launches and event edges
-        for pts, (yc, yr) in zip(clouds, ys):
-            d_pts, d_yc, d_yr = (torch.from_numpy(a).to(dev) for a in (pts, yc, yr))
-            if captured:
+        dev_in = [tuple(torch.from_numpy(a).to(dev) for a in (pts, yc, yr)) for pts, (yc, yr) in zip(clouds, ys)]
+        if captured == "pipelined":
+            step.prime(*dev_in[0])
+        for k, (pts, (yc, yr)) in enumerate(zip(clouds, ys)):
+            d_pts, d_yc, d_yr = dev_in[k]
+            if captured == "pipelined":
+                # trains on sweep k; sweep k + 1 is voxelised inside the step (nothing staged after the last one)
+                lo = step.step(*dev_in[k + 1]) if k + 1 < len(dev_in) else step.step()
+            elif captured:
                 lo = step(d_pts, d_yc, d_yr)
             else:
                 # same capacity as the captured buffer: the row-list kernels plan their K slices per capacity
@@ -237,6 +243,9 @@ def test_recorded_step_equals_eager_steps():
     assert np.array_equal(l_e, l_g)
     assert np.array_equal(t_e, t_g) and np.array_equal(s_e, s_g)
     assert np.array_equal(c_e, c_g)
+    # ... and so does the pipelined form (sweep k + 1 voxelised on the second stream while step k runs)
+    t_p, s_p, l_p, c_p = run("pipelined")
+    assert np.array_equal(l_e, l_p) and np.array_equal(t_e, t_p) and np.array_equal(s_e, s_p) and np.array_equal(c_e, c_p)
     # padding itself: the unpadded sweeps give the same voxels, hence the same step up to fp32 summation order
     t_u, s_u, l_u, _ = run(False, pad=False)
     assert np.allclose(l_u, l_e, rtol=1e-6) and np.allclose(t_u, t_e, rtol=1e-4, atol=1e-6)
