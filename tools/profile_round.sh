@@ -13,8 +13,8 @@ for set in "pmc_fetch:FETCH_SIZE" "pmc_write:WRITE_SIZE" "pmc_clk:GRBM_GUI_ACTIV
   rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $R/gpurun_out/${tag}_pmc/$name -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline > $R/gpurun_out/${tag}_$name.log 2>&1 || exit 1
 done
 cd $R
-f=$(ls gpurun_out/${tag}_trace/*/*kernel_trace.csv | head -1)
+f=$(ls -t gpurun_out/${tag}_trace/*/*kernel_trace.csv | head -1)
 python tools/trace_csv.py $f 8 > gpurun_out/${tag}_step_timeline.txt
 python tools/trace_csv.py $f 8 --sum > gpurun_out/${tag}_step_anatomy.txt
 python tools/pmc_summary.py --dominant gpurun_out/${tag}_pmc_dominant.json gpurun_out/${tag}_pmc/pmc_fetch gpurun_out/${tag}_pmc/pmc_write gpurun_out/${tag}_pmc/pmc_clk gpurun_out/${tag}_pmc/pmc_sq > gpurun_out/${tag}_pmc_summary.txt
-cp $(ls gpurun_out/${tag}_stats/*/*kernel_stats.csv | head -1) gpurun_out/${tag}_bench_kernel_stats.csv
+cp $(ls -t gpurun_out/${tag}_stats/*/*kernel_stats.csv | head -1) gpurun_out/${tag}_bench_kernel_stats.csv

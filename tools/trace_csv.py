@@ -11,9 +11,11 @@ for r in rows:
     r["s"], r["e"] = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
 rows.sort(key=lambda r: r["s"])
 step = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].isdigit() else 8
-idx = [i for i, r in enumerate(rows) if "k_key_count" in r["Kernel_Name"]]
+# a step ends with the optimizer update (the voxeliser is no step boundary any more: PipelinedStep runs the NEXT sweep's
+# voxelisation on the second stream in the middle of the backward pass)
+idx = [i + 1 for i, r in enumerate(rows) if "k_sgd_nesterov" in r["Kernel_Name"]]
 a, b = idx[step], idx[step + 1]
-t0 = rows[a]["s"]
+t0 = rows[a - 1]["e"]
 agg = defaultdict(lambda: [0, 0.0])
 busy, cur_s, cur_e = 0.0, None, None
 prev_end = {}
@@ -36,7 +38,7 @@ for r in rows[a:b]:
         nwg = int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"]) // max(wg, 1)
         print("%7.0f %7.1f gap %5.1f q%s %-34s wgs %6d" % ((r["s"] - t0) / 1000.0, d, gap, q, n[:34], nwg))
 busy += cur_e - cur_s
-print("step span %.0f us, busy (union) %.0f us, kernel sum %.0f us" % ((rows[b]["s"] - t0) / 1000.0, busy / 1000.0,
+print("step span %.0f us (end of one optimizer update to the end of the next), busy (union) %.0f us, kernel sum %.0f us" % ((rows[b - 1]["e"] - t0) / 1000.0, busy / 1000.0,
                                                                    sum(v[1] for v in agg.values())))
 for n, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:30]:
     print("%-36s %4d %8.1f" % (n[:36], c, t))
