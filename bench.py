@@ -413,7 +413,15 @@ def main():
         def side_leg(points_np, loss_name, steps=10):
             """The same step on another sweep / loss pair, `steps` timed steps after 2 warm-up steps."""
             p2 = torch.from_numpy(points_np).to(dev)
-            if use_plan:
+            if use_plan and _lib.knob("pipeline_voxels", True):
+                from lisec_amd.network import PipelinedStep
+                rec = PipelinedStep(net, vox, len(points_np), dtype=p2.dtype, loss=loss_name)
+                rec.prime(p2, ycls, yreg)
+                rec.stage_next(p2, ycls, yreg)
+                rec.step()
+                rec.stage_next(p2, ycls, yreg)
+                run = rec.step
+            elif use_plan:
                 from lisec_amd.network import RecordedStep
                 rec = RecordedStep(net, vox, len(points_np), dtype=p2.dtype, loss=loss_name)
                 rec.load(p2, ycls, yreg)
