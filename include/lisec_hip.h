@@ -354,7 +354,7 @@ typedef struct lisec_wgrad_plan {
     int staging_passes;  /* halo: 7 (tiles of <= 110 rows, three workgroups per CU) or 9                                  */
     int tiles, slabs, tiles_per_slab;   /* M tiles, partial slabs (= ranges of tiles), tiles per range                   */
     int workgroups;
-    int lane_reduce;     /* many slabs over a small kernel: the lane-strided slab sum                                     */
+    int lane_reduce;     /* >= 32 slabs summed by a separate launch: the lane-strided slab sum                            */
     int combine_in_kernel; /* few slabs per cell: summed by the last slice to arrive, no slab-sum launch                  */
 } lisec_wgrad_plan;
 int lisec_conv_wgrad_plan_query(const lisec_conv_geom* g, int flags, int has_dy_bnstate, int has_row_list, int row_capacity,

@@ -741,8 +741,7 @@ extern "C" int lisec_conv_wgrad_plan_query(const lisec_conv_geom* c, int flags, 
     out->slabs = p.nsplit;
     out->tiles_per_slab = p.tiles_per_split;
     out->workgroups = p.nsplit * p.ngroups * cdiv(g.Cin, BC) * cdiv(g.Cout, BC);
-    const long long per = (long long)g.KD * g.KH * g.KW * g.Cin * g.Cout;
-    out->lane_reduce = (!p.combine && cdiv(per / 4, 256) < 64 && p.nsplit >= 128) ? 1 : 0;
+    out->lane_reduce = (!p.combine && p.nsplit >= 32) ? 1 : 0;
     out->combine_in_kernel = p.combine ? 1 : 0;
     return LISEC_OK;
 }
@@ -811,7 +810,10 @@ int launch_slab_sum(const ConvGeom& g, const WgradPlan& p, const float* partial,
     long long per = (long long)ntaps * g.Cin * g.Cout;
     int gb = cdiv(per / 4, 256);
     if (gb > 4096) gb = 4096;
-    if (gb < 64 && p.nsplit >= 128)
+    // many slabs: 32 lane groups per output sum nsplit / 32 slabs each (one or two memory round trips instead of
+    // nsplit / 8 dependent ones -- the pass runs beside the data-gradient chain and every round trip costs microseconds
+    // there: 22-151 us in the step for the 47 MB of a middle layer, 12 us alone)
+    if (p.nsplit >= 32)
         LISEC_LAUNCH(k_wgrad_reduce_lanes, dim3(cdiv(per / 4, 8)), dim3(256), 0, st, partial, p.nsplit, ntaps,
                            g.Cin, g.Cout, transpose_out, dW, dead_taps);
     else

@@ -186,7 +186,7 @@ def test_data_gradient(case):
 # weight gradients: name, mode, in dims, out dims, kernel, stride, pad, cin, cout, BN+ReLU on load, transpose_out, plan
 WGRAD = [
     ("mid2", 0, (4, H, W), (2, H, W), (3, 3, 3), (1, 1, 1), (0, 1, 1), 64, 64, False, False,
-     dict(halo=1, groups=9, tile_rows=100, staging_passes=7, taps_per_group=3)),
+     dict(halo=1, groups=9, tile_rows=100, staging_passes=7, taps_per_group=3, lane_reduce=1)),
     ("mid3", 0, (2, H, W), (1, H, W), (3, 3, 3), (2, 1, 1), (1, 1, 1), 64, 64, False, False,
      dict(halo=1, groups=6, tile_rows=100, staging_passes=7)),                      # the kd = 0 groups read nothing
     ("mid1.dense", 0, (4, H, W), (4, H, W), (1, 1, 1), (1, 1, 1), (0, 0, 0), 64, 64, True, False,
