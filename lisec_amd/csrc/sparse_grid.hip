@@ -40,20 +40,37 @@ k_line_sums(ConvGeom g, const float* dy, float* __restrict__ line_s, const float
     for (int k = 0; k < 4; ++k) acc[k] = make_float4(0, 0, 0, 0);
     const size_t row0 = (size_t)line * g.Wo;
     const float* base = dy + row0 * g.out_stride;
-    for (int w = wsub; w < g.Wo; w += wlanes) {
-        float4 v = *reinterpret_cast<const float4*>(base + (size_t)w * g.out_stride + q * 4);
-        if (APPLY) {
-            const float4 yv = *reinterpret_cast<const float4*>(y + (row0 + w) * C + q * 4);
-            v.x = sc.x * (v.x - m1.x - (yv.x - mu.x) * is.x * m2.x);
-            v.y = sc.y * (v.y - m1.y - (yv.y - mu.y) * is.y * m2.y);
-            v.z = sc.z * (v.z - m1.z - (yv.z - mu.z) * is.z * m2.z);
-            v.w = sc.w * (v.w - m1.w - (yv.w - mu.w) * is.w * m2.w);
-            *reinterpret_cast<float4*>(dy_out + (row0 + w) * g.out_stride + q * 4) = v;
-        }
-        const int b = (w << g.ls_w) - g.pw;
+    // kLineBatch positions per pass, every load of the pass issued before the first store: dy_out may alias dy (same
+    // index only), so the compiler cannot move a later position's loads above an earlier one's store by itself, and one
+    // memory round trip per position (25 for a 400-wide line) is what this kernel cost beside the weight gradients
+    constexpr int kLineBatch = 5;
+    for (int w0 = wsub; w0 < g.Wo; w0 += kLineBatch * wlanes) {
+        float4 v[kLineBatch], yv[kLineBatch];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (k < g.KW && b + k >= 0 && b + k < g.Wi) { acc[k].x += v.x; acc[k].y += v.y; acc[k].z += v.z; acc[k].w += v.w; }
+        for (int u = 0; u < kLineBatch; ++u) {
+            const int w = w0 + u * wlanes;
+            const int wc = w < g.Wo ? w : w0;                        // (clamped, not predicated)
+            v[u] = *reinterpret_cast<const float4*>(base + (size_t)wc * g.out_stride + q * 4);
+            if (APPLY) yv[u] = *reinterpret_cast<const float4*>(y + (row0 + wc) * C + q * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < kLineBatch; ++u) {
+            const int w = w0 + u * wlanes;
+            if (w < g.Wo) {
+                float4 t = v[u];
+                if (APPLY) {
+                    t.x = sc.x * (t.x - m1.x - (yv[u].x - mu.x) * is.x * m2.x);
+                    t.y = sc.y * (t.y - m1.y - (yv[u].y - mu.y) * is.y * m2.y);
+                    t.z = sc.z * (t.z - m1.z - (yv[u].z - mu.z) * is.z * m2.z);
+                    t.w = sc.w * (t.w - m1.w - (yv[u].w - mu.w) * is.w * m2.w);
+                    *reinterpret_cast<float4*>(dy_out + (row0 + w) * g.out_stride + q * 4) = t;
+                }
+                const int b = (w << g.ls_w) - g.pw;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (k < g.KW && b + k >= 0 && b + k < g.Wi) { acc[k].x += t.x; acc[k].y += t.y; acc[k].z += t.z; acc[k].w += t.w; }
+                }
+            }
         }
     }
 #pragma unroll
