@@ -550,12 +550,12 @@ k_wgrad_reduce(const float* __restrict__ partial, int nsplit, int ntaps, int Cin
         const float4* src = reinterpret_cast<const float4*>(partial) + i4;
         float4 s = make_float4(0, 0, 0, 0);
         int k = (dead_taps >> (i4 / tap4)) & 1 ? nsplit : 0;      // a tap no workgroup ran: its slabs were never written
-        for (; k + 8 <= nsplit; k += 8) {
-            float4 v[8];
+        for (; k + 4 <= nsplit; k += 4) {               // (four in flight: <= 56 registers, see k_wgrad_reduce_lanes)
+            float4 v[4];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(k + u) * per4];
+            for (int u = 0; u < 4; ++u) v[u] = src[(size_t)(k + u) * per4];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+            for (int u = 0; u < 4; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
         }
         for (; k < nsplit; ++k) {
             const float4 v = src[(size_t)k * per4];
@@ -577,34 +577,42 @@ k_wgrad_reduce(const float* __restrict__ partial, int nsplit, int ntaps, int Cin
 
 // Many slabs over a small kernel (the 64x64 Dense layers: > 1000 slabs of 16 KB): 32 lanes stride over the slabs of
 // 8 float4 outputs per block (loads batched 8 deep), combined in lane order through LDS.
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 8)            // <= 56 registers
 k_wgrad_reduce_lanes(const float* __restrict__ partial, int nsplit, int ntaps, int Cin, int Cout,
                      int transpose, float* __restrict__ dW, unsigned long long dead_taps) {
-    __shared__ float4 red[32][8];
+    // One WAVE per 8 outputs (float4 each): lane = 8 * g + t sums slabs g, g + 8, g + 16, ... of output t (eight loads in
+    // flight), then the eight partial sums of an output are added across lanes in a fixed tree -- no LDS and no barrier:
+    // the pass runs beside data-gradient kernels that hold all but a few KB of every CU's LDS, and with 4 KB of LDS per
+    // workgroup only one of its workgroups fitted a CU at a time.  Registers for the same reason: three waves of a
+    // 148-register contraction leave 56 registers per SIMD lane; at 64 this kernel's waves only found room when a
+    // data-gradient workgroup ENDED (171-226 us in the step for the 47 MB of a middle layer, 12 us alone).
     const long long per4 = ((long long)ntaps * Cin * Cout) >> 2;
     const long long tap4 = ((long long)Cin * Cout) >> 2;
-    const int tx = threadIdx.x & 7, ty = threadIdx.x >> 3;
-    const long long i4 = blockIdx.x * 8LL + tx;
+    const int lane = threadIdx.x & 63, tx = lane & 7, ty = lane >> 3;
+    const long long i4 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + tx;
     float4 s = make_float4(0, 0, 0, 0);
-    if (i4 < per4 && !((dead_taps >> (i4 / tap4)) & 1)) {
+    const bool live = i4 < per4 && !((dead_taps >> ((i4 < per4 ? i4 : 0) / tap4)) & 1);
+    if (live) {
         const float4* src = reinterpret_cast<const float4*>(partial) + i4;
         int k = ty;
-        for (; k + 7 * 32 < nsplit; k += 8 * 32) {
-            float4 v[8];
+        for (; k + 3 * 8 < nsplit; k += 4 * 8) {                // (four in flight, not eight: see the register note below)
+            float4 v[4];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(k + 32 * u) * per4];
+            for (int u = 0; u < 4; ++u) v[u] = src[(size_t)(k + 8 * u) * per4];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+            for (int u = 0; u < 4; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
         }
-        for (; k < nsplit; k += 32) {
+        for (; k < nsplit; k += 8) {
             const float4 v = src[(size_t)k * per4];
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
     }
-    red[ty][tx] = s;
-    __syncthreads();
+#pragma unroll
+    for (int o = 8; o < 64; o <<= 1) {                 // groups g and g + o/8: ((0+1)+(2+3))+((4+5)+(6+7))
+        s.x += __shfl_down(s.x, o, 64); s.y += __shfl_down(s.y, o, 64);
+        s.z += __shfl_down(s.z, o, 64); s.w += __shfl_down(s.w, o, 64);
+    }
     if (ty != 0 || i4 >= per4) return;
-    for (int l = 1; l < 32; ++l) { const float4 v = red[l][tx]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
     const long long i = i4 << 2;
     if (!transpose) {
         reinterpret_cast<float4*>(dW)[i4] = s;
@@ -792,14 +800,17 @@ void place_workspace(HaloCall* hc, void* workspace, int counter0, size_t slab_of
     hc->it.partial = reinterpret_cast<float*>(static_cast<char*>(workspace) + sizeof(int) * kWgradCounters + slab_off);
 }
 
-// LDS of a halo workgroup.  At LT = 100 that is 53 760 B and three fit a CU's 160 KB exactly -- which starves the
-// data-gradient chain running beside the weight gradients on the other stream of its 51 KB (measured in the step: 227.7
-// samples/s with three per CU against 232 with two; alone the three-per-CU launch is 5 % faster).  tuning().wgrad_per_cu
-// == 2 (default) therefore asks for just over a third of the CU.
+// LDS of a halo workgroup.  At LT = 100 that is 53 760 B = 42 of the CU's 128 granules of 1 280 B, and three fit -- which
+// starves the data-gradient chain running beside the weight gradients on the other stream of its 41 granules (measured
+// in the step: 227.7 samples/s with three per CU against 232 with two; alone the three-per-CU launch is 5 % faster).
+// tuning().wgrad_per_cu == 2 (default) therefore asks for 43 granules: two of these + one chain workgroup = 127 of 128.
 size_t halo_lds(const HaloCall& hc) {
     const int DR = (hc.p.LT + 7) & ~7;
     size_t lds = (size_t)(2 * DR + 2) * BC * sizeof(float);
-    const size_t third = 160 * 1024 / 3 + 1024;
+    // just over a third of 160 KB and not more: LDS is handed out in 1 280-byte granules, 2 x 43 granules leave 53 760 B --
+    // room for the 52 224 B of a data-gradient workgroup; a request of 55 637 B (44 granules) left 51 200 and locked the
+    // chain out of every CU that held two of these
+    const size_t third = 54700;
     if (tuning().wgrad_per_cu == 2 && lds < third) lds = third;
     return lds;
 }
@@ -814,7 +825,7 @@ int launch_slab_sum(const ConvGeom& g, const WgradPlan& p, const float* partial,
     // nsplit / 8 dependent ones -- the pass runs beside the data-gradient chain and every round trip costs microseconds
     // there: 22-151 us in the step for the 47 MB of a middle layer, 12 us alone)
     if (p.nsplit >= 32)
-        LISEC_LAUNCH(k_wgrad_reduce_lanes, dim3(cdiv(per / 4, 8)), dim3(256), 0, st, partial, p.nsplit, ntaps,
+        LISEC_LAUNCH(k_wgrad_reduce_lanes, dim3(cdiv(per / 4, 32)), dim3(256), 0, st, partial, p.nsplit, ntaps,
                            g.Cin, g.Cout, transpose_out, dW, dead_taps);
     else
         LISEC_LAUNCH(k_wgrad_reduce, dim3(gb), dim3(256), 0, st, partial, p.nsplit, ntaps, g.Cin, g.Cout,
