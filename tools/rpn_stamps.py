@@ -39,6 +39,20 @@ def case(name, mode, ind, outd, k, s, p, cin, cout, in_bn=True, sink=True, iters
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / iters * 1e3
     flops = 2.0 * M * ntaps * cin * cout
+    # the same launch with COLD weights: a step runs every layer once, so no layer finds its kernel in L2; here 64 copies
+    # of the packed kernel are rotated through (64 x a few MB: beyond every XCD's 4 MB)
+    copies = [wp.clone() for _ in range(64)]
+    for c in copies[:3]:
+        ops.conv_forward(g, x, c, out, in_bn=bn, flags=fl, sink=sk)
+    torch.cuda.synchronize()
+    e0.record()
+    for i in range(iters):
+        ops.conv_forward(g, x, copies[i % 64], out, in_bn=bn, flags=fl, sink=sk)
+    e1.record()
+    torch.cuda.synchronize()
+    us_cold = e0.elapsed_time(e1) / iters * 1e3
+    del copies
+    print(f"   ({us_cold:.1f} us per call with a different copy of the packed kernel every call: weights not in L2)")
     buf = torch.zeros(8192 * 8, dtype=torch.int64, device=dev)
     _lib.check(lib.lisec_debug_igemm_stamps(buf.data_ptr()))
     torch.cuda.synchronize()
