@@ -356,6 +356,12 @@ typedef struct lisec_wgrad_plan {
     int workgroups;
     int lane_reduce;     /* >= 32 slabs summed by a separate launch: the lane-strided slab sum                            */
     int combine_in_kernel; /* few slabs per cell: summed by the last slice to arrive, no slab-sum launch                  */
+    int ring;            /* ring kernel (3 x 3 taps in (h, w) at stride 1): one 768-thread workgroup owns a run of output  */
+                         /* lines of one (cell, kd, plane, w segment) column and all nine taps; the three input lines live */
+                         /* in an LDS ring, so x and dy are staged once per nine taps.  groups = (kd, plane) pairs,        */
+                         /* taps_per_group = 9, staging_passes = 48-row passes (2 or 3), slabs = most slices of a cell     */
+    int runs_per_column; /* ring: runs every column of Ho output lines is cut into                                        */
+    int lines_per_run;   /* ring: most output lines of a run                                                               */
 } lisec_wgrad_plan;
 int lisec_conv_wgrad_plan_query(const lisec_conv_geom* g, int flags, int has_dy_bnstate, int has_row_list, int row_capacity,
                                 lisec_wgrad_plan* plan);
@@ -643,6 +649,8 @@ typedef struct lisec_tuning {
     int lone_db;            /* small K-sliced layers: one workgroup per CU on the two-image kernels (1)         */
     int wgrad_per_cu;       /* weight-gradient workgroups per CU: 2 leaves 53 KB of LDS for a workgroup of the   */
                             /* data-gradient chain on the other stream (default), 3 = as many as fit            */
+    int wgrad_ring;         /* ring kernel for the 3 x 3 stride-1 weight gradients                 (1)         */
+    int wgrad_ring_slots;   /* workgroups a ring launch fills, 0 = one per CU                      (0)         */
 } lisec_tuning;
 int lisec_tuning_get(lisec_tuning* t);        /* fills *t with the current record (t->struct_bytes set)          */
 int lisec_tuning_set(const lisec_tuning* t);  /* t->struct_bytes must be sizeof(lisec_tuning)                    */

@@ -49,13 +49,15 @@ class ConvPlan(Structure):                     # lisec_conv_plan
 
 class WgradPlan(Structure):                    # lisec_wgrad_plan
     _fields_ = [(n, c_int) for n in ("halo", "mirrored", "taps_per_group", "groups", "tile_rows", "staging_passes", "tiles",
-                                     "slabs", "tiles_per_slab", "workgroups", "lane_reduce", "combine_in_kernel")]
+                                     "slabs", "tiles_per_slab", "workgroups", "lane_reduce", "combine_in_kernel", "ring",
+                                     "runs_per_column", "lines_per_run")]
 
 
 class Tuning(Structure):                       # lisec_tuning
     _fields_ = [(n, c_int) for n in ("struct_bytes", "max_splitk", "splitk_min_steps", "min_splitk", "plane_pair", "dense64",
                                      "half_n", "vfe_shape", "field_seg", "field_tpw", "wgrad_blocks", "debug_sync",
-                                     "force_splitk", "wgrad_combine_max", "wgrad_batch_blocks", "lone_db", "wgrad_per_cu")]
+                                     "force_splitk", "wgrad_combine_max", "wgrad_batch_blocks", "lone_db", "wgrad_per_cu",
+                                     "wgrad_ring", "wgrad_ring_slots")]
 
 
 KERNEL_NAMES = {0: "igemm", 1: "halo2", 2: "halo3", 3: "dense64", 4: "queue"}

@@ -13,7 +13,7 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-static lisec_tuning g_tuning = {(int)sizeof(lisec_tuning), 12, 3, 2, 1, 1, 1, -1, 0, 0, 1024, 0, 0, 32, 1024, 1, 2};
+static lisec_tuning g_tuning = {(int)sizeof(lisec_tuning), 12, 3, 2, 1, 1, 1, -1, 0, 0, 1024, 0, 0, 32, 1024, 1, 2, 1, 0};
 const lisec_tuning& tuning() { return g_tuning; }
 }  // namespace lisec
 

@@ -175,6 +175,7 @@ class LisecNet:
         self.side = torch.cuda.Stream(device=dev, priority=_lib.knob("side_priority", -1))
 
         self.branch_overlap = _lib.knob("branch_overlap", True)
+        self.chain_first = _lib.knob("chain_first", True)      # head phase: the chain's contraction is enqueued before the leaves
         self._fwd_events = {}
         self._packed_version = -1
         self.params_version = 0
@@ -581,15 +582,25 @@ class LisecNet:
 
         pending = []
 
-        def flush_side():
-            """Records ONE event on the main stream and runs every pending closure on the second stream behind it."""
-            if not pending:
-                return
+        marked = []
+
+        def mark_fork():
+            """Records the fork event NOW; the next flush_side() waits for this one instead of recording its own.  Lets the
+            chain's next kernel be ENQUEUED before the second stream's work although that work does not depend on it."""
             if nfork[0] == len(events):
                 events.append(self._new_event())
             ev = events[nfork[0]]                       # events are reused step after step
             nfork[0] += 1
             self._record(ev, main)
+            marked.append(ev)
+
+        def flush_side():
+            """Records ONE event on the main stream and runs every pending closure on the second stream behind it."""
+            if not pending:
+                return
+            if not marked:
+                mark_fork()
+            ev = marked.pop()
             self._wait(ev, self.side)
             pin = _lib.pin_stream(side_handle)
             try:
@@ -736,12 +747,21 @@ class LisecNet:
             if L["kind"] == "deconv":
                 if L["name"] in early_layers:
                     continue
-                on_side(lambda L=L: deconv_wgrad(L))
+                if self.chain_first:
+                    # the chain's contraction goes into its queue BEFORE the leaves that hang off the same gradient: the
+                    # second stream's queue is served first (priority) and its kernels fill every CU's LDS, so a chain
+                    # kernel enqueued behind them waited for the whole leaf sequence (r03 timeline: 214 us)
+                    mark_fork()
+                    dgrad_into(c, branch_dy(L), L["src"])
+                    on_side(lambda L=L: deconv_wgrad(L))
+                else:
+                    on_side(lambda L=L: deconv_wgrad(L))
                 if side_filler is not None:
                     pending.append((side_filler, False))
                     flush_side()
                     side_filler = None
-                dgrad_into(c, branch_dy(L), L["src"])
+                if not self.chain_first:
+                    dgrad_into(c, branch_dy(L), L["src"])
             elif L["kind"] == "conv":
                 dst = L["dst"]
                 C = c.g.Cout

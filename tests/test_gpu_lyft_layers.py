@@ -185,30 +185,35 @@ def test_data_gradient(case):
 
 # weight gradients: name, mode, in dims, out dims, kernel, stride, pad, cin, cout, BN+ReLU on load, transpose_out, plan
 WGRAD = [
+    ("mid1 dense form", 0, (8, H, W), (4, H, W), (3, 3, 3), (2, 1, 1), (1, 1, 1), 64, 64, False, False,
+     dict(ring=1, halo=0, groups=11, tile_rows=100, staging_passes=5, taps_per_group=9, lane_reduce=1)),   # kd = 0 reads no plane at d = 0
     ("mid2", 0, (4, H, W), (2, H, W), (3, 3, 3), (1, 1, 1), (0, 1, 1), 64, 64, False, False,
-     dict(halo=1, groups=9, tile_rows=100, staging_passes=7, taps_per_group=3, lane_reduce=1)),
+     dict(ring=1, halo=0, groups=6, tile_rows=100, staging_passes=5, taps_per_group=9, lane_reduce=1, runs_per_column=10,
+          workgroups=240)),
     ("mid3", 0, (2, H, W), (1, H, W), (3, 3, 3), (2, 1, 1), (1, 1, 1), 64, 64, False, False,
-     dict(halo=1, groups=6, tile_rows=100, staging_passes=7)),                      # the kd = 0 groups read nothing
+     dict(ring=1, groups=2, tile_rows=100, staging_passes=5, lane_reduce=1)),      # the kd = 0 cells read nothing: zeros
     ("mid1.dense", 0, (4, H, W), (4, H, W), (1, 1, 1), (1, 1, 1), (0, 0, 0), 64, 64, True, False,
-     dict(halo=0, taps_per_group=1, lane_reduce=1)),
+     dict(ring=0, halo=0, taps_per_group=1, lane_reduce=1)),
     ("rpn1.conv0", 0, (1, H, W), (1, 100, 200), (1, 3, 3), (1, 2, 2), (0, 1, 1), 64, 128, False, False,
-     dict(halo=0, taps_per_group=3, groups=3)),
+     dict(ring=0, halo=0, taps_per_group=3, groups=3)),
     ("rpn1.conv1", 0, (1, 100, 200), (1, 100, 200), (1, 3, 3), (1, 1, 1), (0, 1, 1), 128, 128, True, False,
-     dict(halo=1, groups=3, tile_rows=100, staging_passes=7)),
+     dict(ring=1, groups=1, tile_rows=100, staging_passes=5, runs_per_column=25, lane_reduce=1)),   # alone: 50 slices per cell
+    ("rpn2.conv0", 0, (1, 100, 200), (1, 50, 100), (1, 3, 3), (1, 2, 2), (0, 1, 1), 128, 128, True, False,
+     dict(ring=0, halo=0, taps_per_group=3)),
     ("rpn2.conv1", 0, (1, 50, 100), (1, 50, 100), (1, 3, 3), (1, 1, 1), (0, 1, 1), 128, 128, True, False,
-     dict(halo=1, groups=3, tile_rows=100, staging_passes=7)),
+     dict(ring=1, groups=1, tile_rows=100, staging_passes=5, lane_reduce=1)),
     ("rpn3.conv0", 0, (1, 50, 100), (1, 25, 50), (1, 3, 3), (1, 2, 2), (0, 1, 1), 128, 256, True, False,
-     dict(halo=0, taps_per_group=3)),
+     dict(ring=0, halo=0, taps_per_group=3)),
     ("rpn3.conv1", 0, (1, 25, 50), (1, 25, 50), (1, 3, 3), (1, 1, 1), (0, 1, 1), 256, 256, True, False,
-     dict(halo=1, groups=3, tile_rows=50, staging_passes=7)),
+     dict(ring=1, groups=1, tile_rows=50, staging_passes=3, combine_in_kernel=1)),
     ("up1 (256 channels)", 1, (1, 100, 200), (1, 100, 200), (1, 3, 3), (1, 1, 1), (0, 1, 1), 128, 256, True, True,
-     dict(halo=1, mirrored=1, groups=3, tile_rows=100)),
+     dict(ring=1, mirrored=1, groups=1, tile_rows=100)),
     ("up1 collapsed (16 channels)", 1, (1, 100, 200), (1, 100, 200), (1, 3, 3), (1, 1, 1), (0, 1, 1), 128, 16, True, False,
-     dict(halo=1, mirrored=1, groups=3, tile_rows=100)),
+     dict(ring=1, mirrored=1, groups=1, tile_rows=100)),
     ("up2 collapsed (1x1, 64 columns)", 0, (1, 50, 100), (1, 50, 100), (1, 1, 1), (1, 1, 1), (0, 0, 0), 128, 64, True, False,
-     dict(halo=0, taps_per_group=1)),
+     dict(ring=0, halo=0, taps_per_group=1)),
     ("up3 collapsed (1x1, 256 columns)", 0, (1, 25, 50), (1, 25, 50), (1, 1, 1), (1, 1, 1), (0, 0, 0), 256, 256, True, False,
-     dict(halo=0, taps_per_group=1)),
+     dict(ring=0, halo=0, taps_per_group=1)),
 ]
 
 

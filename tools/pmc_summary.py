@@ -15,7 +15,9 @@ from collections import defaultdict
 DOMINANT = "mid2 Conv3D data gradient (roofline launch)"
 KEYS = {"k_igemm_halo<1, false, 1, 2": DOMINANT, "k_wgrad_halo<false, 7>": "mid wgrad (halo)", "k_field_taps": "field conv: taps",
         "k_field_combine": "field conv: combine", "k_igemm_halo<0, false, 1, 2>": "mid1 Conv3D fwd (roofline launch)", "k_vfe_grid": "VFE grid writer",
-        "k_vfe_stage<2": "VFE layers 1+2", "k_vfe_stage<3": "VFE layer 3", "k_wgrad_halo<false>": "mid wgrad (halo)"}
+        "k_vfe_stage<2": "VFE layers 1+2", "k_vfe_stage<3": "VFE layer 3", "k_wgrad_halo<false>": "mid wgrad (halo)",
+        "k_wgrad_ring<false, 5>": "mid wgrad (ring)", "k_wgrad_ring_batch<true, 5>": "rpn1/rpn2 batched wgrad (ring)",
+        "k_wgrad_ring_batch<true, 3>": "rpn3 batched wgrad (ring)", "k_wgrad_ring_reduce": "ring slab sum"}
 args = sys.argv[1:]
 dominant_out = None
 if args and args[0] == "--dominant":

@@ -63,6 +63,9 @@ def case(name, mode, ind, outd, k, s, p, cin, cout, in_bn, iters=10):
     d = lambda a, b: (t[:, b] - t[:, a]) / 100.0
     print(f"   per workgroup (median): entry -> first tile in LDS {np.median(d(0, 1)):.2f} us; loop {np.median(d(1, 2)):.2f} us over "
           f"{np.median(t[:, 5]):.0f} tiles = {np.median(d(1, 2) / nt):.2f} us per tile; slab stores {np.median(d(2, 3)):.2f} us; whole {np.median(d(0, 3)):.2f}")
+    if (t[:, 7] > t[:, 4]).all():
+        ghz = (t[:, 7] - t[:, 4]) / np.maximum(t[:, 2] - t[:, 1], 1) / 10.0
+        print(f"   in-kernel clock over the loop (s_memtime / s_memrealtime): median {np.median(ghz):.3f} GHz, p10 {np.percentile(ghz, 10):.3f}, p90 {np.percentile(ghz, 90):.3f}")
 
 
 if __name__ == "__main__":
