@@ -291,6 +291,13 @@ typedef struct lisec_conv_extras {
      * draw their tiles from a counter -- the tiles of a row list do very unequal work (rows beyond the device-side count,
      * depth parity), which one workgroup per tile turns into idle CUs. */
     int32_t* queue;
+    /* optional second contraction riding on the stored tile (model_training.py:195, backwards: the gradient this call stores
+     * is the one w.r.t. a middle block's Dense(64, relu) output, gated by out_mask; the Dense's own data gradient is one more
+     * 64 x 64 contraction of the same rows):  tail_out[m, :] = out[m, :] (as stored) @ tail_w,  tail_w a packed 64 x 64 kernel
+     * (lisec_conv_pack_weights), tail_out (positions, 64).  bwd_y / bwd_bnstate / bwd_relu / sink then describe tail_out.
+     * Needs the two-line w-halo kernel (3 taps along w, stride 1, Wo >= 126), Cout = out_stride = 64; LISEC_EINVAL otherwise. */
+    const float* tail_w;
+    float* tail_out;
 } lisec_conv_extras;
 int lisec_conv_num_mblocks_bwd(const lisec_conv_geom* g);
 

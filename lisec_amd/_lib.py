@@ -39,7 +39,8 @@ class BnSinkDesc(ctypes.Structure):           # lisec_bn_sink
 
 class ConvExtras(ctypes.Structure):           # lisec_conv_extras
     _fields_ = [("out_mask", ctypes.c_void_p), ("bwd_y", ctypes.c_void_p), ("bwd_bnstate", ctypes.c_void_p),
-                ("bwd_relu", ctypes.c_int), ("sink", POINTER(BnSinkDesc)), ("queue", ctypes.c_void_p)]
+                ("bwd_relu", ctypes.c_int), ("sink", POINTER(BnSinkDesc)), ("queue", ctypes.c_void_p),
+                ("tail_w", ctypes.c_void_p), ("tail_out", ctypes.c_void_p)]
 
 
 class ConvPlan(Structure):                     # lisec_conv_plan

@@ -49,6 +49,10 @@ struct ConvGeom {
     const float* bwd_bn;     // its bnstate float[4*Cout]
     int bwd_relu;
     BnSink sink;             // optional destination of the per-tile sums (acc == nullptr: the partial table, if any)
+    // optional second contraction on the stored tile (lisec_conv_extras.tail_w): tail_out[m, :] = stored out[m, :] @ tail_w,
+    // 64 -> 64; the backward statistics / sink then belong to tail_out
+    const float* tail_w;
+    float* tail_out;
 };
 
 int conv_geom_check(const lisec_conv_geom* c, ConvGeom* g);

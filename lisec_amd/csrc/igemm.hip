@@ -109,7 +109,10 @@ __device__ __forceinline__ bool splitk_arrive(f32x16& acc0, f32x16& acc1, float*
 __device__ __forceinline__ void store_tile(const ConvGeom& g, const f32x16& acc0, const f32x16& acc1, float* smem,
                                            int mw, int n0, int mb, int mlimit, int wave, int lane, int tid,
                                            const float* __restrict__ bias, int flags, float* __restrict__ out,
-                                           double* __restrict__ stats, bool storer = true, bool half = false) {
+                                           double* __restrict__ stats, bool storer = true, bool half = false,
+                                           int phase = 0, float* lds_tile = nullptr) {
+    // phase (calls with g.tail_w): 1 = the gated first output, no statistics, the stored values also go to lds_tile
+    // ([128][LDA], the A operand of the tail contraction); 2 = the tail's output: no gate, the backward statistics
     // half: the workgroup computed a 32-column slab (acc1 is unused): the second 32 columns are treated as outside Cout
     const int col = lane & 31;
     const int nA = n0 + col, nB = half ? g.Cout : n0 + 32 + col;
@@ -127,7 +130,9 @@ __device__ __forceinline__ void store_tile(const ConvGeom& g, const f32x16& acc0
     }
     // BatchNormalization-backward statistics: per-column constants of the layer the gradient belongs to
     float ysA = 1.f, yhA = 0.f, ymA = 0.f, yiA = 0.f, ysB = 1.f, yhB = 0.f, ymB = 0.f, yiB = 0.f;
-    if (g.bwd_y) {
+    const float* bwd_y = phase == 1 ? nullptr : g.bwd_y;
+    const float* omask = phase == 2 ? nullptr : g.out_mask;
+    if (bwd_y) {
         if (nA < g.Cout) { ysA = g.bwd_bn[nA]; yhA = g.bwd_bn[g.Cout + nA]; ymA = g.bwd_bn[2 * g.Cout + nA]; yiA = g.bwd_bn[3 * g.Cout + nA]; }
         if (nB < g.Cout) { ysB = g.bwd_bn[nB]; yhB = g.bwd_bn[g.Cout + nB]; ymB = g.bwd_bn[2 * g.Cout + nB]; yiB = g.bwd_bn[3 * g.Cout + nB]; }
     }
@@ -159,17 +164,18 @@ __device__ __forceinline__ void store_tile(const ConvGeom& g, const f32x16& acc0
                 if (nA < g.Cout) va += o[ncA];
                 if (nB < g.Cout) vb += o[ncB];
             }
-            if (g.out_mask) {
-                const float* mk = g.out_mask + orow * g.out_stride;
+            if (omask) {
+                const float* mk = omask + orow * g.out_stride;
                 if (nA < g.Cout && !(mk[ncA] > 0.f)) va = 0.f;
                 if (nB < g.Cout && !(mk[ncB] > 0.f)) vb = 0.f;
             }
             if (orelu) { va = fmaxf(va, 0.f); vb = fmaxf(vb, 0.f); }
             if (nA < g.Cout) o[ncA] = va;
             if (nB < g.Cout) o[ncB] = vb;
-            if (g.bwd_y) {
+            if (lds_tile) { lds_tile[(wave * 32 + row) * LDA + col] = va; lds_tile[(wave * 32 + row) * LDA + 32 + col] = vb; }
+            if (bwd_y) {
                 // (sum dz, sum dz * yhat) of the gradient just stored, for the BatchNormalization it is about to cross
-                const float* yr = g.bwd_y + orow * g.Cout;
+                const float* yr = bwd_y + orow * g.Cout;
                 const float ya = nA < g.Cout ? yr[nA] : 0.f, yb = nB < g.Cout ? yr[nB] : 0.f;
                 const float da = (g.bwd_relu && !(fmaf(ya, ysA, yhA) > 0.f)) || nA >= g.Cout ? 0.f : va;
                 const float db = (g.bwd_relu && !(fmaf(yb, ysB, yhB) > 0.f)) || nB >= g.Cout ? 0.f : vb;
@@ -179,9 +185,11 @@ __device__ __forceinline__ void store_tile(const ConvGeom& g, const f32x16& acc0
                 sumA += va; sqA = fmaf(va, va, sqA);
                 sumB += vb; sqB = fmaf(vb, vb, sqB);
             }
+        } else if (lds_tile) {
+            lds_tile[(wave * 32 + row) * LDA + col] = 0.f; lds_tile[(wave * 32 + row) * LDA + 32 + col] = 0.f;
         }
     }
-    if (stats || g.sink.acc) {
+    if (phase != 1 && (stats || g.sink.acc)) {
         // per-channel partial sums of this 128-row tile (BatchNormalization batch statistics)
         __syncthreads();
         float* red = smem;                       // [4 waves][4][32]
@@ -544,7 +552,7 @@ k_igemm_queue(ConvGeom g, const float* __restrict__ in, const float* __restrict_
 constexpr int halo_rows(int nseg) { return BM + 2 * nseg; }     // segments + two halo columns each
 constexpr size_t halo_lds_bytes(int nseg) { return (size_t)(halo_rows(nseg) * LDA + B_FLOATS) * sizeof(float); }   // <= 52 832 B: 3 per CU
 
-template <int MODE, bool XF, int NSEG, int NW = 64, bool DB = false>
+template <int MODE, bool XF, int NSEG, int NW = 64, bool DB = false, bool TAIL = false>
 __device__ __forceinline__ void
 halo_tile(const ConvGeom& g, const float* __restrict__ in, const float* __restrict__ wp,
           const float* __restrict__ bias, const float* __restrict__ in_bn, int flags,
@@ -810,6 +818,47 @@ halo_tile(const ConvGeom& g, const float* __restrict__ in, const float* __restri
         IGEMM_STAMP(7);
         if (!last) { IGEMM_STAMP(4); return; }
     }
+    if (TAIL) {
+        // Dense(64) backward riding on the tile (model_training.py:195: the gradient this call stores is the one w.r.t. a
+        // middle block's Dense output, gated by its ReLU): dz = (gated tile) @ Wd^T goes to tail_out with the backward
+        // statistics of the BatchNormalization under the Dense -- 64 more MFMAs per wave on top of the tile's 27 x 64
+        // instead of a launch that re-reads the 82 MB gradient (k_dense64<false, true>: 148 us alone at 320 000 rows)
+        float* tA = smem;                             // [128][LDA]; the halo image is dead (the loop ended on a barrier)
+        float* tB = smem + HALO_MAX_ROWS * LDA;
+        store_tile(g, acc0, acc1, smem, m0 + wave * 32, n0, mb, mlimit, wave, lane, tid, bias, flags, out, nullptr, true, false,
+                   1, tA);
+        {
+            // (behind the store, not under it: with the accumulators still live the 16 registers of the kernel's copy
+            // took the workgroup from 152 to 168 registers, and a 168-register wave no longer fits beside the three
+            // 120-register waves of a weight-gradient workgroup)
+            const float* wl = g.tail_w + (size_t)(tid >> 6) * BN * 4 + (tid & 63) * 4;
+            float* bl = tB + ((tid >> 6) * BN + (tid & 63)) * 4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                *reinterpret_cast<float4*>(bl + i * 4 * BN * 4) = *reinterpret_cast<const float4*>(wl + i * 4 * BN * 4);
+        }
+        __syncthreads();
+        f32x16 t0 = {0}, t1 = {0};
+        const float* aRow = tA + (wave * 32 + (lane & 31)) * LDA + 4 * (lane >> 5);
+        const float* bC = tB + ((lane >> 5) * BN + (lane & 31)) * 4;
+#pragma unroll
+        for (int kc = 0; kc < BK / 8; ++kc) {
+            const float4 a = *reinterpret_cast<const float4*>(aRow + kc * 8);
+            const float4 b0 = *reinterpret_cast<const float4*>(bC + kc * 2 * BN * 4);
+            const float4 b1 = *reinterpret_cast<const float4*>(bC + kc * 2 * BN * 4 + 32 * 4);
+            t0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, t0, 0, 0, 0);
+            t1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1.x, t1, 0, 0, 0);
+            t0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b0.y, t0, 0, 0, 0);
+            t1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1.y, t1, 0, 0, 0);
+            t0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b0.z, t0, 0, 0, 0);
+            t1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b1.z, t1, 0, 0, 0);
+            t0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b0.w, t0, 0, 0, 0);
+            t1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b1.w, t1, 0, 0, 0);
+        }
+        store_tile(g, t0, t1, smem, m0 + wave * 32, n0, mb, mlimit, wave, lane, tid, nullptr, 0, g.tail_out, stats, true, false, 2);
+        IGEMM_STAMP(4);
+        return;
+    }
     store_tile(g, acc0, acc1, smem, m0 + wave * 32, n0, mb, mlimit, wave, lane, tid, bias, flags, out, stats, true, NW == 32);
     IGEMM_STAMP(4);
 }
@@ -819,7 +868,7 @@ halo_tile(const ConvGeom& g, const float* __restrict__ in, const float* __restri
 // gradient of the second middle block: 9 / 18 / 18 / 9 of 27 per plane); the hardware hands workgroups to the CUs in a
 // fixed rotation and waits for a slot on the CU whose turn it is, so a launch of mixed 9- and 18-step workgroups left
 // 40 % of the slots empty (tools/igemm_stamps.py).  Paired, every workgroup runs 27 steps.
-template <int MODE, bool XF, int TAG = 0, int NSEG = 2, int NW = 64, bool DB = false>
+template <int MODE, bool XF, int TAG = 0, int NSEG = 2, int NW = 64, bool DB = false, bool TAIL = false>
 __global__ void __launch_bounds__(kThreads)
 k_igemm_halo(ConvGeom g, const float* __restrict__ in, const float* __restrict__ wp,
              const float* __restrict__ bias, const float* __restrict__ in_bn, int flags,
@@ -830,16 +879,16 @@ k_igemm_halo(ConvGeom g, const float* __restrict__ in, const float* __restrict__
     IGEMM_STAMP(0);
     const int v = tile0 + xcd_remap(blockIdx.x, gridDim.x);
     if (DB || !g.plane_pair) {
-        halo_tile<MODE, XF, NSEG, NW, DB>(g, in, wp, bias, in_bn, flags, out, stats, nsplit, partial, tile0, v, smem, stamps,
-                                          stamp_wg);
+        halo_tile<MODE, XF, NSEG, NW, DB, TAIL>(g, in, wp, bias, in_bn, flags, out, stats, nsplit, partial, tile0, v, smem, stamps,
+                                                stamp_wg);
         return;
     }
     const int q = v / g.plane_tiles, i = v - q * g.plane_tiles;
-    halo_tile<MODE, XF, NSEG, NW>(g, in, wp, bias, in_bn, flags, out, stats, nsplit, partial, tile0,
-                              2 * q * g.plane_tiles + i, smem, stamps, stamp_wg);
+    halo_tile<MODE, XF, NSEG, NW, false, TAIL>(g, in, wp, bias, in_bn, flags, out, stats, nsplit, partial, tile0,
+                                               2 * q * g.plane_tiles + i, smem, stamps, stamp_wg);
     __syncthreads();                                  // the epilogue's statistics scratch is the next tile's staging area
-    halo_tile<MODE, XF, NSEG, NW>(g, in, wp, bias, in_bn, flags, out, stats, nsplit, partial, tile0,
-                              (2 * q + 1) * g.plane_tiles + i, smem, stamps, stamp_wg);
+    halo_tile<MODE, XF, NSEG, NW, false, TAIL>(g, in, wp, bias, in_bn, flags, out, stats, nsplit, partial, tile0,
+                                               (2 * q + 1) * g.plane_tiles + i, smem, stamps, stamp_wg);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1052,6 +1101,7 @@ int conv_geom_check(const lisec_conv_geom* c, ConvGeom* g) {
     g->bwd_y = nullptr; g->bwd_bn = nullptr; g->bwd_relu = 0;
     g->sink.acc = nullptr;
     g->plane_tiles = 0; g->plane_pair = 0; g->queue = nullptr;
+    g->tail_w = nullptr; g->tail_out = nullptr;
     g->pointwise = c->KD * c->KH * c->KW == 1 && ld == 0 && lh == 0 && lw == 0 && c->pd == 0 && c->ph == 0 && c->pw == 0 &&
                    c->Di == c->Do && c->Hi == c->Ho && c->Wi == c->Wo;
     return 0;
@@ -1298,6 +1348,20 @@ int plan_conv(const lisec_conv_geom* c, bool has_in_bn, int flags, const lisec_c
         return LISEC_OK;
     }
     p->roofline = false;
+    if (extras && extras->tail_w) {
+        // second contraction on the stored tile: one un-sliced launch of the two-line halo kernel over 64 columns
+        LISEC_CHECK_ARG(extras->tail_out && ((uintptr_t)extras->tail_w & 15) == 0 && ((uintptr_t)extras->tail_out & 15) == 0,
+                        "tail: packed 64 x 64 kernel and an output, 16-byte aligned");
+        LISEC_CHECK_ARG(halo_geom && !p->halo3 && g.Cout == 64 && g.out_stride == 64 && !g.pc_span && !table_stats &&
+                        !(flags & (LISEC_CONV_ACCUMULATE | LISEC_CONV_OUT_RELU)) && (!bwd_stats || sk),
+                        "tail: needs the two-line w-halo kernel, Cout = out_stride = 64, no accumulate / ReLU, statistics through a sink");
+        g.tail_w = extras->tail_w; g.tail_out = extras->tail_out;
+        p->tile0_tail = ntiles; p->nsplit = 1; p->db = false;
+        p->halo = true; p->dense64 = false; p->half_n = false;
+        p->launch_tiles = g.plane_pair ? ntiles / 2 : ntiles;
+        p->kernel = KERN_HALO2;
+        return LISEC_OK;
+    }
     // Dense(64) and its data gradient: the resident-workgroup kernel
     if (tn.dense64 && g.pointwise && g.Cin == 64 && g.Cout == 64 && g.in_stride == 64 && g.out_stride == 64 && !g.row_coords &&
         !g.out_mask && !(flags & (LISEC_CONV_ACCUMULATE | LISEC_CONV_TAG_ROOFLINE)) && !table_stats &&
@@ -1389,7 +1453,7 @@ extern "C" int lisec_conv_forward_masked(const lisec_conv_geom* c, const float* 
                                          const float* out_mask, double* stats_partials, void* workspace,
                                          size_t workspace_bytes, const int32_t* row_coords,
                                          const int32_t* row_count, int row_capacity, lisec_stream_t stream_) {
-    lisec_conv_extras ex = {out_mask, nullptr, nullptr, 0, nullptr, nullptr};
+    lisec_conv_extras ex = {out_mask, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr};
     return lisec_conv_forward_ex(c, in, packed_w, bias, in_bnstate, flags, out, &ex, stats_partials, workspace,
                                  workspace_bytes, row_coords, row_count, row_capacity, stream_);
 }
@@ -1493,6 +1557,16 @@ extern "C" int lisec_conv_forward_ex(const lisec_conv_geom* c, const float* in, 
         if (c->mode == 0) { if (xf) LISEC_IQ(0, true); else LISEC_IQ(0, false); }
         else              { if (xf) LISEC_IQ(1, true); else LISEC_IQ(1, false); }
 #undef LISEC_IQ
+        LISEC_LAUNCH_CHECK();
+        return LISEC_OK;
+    }
+    if (g.tail_w) {                                  // one un-sliced launch of the two-line halo kernel with the tail contraction
+        dim3 grid(g.plane_pair ? p.launch_tiles : ntiles, 1, 1);
+#define LISEC_IT(M_, X_) LISEC_LAUNCH((k_igemm_halo<M_, X_, 0, 2, 64, false, true>), grid, dim3(kThreads), lds_halo, st, g, in, \
+        packed_w, bias, in_bnstate, flags, out, stats_partials, 1, (float*)nullptr, 0)
+        if (c->mode == 0) { if (xf) LISEC_IT(0, true); else LISEC_IT(0, false); }
+        else              { if (xf) LISEC_IT(1, true); else LISEC_IT(1, false); }
+#undef LISEC_IT
         LISEC_LAUNCH_CHECK();
         return LISEC_OK;
     }

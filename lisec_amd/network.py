@@ -175,6 +175,9 @@ class LisecNet:
         self.side = torch.cuda.Stream(device=dev, priority=_lib.knob("side_priority", -1))
 
         self.branch_overlap = _lib.knob("branch_overlap", True)
+        self._tail_ok = {}
+        self.mid_wgrad_first = _lib.knob("mid_wgrad_first", True)   # ring weight gradient enqueued before the block's data gradient
+        self.fuse_dense_bwd = _lib.knob("fuse_dense_bwd", True)   # Dense(64) data gradients ride on the tile of the block above
         self.chain_first = _lib.knob("chain_first", True)      # head phase: the chain's contraction is enqueued before the leaves
         self._fwd_events = {}
         self._packed_version = -1
@@ -560,6 +563,26 @@ class LisecNet:
         finally:
             _lib.pin_stream(prev_pin)
 
+    def _tail_supported(self, c, dst_name):
+        """Can the Dense data gradient of block dst_name[:-2] ride on the data gradient of conv `c`?  (asked of the library
+        once per layer: lisec_conv_plan_query refuses geometries the two-line w-halo kernel does not serve)"""
+        ok = self._tail_ok.get(c.name)
+        if ok is None:
+            n = dst_name[:-2]
+            Ln = {L["name"]: L for L in self.layers}.get(n)
+            ok = False
+            if Ln is not None and "dense" in Ln and self.dgeom[c.name].Cout == 64:
+                cn, dn = Ln["conv"], Ln["dense"]
+                try:
+                    ops.conv_plan(self.dgeom[c.name], out_mask=self.act[dst_name],
+                                  bwd=(self.act[n + ".y"], self.bnstate[cn.bn], False), sink=self._bwd_sink(cn.bn, 64, cn.M),
+                                  tail=(self.packed_t[dn.name][0], self.dact[n + ".z"]))
+                    ok = True
+                except _lib.LisecError:
+                    ok = False
+            self._tail_ok[c.name] = ok
+        return ok
+
     def _backward(self, y_cls, y_reg, loss, grad_scale, rpn_grads_ready, side_filler=None):
         self._prepare_training()
         self._pack_all_t()
@@ -673,6 +696,7 @@ class LisecNet:
         bwd_ready = {}                         # gradient buffer -> partial rows of its BN-backward statistics
 
         early_dst = {}                         # gradient buffer -> event behind a contribution made on the second stream
+        fused_dense = {}                       # middle block -> backward sink of a Dense data gradient that rode on a tile
 
         def dgrad_into(c, dy, dst_name, ws_tag="main"):
             ev = early_dst.pop(dst_name, None) if ws_tag == "main" else None
@@ -685,13 +709,24 @@ class LisecNet:
             # the LAST contribution to the gradient of a conv output also reduces the statistics its
             # BatchNormalization backward needs (pass 1 of bn_backward folded into the store)
             writes[dst_name] = writes.get(dst_name, 0) + 1
-            bwd = sink = None
+            bwd = sink = tail = None
             if dst_name in self.bn_of and writes[dst_name] == self.consumers[dst_name]:
                 bn_name, C = self.bn_of[dst_name]
                 bwd, sink = (a[dst_name], self.bnstate[bn_name], True), self._bwd_sink(bn_name, C, a[dst_name].numel() // C)
                 bwd_ready[dst_name] = sink
+            if mask is not None and self.fuse_dense_bwd and self._tail_supported(c, dst_name):
+                # the Dense(64, relu) of the block BELOW (model_training.py:195) rides on this tile: its data gradient
+                # dz = (gated gradient) @ Wd^T and the statistics of the BatchNormalization under it come out of the same
+                # launch (lisec_conv_extras.tail_w); the separate Dense data-gradient launch is skipped further down
+                n = dst_name[:-2]
+                Ln = next(L for L in self.layers if L["name"] == n)
+                cn, dn = Ln["conv"], Ln["dense"]
+                sink = self._bwd_sink(cn.bn, 64, cn.M)
+                bwd = (a[n + ".y"], self.bnstate[cn.bn], False)
+                tail = (self.packed_t[dn.name][0], d[n + ".z"])
+                fused_dense[n] = sink
             ops.conv_forward(self.dgeom[c.name], dy, self.packed_t[c.name][0], d[dst_name], flags=flags, out_mask=mask,
-                             bwd=bwd, sink=sink, ws_tag=ws_tag)
+                             bwd=bwd, sink=sink, ws_tag=ws_tag, tail=tail)
             first_write.add(dst_name)
 
         def branch_dy(L):
@@ -797,9 +832,12 @@ class LisecNet:
                 on_side(lambda n=n, dn=dn: ops.conv_wgrad(dn.g, a[n + ".y"], d[n + ".u"], p.grad_view(G, dn.wname),
                                                           self.wgrad_ws, in_bn=self.bnstate[dn.in_bn]))
                 # Dense data gradient; its store also reduces the statistics of the BatchNormalization under it
-                msink = self._bwd_sink(c.bn, 64, c.M)
-                ops.conv_forward(self.dgeom[dn.name], d[n + ".u"], self.packed_t[dn.name][0], d[n + ".z"],
-                                 bwd=(a[n + ".y"], self.bnstate[c.bn], False), sink=msink)
+                if n in fused_dense:
+                    msink = fused_dense.pop(n)         # done inside the data gradient of the block above (dgrad_into)
+                else:
+                    msink = self._bwd_sink(c.bn, 64, c.M)
+                    ops.conv_forward(self.dgeom[dn.name], d[n + ".u"], self.packed_t[dn.name][0], d[n + ".z"],
+                                     bwd=(a[n + ".y"], self.bnstate[c.bn], False), sink=msink)
                 if L["src"] != "grid":
                     ops.bn_backward_apply_coef(d[n + ".z"], 64, a[n + ".y"], self.bnstate[c.bn], c.M, 64, False, msink.coef,
                                                d[n + ".z"])
@@ -828,9 +866,14 @@ class LisecNet:
                     # on their own and run slower side by side than one after the other (mid2: 800 us together,
                     # 333 + 358 alone); behind the data gradient the weight gradient shares the chip with the
                     # short kernels of the rest of the chain instead
-                    dgrad_into(c, d[n + ".z"], L["src"])
-                    on_side(lambda L=L, c=c, n=n: ops.conv_wgrad(c.g, a[L["src"]], d[n + ".z"],
-                                                                 p.grad_view(G, c.wname), self.wgrad_ws))
+                    wg = lambda L=L, c=c, n=n: ops.conv_wgrad(c.g, a[L["src"]], d[n + ".z"], p.grad_view(G, c.wname),
+                                                              self.wgrad_ws)
+                    if self.mid_wgrad_first:
+                        on_side(wg)
+                        dgrad_into(c, d[n + ".z"], L["src"])
+                    else:
+                        dgrad_into(c, d[n + ".z"], L["src"])
+                        on_side(wg)
         # ---- VFE -----------------------------------------------------------------------------------
         flush_side()
         self.vfe.backward(None, G, dout_rows=self.dout_rows, g_all=self.g_all)

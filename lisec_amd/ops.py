@@ -134,19 +134,22 @@ class BnSink:
 
 
 def conv_forward(g, x, wp, out, bias=None, in_bn=None, flags=0, stats=None, splitk=True, rows=None, out_mask=None,
-                 bwd=None, sink=None, ws_tag="main", queue=None):
+                 bwd=None, sink=None, ws_tag="main", queue=None, tail=None):
     """rows: optional (row_coords int32 (cap,3), row_count int32 device scalar, capacity) row list.
     out_mask: optional tensor laid out like `out`; values are stored as 0 where out_mask <= 0.
     bwd: optional (y, bnstate, relu): `out` is a gradient about to cross that BatchNormalization(+ReLU) backwards and
     `stats` (num_mblocks_bwd(g) rows) receives the per-tile (sum dz, sum dz*yhat) -- see bn_backward_apply.
     sink: optional BnSink taking the per-tile sums instead of `stats` (finalised inside the call).
     queue: optional int32[2] device tensor, zero before its first use: lets a big row list run as resident workgroups
-    that draw their tiles from a counter (lisec_conv_extras.queue)."""
+    that draw their tiles from a counter (lisec_conv_extras.queue).
+    tail: optional (packed 64 x 64 kernel, out2): out2 = out (as stored) @ kernel rides on the tile; bwd / sink then describe
+    out2 (lisec_conv_extras.tail_w)."""
     rc, rn, cap = rows if rows is not None else (None, None, 0)
     ws = conv_workspace(g, out.device, cap, ws_tag) if splitk else None
     ex = _lib.ConvExtras(_lib.ptr(out_mask), _lib.ptr(bwd[0]) if bwd is not None else None,
                          _lib.ptr(bwd[1]) if bwd is not None else None, 1 if (bwd is not None and bwd[2]) else 0,
-                         sink.ref if sink is not None else None, _lib.ptr(queue))
+                         sink.ref if sink is not None else None, _lib.ptr(queue),
+                         _lib.ptr(tail[0]) if tail is not None else None, _lib.ptr(tail[1]) if tail is not None else None)
     _lib.check(_lib.load().lisec_conv_forward_ex(ctypes.byref(g), _lib.ptr(x), _lib.ptr(wp), _lib.ptr(bias),
                                                  _lib.ptr(in_bn), flags, _lib.ptr(out), ctypes.byref(ex),
                                                  _lib.ptr(stats), _lib.ptr(ws),
@@ -156,7 +159,7 @@ def conv_forward(g, x, wp, out, bias=None, in_bn=None, flags=0, stats=None, spli
 
 
 def conv_plan(g, in_bn=False, flags=0, stats=False, splitk=True, rows_capacity=0, out_mask=None, bwd=None, sink=None,
-              queue=None):
+              queue=None, tail=None):
     """The launch plan conv_forward(...) with the same arguments runs (lisec_conv_plan_query), as a dict."""
     lib = _lib.load()
     ws_bytes = 0
@@ -165,7 +168,8 @@ def conv_plan(g, in_bn=False, flags=0, stats=False, splitk=True, rows_capacity=0
                     else lib.lisec_conv_forward_workspace_bytes(ctypes.byref(g)))
     ex = _lib.ConvExtras(_lib.ptr(out_mask), _lib.ptr(bwd[0]) if bwd is not None else None,
                          _lib.ptr(bwd[1]) if bwd is not None else None, 1 if (bwd is not None and bwd[2]) else 0,
-                         sink.ref if sink is not None else None, _lib.ptr(queue))
+                         sink.ref if sink is not None else None, _lib.ptr(queue),
+                         _lib.ptr(tail[0]) if tail is not None else None, _lib.ptr(tail[1]) if tail is not None else None)
     plan = _lib.ConvPlan()
     _lib.check(lib.lisec_conv_plan_query(ctypes.byref(g), 1 if in_bn else 0, flags, ctypes.byref(ex), 1 if stats else 0,
                                          ws_bytes, 1 if rows_capacity > 0 else 0, rows_capacity, ctypes.byref(plan)))

@@ -183,6 +183,50 @@ def test_data_gradient(case):
         assert np.abs(coef[:cout] - db / M).max() <= tol_s / M and np.abs(coef[cout:] - dg / M).max() <= 3 * tol_s / M, name
 
 
+@pytest.mark.parametrize("case", [c for c in DGRAD if c[0] in ("mid2", "mid3")], ids=["mid2", "mid3"])
+def test_data_gradient_with_dense_tail(case):
+    """The Dense(64, relu) data gradient of the block below riding on the tile (lisec_conv_extras.tail_w,
+    model_training.py:195 backwards): out = gate(dy (*) W^T), out2 = out @ Wd^T, and (sum dz, sum dz*yhat) of out2 for the
+    BatchNormalization under the Dense -- against the two separate steps in fp64."""
+    from lisec_amd import ops
+    from oracle import conv_ref
+    name, mode, ind, outd, k, s, p, cin, cout, kind, expect = case
+    dev = torch.device("cuda")
+    rng = np.random.default_rng(seed_of("tail" + name))
+    ntaps = k[0] * k[1] * k[2]
+    dy = rng.normal(0, 1, (*ind, cin)).astype(np.float32)
+    Wt = (rng.normal(0, 1, (ntaps, cin, cout)) / np.sqrt(ntaps * cin)).astype(np.float32)
+    Wd = (rng.normal(0, 1, (1, 64, 64)) / 8).astype(np.float32)          # the tail kernel as the contraction sees it: (c, j)
+    M = outd[0] * outd[1] * outd[2]
+    g = ops.geom(mode, ind, outd, k, s, p, cin, cout)
+    wp = ops.pack_weights(torch.from_numpy(Wt).to(dev), ntaps, cin, cout, cin * cout, cout, 1)
+    wdp = ops.pack_weights(torch.from_numpy(Wd).to(dev), 1, 64, 64, 0, 64, 1)
+    act = rng.normal(0, 1, (*outd, cout)).astype(np.float32)
+    y = rng.normal(0, 1, (*outd, 64)).astype(np.float32)
+    st_dev, _ = make_bn(rng, 64, dev)
+    st = st_dev.cpu().numpy().astype(np.float64)
+    dgamma, dbeta = torch.zeros(64, device=dev), torch.zeros(64, device=dev)
+    sink = ops.BnSink(64, M, dev, dgamma=dgamma, dbeta=dbeta)
+    out = torch.full((*outd, cout), float("nan"), device=dev)
+    out2 = torch.full((*outd, 64), float("nan"), device=dev)
+    kw = dict(out_mask=torch.from_numpy(act).to(dev), bwd=(torch.from_numpy(y).to(dev), st_dev, False), sink=sink,
+              tail=(wdp, out2))
+    check_plan(ops.conv_plan(g, **kw), dict(kernel="halo2", cols=64, k_slices=1, workgroups=1250))
+    for rep in range(2):                                  # twice: the sink must come back to zero
+        ops.conv_forward(g, torch.from_numpy(dy).to(dev), wp, out, **kw)
+        torch.cuda.synchronize()
+        ref = np.where(act > 0, conv_ref.conv_forward(dy, Wt, outd, k, s, p, mode=mode), 0.0)
+        assert rel_l2(out.cpu().numpy(), ref, note="data gradient with tail " + name) <= TOL
+        ref2 = ref.reshape(M, 64) @ Wd[0].astype(np.float64)
+        assert rel_l2(out2.cpu().numpy(), ref2, note="dense tail " + name) <= TOL
+        yhat = (y.astype(np.float64).reshape(M, 64) - st[128:192]) * st[192:]
+        db, dg = ref2.sum(0), (ref2 * yhat).sum(0)
+        tol_s = 3e-6 * np.sqrt(M) * np.abs(ref2).max()
+        assert np.abs(dbeta.cpu().numpy() - db).max() <= tol_s and np.abs(dgamma.cpu().numpy() - dg).max() <= 4 * tol_s, name
+        coef = sink.coef.cpu().numpy().astype(np.float64)
+        assert np.abs(coef[:64] - db / M).max() <= tol_s / M and np.abs(coef[64:] - dg / M).max() <= 4 * tol_s / M, name
+
+
 # weight gradients: name, mode, in dims, out dims, kernel, stride, pad, cin, cout, BN+ReLU on load, transpose_out, plan
 WGRAD = [
     ("mid1 dense form", 0, (8, H, W), (4, H, W), (3, 3, 3), (2, 1, 1), (1, 1, 1), 64, 64, False, False,
