@@ -288,16 +288,16 @@ def main():
     allreduce = dp.bucketed() if dp is not None else None
     # One GPU: the whole step (voxelise + forward + backward + SGD + the repack for the next step) is recorded once as a
     # step plan of the C ABI and re-issued by ONE call per step (lisec_step_plan_run: the eager launches on the same two
-    # streams, without the Python schedule in front of each of them).  LISEC_TUNING=step_plan=0, and every data-parallel
-    # run, issue each step from the Python schedule.
+    # streams, without the Python schedule in front of each of them) -- with N > 1 ranks too: the two-bucket gradient
+    # exchange is part of the recorded schedule.  LISEC_TUNING=step_plan=0 issues each step from the Python schedule.
     from lisec_amd import _lib
-    use_plan = dp is None and _lib.knob("step_plan", True)
+    use_plan = _lib.knob("step_plan", True)       # data parallel too: the gradient exchange is part of the recorded schedule
 
     if use_plan and _lib.knob("pipeline_voxels", True):
         # ... with the NEXT sweep's voxelisation inside the step (second stream, under the backward pass): every step still
         # voxelises one sweep and trains on one
         from lisec_amd.network import PipelinedStep
-        captured = PipelinedStep(net, vox, len(cloud), dtype=pts.dtype, loss=args.loss)
+        captured = PipelinedStep(net, vox, len(cloud), dtype=pts.dtype, loss=args.loss, allreduce=allreduce)
         captured.prime(pts, ycls, yreg)         # inputs resident in HBM before the timed region, as in the eager path
         captured.stage_next(pts, ycls, yreg)
         captured.step()
@@ -305,7 +305,7 @@ def main():
         step = captured.step
     elif use_plan:
         from lisec_amd.network import RecordedStep
-        captured = RecordedStep(net, vox, len(cloud), dtype=pts.dtype, loss=args.loss)
+        captured = RecordedStep(net, vox, len(cloud), dtype=pts.dtype, loss=args.loss, allreduce=allreduce)
         captured.load(pts, ycls, yreg)          # inputs resident in HBM before the timed region, as in the eager path
         step = captured.replay
     else:

@@ -626,11 +626,17 @@ int lisec_step_plan_begin(lisec_step_plan_t plan);
 int lisec_step_plan_end(lisec_step_plan_t plan);
 int lisec_step_plan_run(lisec_step_plan_t plan);
 int lisec_step_plan_size(lisec_step_plan_t plan);    /* recorded operations, -1 for NULL */
+int lisec_step_plan_recording(void);                  /* 1 while the calling thread records a plan */
 int lisec_step_plan_destroy(lisec_step_plan_t plan);
 /* hipEventRecord(event, stream) / hipStreamWaitEvent(stream, event, 0) through the library, so that a recording plan sees
  * the fork / join edges between the streams of a step; event: a hipEvent_t the caller made. */
 int lisec_event_record(void* event, lisec_stream_t stream);
 int lisec_stream_wait_event(lisec_stream_t stream, void* event);
+/* A host function as a step of the plan: fn(arg) runs now and, when the calling thread is recording, again at this place of
+ * the sequence in every lisec_step_plan_run (0 = success).  For work between a step's launches that is not a launch of
+ * this library -- the data-parallel gradient exchange when it goes through torch.distributed (gloo) instead of
+ * lisec_allreduce_grads, which records itself. */
+int lisec_step_plan_host_call(int (*fn)(void*), void* arg);
 
 /* ------------------------------------------------------------------------------------------
  * 6. Launch-plan tuning and diagnostics.  Not needed by a caller of the hot path: the defaults are the measured

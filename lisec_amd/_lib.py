@@ -86,6 +86,8 @@ class WgradItem(Structure):                    # lisec_wgrad_item
                 ("transpose_out", c_int), ("dW", c_void_p)]
 
 
+HOST_CALL = ctypes.CFUNCTYPE(c_int, c_void_p)    # int (*)(void*): lisec_step_plan_host_call
+
 ROW_STATS_REPLICAS = 16                       # LISEC_ROW_STATS_* of include/lisec_hip.h
 ROW_STATS_MOMENT_WORDS = ROW_STATS_REPLICAS * 27 * 2
 ROW_STATS_WORDS = ROW_STATS_MOMENT_WORDS + 4 * 64 * 2
@@ -217,6 +219,10 @@ def _declare(lib):
                  "lisec_step_plan_destroy"):
         getattr(lib, name).restype = c_int
         getattr(lib, name).argtypes = [P]
+    lib.lisec_step_plan_recording.restype = c_int
+    lib.lisec_step_plan_recording.argtypes = []
+    lib.lisec_step_plan_host_call.restype = c_int
+    lib.lisec_step_plan_host_call.argtypes = [HOST_CALL, P]
     lib.lisec_event_record.restype = c_int
     lib.lisec_event_record.argtypes = [P, P]
     lib.lisec_stream_wait_event.restype = c_int
@@ -268,6 +274,21 @@ def load():
             set_tuning(**{k.strip(): int(v) for k, v in (kv.split("=") for kv in spec.split(",") if kv.strip())
                           if k.strip() in dict(Tuning._fields_)})
     return _lib
+
+
+# Grow-on-demand device buffers (VFE saved state / backward scratch, field workspace, weight-gradient scratch, row-list
+# gradient rows, split-K scratch, voxeliser scratch) are reallocated by ordinary eager calls; a recorded step plan
+# (lisec_step_plan_*) holds their RAW addresses.  Every reallocation bumps this counter; a plan remembers the value it was
+# recorded under and refuses to replay (network.StalePlanError) / is re-recorded (Model._captured_step) once it differs.
+_ALLOC_GEN = [0]
+
+
+def alloc_generation():
+    return _ALLOC_GEN[0]
+
+
+def bump_alloc_generation():
+    _ALLOC_GEN[0] += 1
 
 
 def knob(name, default):
@@ -364,6 +385,49 @@ def _hiprt():
         _hip.hipEventCreateWithFlags.argtypes = [POINTER(c_void_p), ctypes.c_uint]
         _hip.hipEventDestroy.argtypes = [c_void_p]
     return _hip
+
+
+def stream_priority_range():
+    """(least, greatest) stream priority of the current device (hipDeviceGetStreamPriorityRange): numerically lower = higher."""
+    lo, hi = c_int(0), c_int(0)
+    rc = _hiprt().hipDeviceGetStreamPriorityRange(ctypes.byref(lo), ctypes.byref(hi))
+    if rc != 0:
+        raise LisecError(f"hipDeviceGetStreamPriorityRange failed ({rc})")
+    return lo.value, hi.value
+
+
+def create_stream(priority):
+    """A non-blocking HIP stream at `priority` (hipStreamCreateWithPriority); returns the raw handle (int)."""
+    h = c_void_p()
+    rc = _hiprt().hipStreamCreateWithPriority(ctypes.byref(h), ctypes.c_uint(1), c_int(priority))   # 1 = hipStreamNonBlocking
+    if rc != 0:
+        raise LisecError(f"hipStreamCreateWithPriority failed ({rc})")
+    return h.value
+
+
+_HOST_CALLS = []      # ctypes trampolines of recorded host calls: a plan may call them for as long as the process lives
+
+
+def host_call(fn):
+    """Runs fn() now and, if this thread is recording a step plan, at this place of the sequence in every replay
+    (lisec_step_plan_host_call).  Exceptions inside a replayed call are reported as a failed step."""
+    if not load().lisec_step_plan_recording():
+        fn()                                        # nothing records: no trampoline to keep alive
+        return
+    err = []
+
+    def tramp(_arg):
+        try:
+            fn()
+            return 0
+        except Exception as e:                      # noqa: BLE001 -- must not unwind through the C frame
+            err.append(e)
+            return 1
+    cb = HOST_CALL(tramp)
+    _HOST_CALLS.append(cb)
+    rc = load().lisec_step_plan_host_call(cb, None)
+    if rc != 0:
+        raise (err[-1] if err else LisecError(load().lisec_last_error().decode()))
 
 
 class DeviceEvent:

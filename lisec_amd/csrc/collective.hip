@@ -123,6 +123,14 @@ extern "C" int lisec_allreduce_grads(lisec_comm_t comm, float* grad, long long n
                     "size, -d = explicit divisor d)", world, count);
     world = world < 0 ? -world : count;
     if (n == 0) return LISEC_OK;
+    if (StepPlan* plan = plan_recording()) {
+        // part of a recorded step (lisec_step_plan_*): the collective is re-issued at this place of the sequence by every
+        // replay -- all ranks record and replay the same schedule, so RCCL sees the same order of collectives everywhere
+        auto fn = rccl().AllReduce;
+        const ncclComm_t c = static_cast<ncclComm_t>(comm);
+        const hipStream_t st = static_cast<hipStream_t>(stream);
+        plan_append(plan, [=]() { return fn(grad, grad, (size_t)n, ncclFloat, ncclSum, c, st) == ncclSuccess ? hipSuccess : hipErrorUnknown; });
+    }
     LISEC_RCCL_TRY(rccl().AllReduce(grad, grad, (size_t)n, ncclFloat, ncclSum, static_cast<ncclComm_t>(comm),
                                     static_cast<hipStream_t>(stream)));
     if (world > 1) return lisec_scale(grad, n, 1.0f / (float)world, stream);

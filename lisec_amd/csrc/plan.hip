@@ -61,6 +61,8 @@ extern "C" int lisec_step_plan_end(lisec_step_plan_t plan) {
     return LISEC_OK;
 }
 
+extern "C" int lisec_step_plan_recording(void) { return t_recording ? 1 : 0; }
+
 extern "C" int lisec_step_plan_size(lisec_step_plan_t plan) {
     StepPlan* p = static_cast<StepPlan*>(plan);
     return p ? (int)p->ops.size() : -1;
@@ -95,5 +97,19 @@ extern "C" int lisec_stream_wait_event(lisec_stream_t stream, void* event) {
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (StepPlan* p = plan_recording()) plan_append(p, [=]() { return hipStreamWaitEvent(st, ev, 0); });
     LISEC_HIP_TRY(hipStreamWaitEvent(st, ev, 0));
+    return LISEC_OK;
+}
+
+// A host function as a step of the plan: executed now, and -- when the calling thread is recording -- re-executed by
+// lisec_step_plan_run at the same place in the sequence.  For work that a step needs between its launches and that is
+// not a launch of this library: a gradient exchange issued through another runtime (torch.distributed over gloo), a
+// host-side hand-off.  fn returns 0 on success; any other value stops the run with LISEC_EHIP.
+extern "C" int lisec_step_plan_host_call(int (*fn)(void*), void* arg) {
+    LISEC_CHECK_ARG(fn, "NULL host function");
+    if (StepPlan* p = plan_recording()) plan_append(p, [=]() { return fn(arg) == 0 ? hipSuccess : hipErrorUnknown; });
+    if (fn(arg) != 0) {
+        set_error("step plan: host call failed");
+        return LISEC_EHIP;
+    }
     return LISEC_OK;
 }

@@ -360,8 +360,9 @@ class Model:
     def _captured_step(self, samples):
         """The recorded form of the step (lisec_amd.network.RecordedStep: the eager schedule re-issued by
         lisec_step_plan_run, one C call per step), when it applies: one GPU, every sample a voxelised sweep that still
-        holds its device points, one grid.  Otherwise (None) the Python schedule issues every step."""
-        if self.dp is not None or not _lib.knob("step_plan", True) or not samples:
+        holds its device points, one grid (data parallel included: the gradient exchange is recorded with the step).
+        Otherwise (None) the Python schedule issues every step."""
+        if not _lib.knob("step_plan", True) or not samples:
             return None
         pts = [getattr(s, "_keepalive", None) for s in samples]
         if any(p is None or not p.is_cuda for p in pts):
@@ -377,14 +378,17 @@ class Model:
         o = self.optimizer
         key = (key0, dtype, self.loss, o.lr, o.decay, o.momentum, id(self.net), torch.cuda.current_stream().cuda_stream)
         cur = getattr(self, "_captured", None)
-        if cur is not None and cur[0] == key and cur[1].capacity >= need:
+        if cur is not None and cur[0] == key and cur[1].capacity >= need and cur[1].alloc_gen == _lib.alloc_generation():
             return cur[1]
         if cur is not None:
-            cur[1].close()                    # another grid / optimizer / network: the old plan points at dead buffers
+            # another grid / optimizer / network -- or an eager call since (predict() on a larger sweep, a second model)
+            # reallocated a workspace the plan holds the raw address of: the old plan points at dead buffers
+            cur[1].close()
         from .network import RecordedStep, PipelinedStep
         capacity = max(1024, -(-need // 4096) * 4096)        # a little head-room: later fits reuse the plan
         step = (PipelinedStep if _lib.knob("pipeline_voxels", True) else RecordedStep)(self.net, Voxelizer(*key0[:3], key0[3], *key0[4:], device=self.net.device), capacity,
-                            dtype=dtype, loss=self.loss, lr=o.lr, decay=o.decay, momentum=o.momentum)
+                            dtype=dtype, loss=self.loss, lr=o.lr, decay=o.decay, momentum=o.momentum,
+                            allreduce=self.dp.bucketed() if self.dp is not None else None)
         self._captured = (key, step)
         return step
 

@@ -335,6 +335,7 @@ class LisecNet:
             need = ops.conv_field_forward_workspace_bytes(first.g, sample.cap)
             if self.field_ws is None or self.field_ws.numel() < need:
                 self.field_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+                _lib.bump_alloc_generation()       # recorded step plans hold the old address
             self.vfe.forward(sample, training, dense=False)
         else:
             self.vfe.forward(sample, training, out=self.dense_grid(rewrite=False))
@@ -597,6 +598,7 @@ class LisecNet:
             if need > self.wgrad_ws.numel():
                 self.wgrad_ws = torch.zeros(need, dtype=torch.uint8, device=self.device)
             self.dout_rows = torch.empty((sample.cap + 1, 64), dtype=torch.float32, device=self.device)
+            _lib.bump_alloc_generation()           # recorded step plans hold the old addresses
         main = torch.cuda.current_stream()
 
         side_handle = self.side.cuda_stream
@@ -922,6 +924,34 @@ class LisecNet:
         return self.loss_out
 
 
+class StalePlanError(RuntimeError):
+    """A recorded step plan holds raw addresses of buffers that an eager call has since reallocated."""
+
+
+def _check_plan_fresh(step):
+    if step.alloc_gen != _lib.alloc_generation():
+        raise StalePlanError(
+            "this step plan was recorded before a workspace of the network / VFE / voxeliser was reallocated (an eager "
+            "call on a larger sweep or grid): replaying it would write through freed addresses.  Record a new one "
+            "(Model.fit does so by itself).")
+
+
+def _sync_packed(net):
+    """The recorded forward contains no repack (the previous step's update left one pending).  If the variables were
+    changed since (params.load_dict / touch, an eager step), repack them now on the replay stream and re-arm the two events
+    the recorded forward waits for."""
+    cur = (net.params_version, net.params.version)
+    if net._packed_version != cur or net._packed_t_version != cur or not getattr(net, "_pack_pending", False):
+        net._pack_pending = False
+        net._late_pending = False
+        net._pack_all()
+        net._pack_all_t()
+        net._record(net._pack_done, torch.cuda.current_stream())
+        net._record(net._pack_late, torch.cuda.current_stream())
+        net._pack_pending = True
+        net._late_pending = True
+
+
 class RecordedStep:
     """One whole fit() step -- voxelise, forward, backward (both streams, fork / join events included), SGD-Nesterov, the
     weight repack for the next step -- recorded ONCE as a step plan of the C ABI (lisec_step_plan_*, csrc/plan.hip) and
@@ -936,15 +966,19 @@ class RecordedStep:
       targets  (Ho,Wo,2) / (Ho,Wo,14) static buffers
       lr_t     derived by the SGD kernel from the device iteration counter (lisec_sgd_nesterov_step_dev)
 
-    Record and replay on ONE torch stream (the current stream at construction).  Single-GPU: the data-parallel step keeps
-    the Python schedule (its gradient exchange is issued from torch hooks)."""
+    Record and replay on ONE torch stream (the current stream at construction).  Data parallel (allreduce=): the gradient
+    exchange is part of the plan."""
 
     PAD = 1.0e6          # metres: floor(1e6 / 0.5) is far beyond maxVoxelX, the point is dropped like any other outlier
 
     def __init__(self, net, voxelizer, capacity, dtype=torch.float32, loss="mse", lr=0.01, decay=1e-6, momentum=0.9,
-                 warmup=2):
+                 warmup=2, allreduce=None):
         import ctypes
         self.net, self.vox, self.capacity, self.loss = net, voxelizer, int(capacity), loss
+        # data parallel: the two-bucket gradient exchange (parallel._BucketedAverage) is part of the recorded schedule --
+        # lisec_allreduce_grads and its event edges record themselves, a torch.distributed exchange rides as host calls.
+        # Every rank records and replays the same sequence (the warm-up and recording steps exchange gradients for real).
+        self.allreduce = allreduce
         dev = net.device
         self.lib = _lib.load()
         self.points = torch.full((self.capacity, 3), self.PAD, dtype=dtype, device=dev)
@@ -985,12 +1019,21 @@ class RecordedStep:
         net._pack_pending = True
         net._late_pending = True
         torch.cuda.synchronize(dev)
+        self.alloc_gen = _lib.alloc_generation()
 
     def _enqueue(self):
         net = self.net
         self.sample = self.vox(self.points, out=self.sample)
         net.forward(self.sample, training=True)
-        net.backward(self.ycls, self.yreg, loss=self.loss)
+        ar = self.allreduce
+        if ar is not None and hasattr(ar, "start_tail"):
+            net.backward(self.ycls, self.yreg, loss=self.loss,
+                         rpn_grads_ready=lambda lo, hi: ar.start_tail(net.grad, lo, hi))
+            ar.finish(net.grad)
+        else:
+            net.backward(self.ycls, self.yreg, loss=self.loss)
+            if ar is not None:
+                ar(net.grad)
         net.apply_gradients(*self.hyper)
 
     def _check_stream(self):
@@ -1013,7 +1056,9 @@ class RecordedStep:
     def replay(self):
         """Runs the recorded step on what load() staged; returns net.loss_out (device, [total, class, regression])."""
         self._check_stream()
+        _check_plan_fresh(self)
         net = self.net
+        _sync_packed(net)
         _lib.check(self.lib.lisec_step_plan_run(self.plan))
         net._iterations += 1
         net.params_version += 1          # theta moved; the recorded step also repacked it for the next one
@@ -1057,9 +1102,10 @@ class PipelinedStep:
     PAD = RecordedStep.PAD
 
     def __init__(self, net, voxelizer, capacity, dtype=torch.float32, loss="mse", lr=0.01, decay=1e-6, momentum=0.9,
-                 warmup=2):
+                 warmup=2, allreduce=None):
         import ctypes
         self.net, self.vox, self.capacity, self.loss = net, voxelizer, int(capacity), loss
+        self.allreduce = allreduce                 # data parallel: see RecordedStep
         dev = net.device
         self.lib = _lib.load()
         self.points = [torch.full((self.capacity, 3), self.PAD, dtype=dtype, device=dev) for _ in range(2)]
@@ -1101,12 +1147,21 @@ class PipelinedStep:
         net._late_pending = True
         self.cur = 0
         torch.cuda.synchronize(dev)
+        self.alloc_gen = _lib.alloc_generation()
 
     def _enqueue(self, j):
         net = self.net
         net.forward(self.samples[j], training=True)
-        net.backward(self.ycls[j], self.yreg[j], loss=self.loss,
-                     side_filler=lambda: self.vox(self.points[1 - j], out=self.samples[1 - j]))
+        filler = lambda: self.vox(self.points[1 - j], out=self.samples[1 - j])
+        ar = self.allreduce
+        if ar is not None and hasattr(ar, "start_tail"):
+            net.backward(self.ycls[j], self.yreg[j], loss=self.loss, side_filler=filler,
+                         rpn_grads_ready=lambda lo, hi: ar.start_tail(net.grad, lo, hi))
+            ar.finish(net.grad)
+        else:
+            net.backward(self.ycls[j], self.yreg[j], loss=self.loss, side_filler=filler)
+            if ar is not None:
+                ar(net.grad)
         net.apply_gradients(*self.hyper)
 
     def _check_stream(self):
@@ -1140,7 +1195,9 @@ class PipelinedStep:
         self._check_stream()
         if next_points is not None:
             self._load(1 - self.cur, next_points, next_ycls, next_yreg)
+        _check_plan_fresh(self)
         net = self.net
+        _sync_packed(net)
         _lib.check(self.lib.lisec_step_plan_run(self.plans[self.cur]))
         net._iterations += 1
         net.params_version += 1

@@ -109,6 +109,7 @@ def conv_workspace(g, device, row_capacity=0, tag="main"):
         if key in _SPLITK_WS:
             torch.cuda.synchronize(device)          # a call on another stream may still be using the old buffer
         _SPLITK_WS[key] = torch.zeros(need, dtype=torch.uint8, device=device)
+        _lib.bump_alloc_generation()                # recorded step plans hold the old address
     return _SPLITK_WS[key]
 
 

@@ -50,6 +50,7 @@ class VFEStack:
                 else self.lib.lisec_vfe_saved_floats(sample.cap))
         if self._saved is None or self._saved.numel() < need:
             self._saved = torch.empty(need, dtype=torch.float32, device=self.device)
+            _lib.bump_alloc_generation()           # recorded step plans hold the old address
         self._saved_rows = rows_cap
         grid = None
         if dense:
@@ -87,6 +88,7 @@ class VFEStack:
         need = self.lib.lisec_vfe_backward_workspace_bytes(sample.cap, sample.n_points)
         if getattr(self, "_bws", None) is None or self._bws.numel() < need:
             self._bws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            _lib.bump_alloc_generation()
         g = VfeGrads()
         for i, n in enumerate(VFE_LAYERS):
             g.kernel[i] = p.ptr(f"{n}.dense.kernel", grad).value

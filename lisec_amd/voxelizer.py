@@ -105,6 +105,7 @@ class Voxelizer:
             raise _lib.LisecError("invalid voxel grid configuration: " + self.lib.lisec_last_error().decode())
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            _lib.bump_alloc_generation()           # recorded step plans hold the old address
         return self._ws
 
     def __call__(self, points, out=None):

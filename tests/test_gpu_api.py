@@ -250,3 +250,61 @@ def test_recorded_step_equals_eager_steps():
     t_u, s_u, l_u, _ = run(False, pad=False)
     assert np.allclose(l_u, l_e, rtol=1e-6) and np.allclose(t_u, t_e, rtol=1e-4, atol=1e-6)
     assert np.allclose(s_u, s_e, rtol=1e-5, atol=1e-7)
+
+
+def test_step_plan_survives_a_larger_eager_sweep():
+    """fit -> predict on a sweep LARGER than the recorded capacity (the VFE / field / row-list scratch is reallocated by the
+    eager call) -> fit again: the cached step plan holds raw addresses of the old buffers, so it must be re-recorded, not
+    replayed into freed memory -- and a plan replayed by hand after such a reallocation refuses.  Variables bit-identical to
+    the Python schedule throughout."""
+    import torch
+    from lisec_amd import _lib, model_training as mt
+    from lisec_amd.network import RecordedStep, StalePlanError
+    from lisec_amd.params import ParamStore
+    from lisec_amd.voxelizer import Voxelizer
+    dev = torch.device("cuda")
+    rng = np.random.default_rng(11)
+    cfgk = (0.5, 0.25, 0.25, 35, 8, 16, 8)
+
+    def cloud(n):
+        return np.stack([rng.uniform(-4.2, 4.2, n), rng.uniform(-4.2, 4.2, n), rng.uniform(0.0, 2.1, n)], 1).astype(np.float32)
+    small = [cloud(900), cloud(700)]
+    big = cloud(9000)
+    ys = [(rng.integers(0, 3, (8, 16, 2)).astype(np.float32), rng.normal(0, 1, (8, 16, 14)).astype(np.float32)) for _ in small]
+    init = ParamStore(dev).to_dict()
+
+    def run(step_plan):
+        os.environ["LISEC_TUNING"] = "step_plan=%d" % (1 if step_plan else 0)
+        try:
+            model = mt.createModel(16, 32, 8, 35)
+            model.net.params.load_dict(init)
+            model.compile(optimizer=mt.optimizers.SGD(lr=0.01, decay=1e-6, momentum=0.9, nesterov=True), loss=["mse", "mse"])
+            vox = Voxelizer(*cfgk[:3], cfgk[3], *cfgk[4:])
+            # the plan pads every sweep into its 4096-point buffer (dropped by the voxeliser's range test); the Python
+            # schedule gets the same padded sweeps, because the row-list kernels plan their K slices per capacity
+            def padded(c):
+                out = np.full((4096, 3), RecordedStep.PAD, np.float32)
+                out[:len(c)] = c
+                return out
+            samples = [vox(torch.from_numpy(c if step_plan else padded(c)).to(dev)) for c in small]
+            ycls = np.stack([y[0] for y in ys]); yreg = np.stack([y[1] for y in ys])
+            model.fit(samples, y=[ycls, yreg], batch_size=1, epochs=1, steps_per_epoch=2, verbose=0, shuffle=False)
+            gen0 = _lib.alloc_generation()
+            plan0 = getattr(model, "_captured", None)
+            out = model.predict([vox(torch.from_numpy(big).to(dev))])         # 10x the points: scratch grows
+            if step_plan:
+                assert plan0 is not None and _lib.alloc_generation() != gen0, "the larger sweep must have reallocated scratch"
+                with pytest.raises(StalePlanError):
+                    plan0[1].replay() if isinstance(plan0[1], RecordedStep) else plan0[1].step()
+            model.fit(samples, y=[ycls, yreg], batch_size=1, epochs=1, steps_per_epoch=2, verbose=0, shuffle=False)
+            if step_plan:
+                assert model._captured[1] is not plan0[1], "the stale plan must have been replaced"
+            torch.cuda.synchronize()
+            return model.net.params.theta.cpu().numpy().copy(), model.net.params.state.cpu().numpy().copy(), out[0]
+        finally:
+            os.environ.pop("LISEC_TUNING", None)
+
+    t_e, s_e, o_e = run(False)
+    t_p, s_p, o_p = run(True)
+    assert np.array_equal(o_e, o_p)
+    assert np.array_equal(t_e, t_p) and np.array_equal(s_e, s_p)

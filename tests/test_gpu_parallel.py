@@ -24,19 +24,31 @@ def _targets(seed):
     return rng.integers(0, 3, (8, 16, 2)).astype(np.float32), rng.normal(0, 1, (8, 16, 14)).astype(np.float32)
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, step_plan=True):
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
-                      MASTER_PORT=str(port), LISEC_DIST_BACKEND="gloo", LISEC_BENCH_DEVICE="0")   # both ranks on cuda:0
+                      MASTER_PORT=str(port), LISEC_DIST_BACKEND="gloo", LISEC_BENCH_DEVICE="0",   # both ranks on cuda:0
+                      LISEC_TUNING="step_plan=%d" % (1 if step_plan else 0))
     from lisec_amd import model_training as mt
     np.random.seed(0)
     model = mt.createModel(16, 32, 8, 35)                 # WORLD_SIZE=2 -> DataParallel inside, params broadcast
     assert model.dp is not None and model.dp.world == 2
     model.compile(optimizer=mt.optimizers.SGD(lr=0.01, decay=1e-6, momentum=0.9, nesterov=True), loss=['mse', 'mse'])
-    samples = [mt.VFE_preprocessing(_cloud(s), **SMALL) for s in range(4)]
+    def cloud(s):
+        # the plan pads every sweep into its 4096-point buffer with points the voxeliser drops; the Python schedule gets
+        # the same padded sweeps (the row-list kernels plan their K slices per capacity: same summation order)
+        c = _cloud(s)
+        if step_plan:
+            return c
+        out = np.full((4096, 3), 1.0e6, np.float32)
+        out[:len(c)] = c
+        return out
+    samples = [mt.VFE_preprocessing(cloud(s), **SMALL) for s in range(4)]
     ys = [_targets(s) for s in range(4)]
     model.fit(x=samples, y=[np.stack([y[0] for y in ys]), np.stack([y[1] for y in ys])], batch_size=1, verbose=0,
               epochs=1, steps_per_epoch=4, shuffle=False)
     torch.cuda.synchronize()
+    # the data-parallel step replays a step plan too: the gloo exchange rides in it as host calls of the library
+    assert (getattr(model, "_captured", None) is not None) == step_plan
     np.save(os.path.join(out_dir, f"theta{rank}.npy"), model.net.params.theta.cpu().numpy())
     np.save(os.path.join(out_dir, f"state{rank}.npy"), model.net.params.state.cpu().numpy())
     # every rank calls save() on the SAME path (as train() does): rank 0 alone writes, the file carries the
@@ -62,6 +74,16 @@ def test_two_ranks_train_identically_and_match_manual_averaging(tmp_path):
     ck = mt.load_model(str(tmp_path / "ckpt.npz"))
     assert np.array_equal(ck.net.params.theta.cpu().numpy(), t0)
     assert np.allclose(ck.net.params.state.cpu().numpy(), 0.5 * (s0.astype(np.float64) + s1), rtol=1e-6, atol=1e-7)
+
+    # the same two ranks on the Python schedule (no step plan): bit-identical variables
+    eager_dir = tmp_path / "eager"
+    eager_dir.mkdir()
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port2 = s.getsockname()[1]
+    s.close()
+    mp.spawn(_worker, args=(2, port2, str(eager_dir), False), nprocs=2, join=True)
+    assert np.array_equal(np.load(eager_dir / "theta0.npy"), t0) and np.array_equal(np.load(eager_dir / "state1.npy"), s1)
 
     # single process: same two steps with the per-rank gradients averaged by hand
     from lisec_amd import model_training as mt
@@ -161,10 +183,33 @@ def test_bench_one_rank_through_rccl_data_plane():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
     env.update(LISEC_FORCE_DP="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     env.pop("LISEC_DIST_BACKEND", None)
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
-                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stderr[-3000:]
-    j = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")][0]
+    def run(extra_env):
+        e = dict(env)
+        e.update(extra_env)
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "3",
+                            "--no-cpu-baseline"], env=e, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        return [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")][0]
+    j = run({})
     assert j["dist_backend"] == "nccl" and j["rccl_ranks"] == 1
     assert j["gradient_exchange"] == "lisec_allreduce_grads (RCCL)"
     assert np.isfinite(j["config"]["final_loss"]) and j["value"] > 0
+    # the exchange is part of the recorded step: same C-side schedule as the one-GPU line, both buckets included ...
+    assert j["config"]["launch"].startswith("step plan")
+    # ... bit-identical to the Python schedule of the same data-parallel step (the plain recorded form: the pipelined one
+    # trains one step more before the timed region, so its final loss is another step's) ...
+    r_ = run({"LISEC_TUNING": "pipeline_voxels=0"})
+    e = run({"LISEC_TUNING": "step_plan=0"})
+    assert r_["config"]["launch"].startswith("step plan") and e["config"]["launch"].startswith("Python schedule")
+    assert e["config"]["final_loss"] == r_["config"]["final_loss"]
+    # ... and as fast as the plain one-GPU line (a one-rank all-reduce of 26 MB in two buckets on its own stream)
+    env2 = {k: v for k, v in env.items() if k != "LISEC_FORCE_DP"}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "20", "--warmup", "3", "--no-cpu-baseline"],
+                       env=env2, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    plain = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")][0]
+    if os.path.isdir(os.path.join(root, "gpurun_out")):
+        with open(os.path.join(root, "gpurun_out", "dp_plan_vs_plain.txt"), "a") as f:
+            f.write(f"one rank through RCCL, step plan: {j['ms_per_step']:.4f} ms; Python schedule: {e['ms_per_step']:.4f} ms; "
+                    f"plain one-GPU line: {plain['ms_per_step']:.4f} ms\n")
+    assert j["ms_per_step"] <= 1.05 * plain["ms_per_step"], (j["ms_per_step"], plain["ms_per_step"])
