@@ -600,6 +600,19 @@ int lisec_rpn_to_region(const lisec_rpn_cfg* cfg, const float* cls, int cls_stri
                         size_t workspace_bytes, double* out_boxes, double* out_probs, int32_t* out_count,
                         lisec_stream_t stream);
 
+/* The decode alone (rpnToRegion.py:118-158: anchor grid + applyRegrssion, rows anchor-major as the reference's reshape at
+ * :146-148): boxes double[2*outX*outY*7], probs double[2*outX*outY], legal int32[2*outX*outY] (0 where :155-158 removes
+ * the box).  What lisec_rpn_to_region runs first; exposed so that it can be checked against the reference's own decode. */
+int lisec_rpn_decode(const lisec_rpn_cfg* cfg, const float* cls, int cls_stride, const float* reg, int reg_stride,
+                     double* boxes, double* probs, int32_t* legal, lisec_stream_t stream);
+/* The box geometry the kernels use, for parity checks: corners double[n*4*2] = boxToShapely's [topRight, botRight, botLeft,
+ * topLeft] (serialize_data.py:149-162) of boxes double[n*7]; per pair (2k, 2k+1): pair_out double[(n/2)*4] =
+ * {calculateIntersection volume (:140-147), calculateUnion (:165-168), IoU (:178), this library's own polygon area},
+ * the first three with the polygon area TAKEN from pair_area[k] when it is not NULL (the reference delegates that area to
+ * shapely). */
+int lisec_box_geometry(const double* boxes, int n, const double* pair_area, double* corners, double* pair_out,
+                       lisec_stream_t stream);
+
 /* preprocessLabels up to the class/regress maps before balancing (serialize_data.py:194-307).
  * fixed_boxes: device double[n_boxes*7], ALREADY scaled by fixBoxScaling (:181-191).
  * valid/overlap: double[outX*outY*2], out_regress: double[outX*outY*14] (all overwritten), indexed with the

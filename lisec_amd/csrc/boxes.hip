@@ -82,6 +82,31 @@ __device__ double rot_iou(const double* b1, const double* b2) {
     return inter / uni;
 }
 
+// The device box geometry, exposed for parity checks against reference-run goldens (tests/golden/box_geometry_decode.npz):
+// per box the four corners of boxToShapely (serialize_data.py:149-162); per PAIR (2k, 2k + 1), with the polygon area
+// GIVEN (the reference delegates it to shapely), calculateIntersection's volume (:140-147), calculateUnion (:165-168) and
+// their quotient (:178) -- and, on the side, the area this file's own clipping finds for the pair.
+__global__ void k_box_geometry(const double* __restrict__ boxes, int n, const double* __restrict__ pair_area,
+                               double* __restrict__ corners, double* __restrict__ pair_out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Pt c[4];
+    box_corners(boxes + (size_t)i * 7, c);
+    for (int k = 0; k < 4; ++k) { corners[((size_t)i * 4 + k) * 2] = c[k].x; corners[((size_t)i * 4 + k) * 2 + 1] = c[k].y; }
+    if ((i & 1) || i + 1 >= n) return;
+    const double* b1 = boxes + (size_t)i * 7;
+    const double* b2 = b1 + 7;
+    Pt c2[4];
+    box_corners(b2, c2);
+    const double area = pair_area ? pair_area[i >> 1] : quad_intersection_area(c, c2);
+    const double botZ = fmax(b1[2] - b1[5], b2[2] - b2[5]);
+    const double topZ = fmin(b1[2] + b1[5], b2[2] + b2[5]);
+    const double inter = (topZ - botZ) * area;
+    const double uni = b1[3] * b1[4] * b1[5] + b2[3] * b2[4] * b2[5] - inter;
+    double* o = pair_out + (size_t)(i >> 1) * 4;
+    o[0] = inter; o[1] = uni; o[2] = inter / uni; o[3] = quad_intersection_area(c, c2);
+}
+
 // ---- decode: anchor grid + applyRegrssion (rpnToRegion.py:75-150) ----------------------------------------
 __global__ void k_rpn_decode(const float* __restrict__ cls, int cls_stride, const float* __restrict__ reg,
                              int reg_stride, lisec_rpn_cfg cfg, double* __restrict__ boxes,
@@ -315,6 +340,26 @@ extern "C" int lisec_rpn_to_region(const lisec_rpn_cfg* cfg, const float* cls, i
     LISEC_LAUNCH(k_nms_gather, dim3(1), dim3(256), 0, st, ws.boxes, ws.probs, ws.picks, ws.npicks, out_boxes,
                        out_probs);
     LISEC_HIP_TRY(hipMemcpyAsync(out_count, ws.npicks, sizeof(int), hipMemcpyDeviceToDevice, st));
+    LISEC_LAUNCH_CHECK();
+    return LISEC_OK;
+}
+
+extern "C" int lisec_rpn_decode(const lisec_rpn_cfg* cfg, const float* cls, int cls_stride, const float* reg, int reg_stride,
+                                double* boxes, double* probs, int32_t* legal, lisec_stream_t stream_) {
+    if (int rc = check_cfg(cfg)) return rc;
+    LISEC_CHECK_ARG(cls && reg && boxes && probs && legal && cls_stride >= 2 && reg_stride >= 14, "bad arguments");
+    const int n = 2 * cfg->outX * cfg->outY;
+    LISEC_LAUNCH(k_rpn_decode, dim3(cdiv(n, 256)), dim3(256), 0, static_cast<hipStream_t>(stream_), cls, cls_stride, reg,
+                 reg_stride, *cfg, boxes, probs, legal);
+    LISEC_LAUNCH_CHECK();
+    return LISEC_OK;
+}
+
+extern "C" int lisec_box_geometry(const double* boxes, int n, const double* pair_area, double* corners, double* pair_out,
+                                  lisec_stream_t stream_) {
+    LISEC_CHECK_ARG(boxes && corners && pair_out && n >= 1, "bad arguments");
+    LISEC_LAUNCH(k_box_geometry, dim3(cdiv(n, 64)), dim3(64), 0, static_cast<hipStream_t>(stream_), boxes, n, pair_area,
+                 corners, pair_out);
     LISEC_LAUNCH_CHECK();
     return LISEC_OK;
 }

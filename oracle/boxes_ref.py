@@ -8,7 +8,11 @@ Restates, in plain Python/numpy float64,
     preprocessLabels (anchor grid x ground-truth boxes -> RPN targets)      serialize_data.py:194-338
     applyRegrssion / rpnToRegion / nonMaxSuppressionFast                    rpnToRegion.py:18-164
 
-PARITY UNPINNED: the polygon intersection is delegated by the reference to shapely (third party, absent
+PINNED BY THE REFERENCE ITSELF (round 4, tests/golden/make_box_goldens.py runs serialize_data.py / rpnToRegion.py
+unmodified under recording stand-ins; tests/golden/box_geometry_decode.npz): box_corners (boxToShapely's vertices),
+intersection_volume / union_volume / the IoU quotient around a GIVEN polygon area, apply_regression, and decode_boxes +
+the probability order (what rpnToRegion hands to nonMaxSuppressionFast).
+STILL UNPINNED: the polygon intersection AREA, which the reference delegates to shapely (third party, absent
 here and unpinned); it is restated as Sutherland-Hodgman clipping of two convex quadrilaterals + the shoelace
 formula, and cross-checked against an independent Monte-Carlo area estimate in tests/test_oracle_boxes.py.
 The reference's unseeded random.sample balancing (serialize_data.py:310-325) and np.argsort tie order
@@ -69,14 +73,33 @@ def convex_intersection_area(p, q):
     return abs(_signed_area(out))
 
 
-def calculate_iou(box1, box2):
-    """calculateIoU (serialize_data.py:170-178) with calculateIntersection / calculateUnion (:138-167)."""
-    area = convex_intersection_area(box_corners(box1), box_corners(box2))
+def intersection_volume(box1, box2, area):
+    """calculateIntersection (serialize_data.py:140-147) around the polygon area: the z extent uses the FULL height as
+    half-extent and is not clamped.  Pinned by a reference run with a chosen area (tests/golden/box_geometry_decode.npz)."""
     botZ = max(box1[2] - box1[5], box2[2] - box2[5])
     topZ = min(box1[2] + box1[5], box2[2] + box2[5])
-    intersect = (topZ - botZ) * area
-    union = box1[3] * box1[4] * box1[5] + box2[3] * box2[4] * box2[5] - intersect
-    return intersect / union
+    return (topZ - botZ) * area
+
+
+def union_volume(box1, box2, intersect):
+    """calculateUnion (serialize_data.py:165-168)."""
+    return box1[3] * box1[4] * box1[5] + box2[3] * box2[4] * box2[5] - intersect
+
+
+def calculate_iou(box1, box2, area=None):
+    """calculateIoU (serialize_data.py:170-178) with calculateIntersection / calculateUnion (:138-167).  area: the polygon
+    intersection area when it is given from outside (parity checks); None = this file's own clipping."""
+    if area is None:
+        area = convex_intersection_area(box_corners(box1), box_corners(box2))
+    intersect = intersection_volume(box1, box2, area)
+    return intersect / union_volume(box1, box2, intersect)
+
+
+def apply_regression(X, regress):
+    """applyRegrssionNP (rpnToRegion.py:90-113): X anchors (7, ...), regress (7, ...) -> decoded (7, ...)."""
+    X, t = np.asarray(X, dtype=np.float64), np.asarray(regress, dtype=np.float64)
+    return np.stack([t[0] * X[3] + X[0], t[1] * X[4] + X[1], t[2] * X[5] + X[2], np.exp(t[3]) * X[3], np.exp(t[4]) * X[4],
+                     np.exp(t[5]) * X[5], t[6] + X[6]])
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -111,3 +111,54 @@ def test_rpn_to_region_module_name():
     b, p = rpnToRegion.rpnToRegion(cls, reg)
     b2, p2 = boxes.rpnToRegion(cls[0], reg[0], maxBoxes=20, overlapThresh=0.)
     assert np.array_equal(b, b2) and np.array_equal(p, p2) and b.shape[1] == 7
+
+
+def test_device_geometry_and_decode_match_reference_run_goldens():
+    """boxes.hip against values the REFERENCE produced (tests/golden/box_geometry_decode.npz, made by running
+    serialize_data.py / rpnToRegion.py unmodified under recording stand-ins): the corners of boxToShapely, the
+    intersection / union / IoU arithmetic around a given polygon area, and the full decode (anchor grid + applyRegrssion,
+    anchor-major order, probabilities) that lisec_rpn_to_region runs before its suppression loop."""
+    import ctypes
+    import os
+    import torch
+    from lisec_amd import _lib, boxes
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "box_geometry_decode.npz"))
+    lib, dev = _lib.load(), torch.device("cuda")
+    bx = torch.from_numpy(np.ascontiguousarray(g["geom_boxes"])).to(dev)
+    n = bx.shape[0]
+    corners = torch.zeros((n, 4, 2), dtype=torch.float64, device=dev)
+    pair = torch.zeros((n // 2, 4), dtype=torch.float64, device=dev)
+    area = torch.from_numpy(np.ascontiguousarray(g["geom_pair_area"])).to(dev)
+    _lib.check(lib.lisec_box_geometry(_lib.ptr(bx), n, _lib.ptr(area), _lib.ptr(corners), _lib.ptr(pair), _lib.current_stream()))
+    torch.cuda.synchronize()
+    assert np.allclose(corners.cpu().numpy(), g["geom_corners"], rtol=0, atol=1e-12)
+    p = pair.cpu().numpy()
+    assert np.allclose(p[:, 0], g["geom_pair_intersection"], rtol=1e-14, atol=0)
+    assert np.allclose(p[:, 1], g["geom_pair_union"], rtol=1e-14, atol=0)
+    assert np.allclose(p[:, 2], g["geom_pair_iou"], rtol=1e-13, atol=0)
+    # the library's own polygon area (unpinned by the reference: shapely) against the oracle's clipping
+    from oracle import boxes_ref as B
+    own = [B.convex_intersection_area(B.box_corners(list(g["geom_boxes"][2 * k])), B.box_corners(list(g["geom_boxes"][2 * k + 1])))
+           for k in range(n // 2)]
+    assert np.allclose(p[:, 3], own, rtol=1e-10, atol=1e-12)
+    # decode
+    cfg = boxes._cfg()
+    cls = torch.from_numpy(g["decode_cls"]).to(dev)
+    reg = torch.from_numpy(g["decode_reg"]).to(dev)
+    N = 2 * cfg.outX * cfg.outY
+    dec = torch.zeros((N, 7), dtype=torch.float64, device=dev)
+    prob = torch.zeros(N, dtype=torch.float64, device=dev)
+    legal = torch.zeros(N, dtype=torch.int32, device=dev)
+    _lib.check(lib.lisec_rpn_decode(ctypes.byref(cfg), _lib.ptr(cls), 2, _lib.ptr(reg), 14, _lib.ptr(dec), _lib.ptr(prob),
+                                    _lib.ptr(legal), _lib.current_stream()))
+    torch.cuda.synchronize()
+    assert np.allclose(dec.cpu().numpy(), g["decode_boxInfo"], rtol=1e-14, atol=1e-14)
+    assert np.array_equal(prob.cpu().numpy(), g["decode_probInfo"])
+    assert int(legal.sum().item()) == N                    # exp(t) * anchor > 0: the reference removed nothing either
+    # and the public function picks from exactly these candidates
+    got_boxes, got_probs = boxes.rpnToRegion(g["decode_cls"], g["decode_reg"])
+    order = np.argsort(-g["decode_probInfo"], kind="stable")
+    assert got_probs[0] == g["decode_probInfo"][order[0]] or len(got_probs) > 0
+    for bxs, pr in zip(got_boxes, got_probs):
+        j = np.nonzero(g["decode_probInfo"] == pr)[0]
+        assert any(np.allclose(bxs, g["decode_boxInfo"][jj], rtol=1e-14, atol=1e-14) for jj in j)

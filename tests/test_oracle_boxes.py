@@ -125,3 +125,47 @@ def test_nms_by_value_known_answer():
     assert list(np.delete(np.array([5, 4, 3, 2, 1]), [3, 1])) == [5, 3, 1]
     with pytest.raises(IndexError):
         np.delete(np.array([5, 4]), [4])
+
+
+# ---- reference-run goldens for the pure-numpy halves (tests/golden/make_box_goldens.py, round 4) -------------------------
+def _box_goldens():
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "box_geometry_decode.npz"))
+
+
+def test_box_corners_match_the_reference_vertices():
+    """boxToShapely (serialize_data.py:149-162) run under a recording Polygon: the four vertices, in the reference's order."""
+    from oracle import boxes_ref as B
+    g = _box_goldens()
+    for box, ref in zip(g["geom_boxes"], g["geom_corners"]):
+        got = np.array(B.box_corners(list(box)))
+        assert np.allclose(got, ref, rtol=0, atol=1e-12)
+
+
+def test_intersection_union_iou_around_a_given_area_match_the_reference():
+    """calculateIntersection's z expression, calculateUnion and calculateIoU (serialize_data.py:140-178) with the polygon
+    area reported by the stand-in: the arithmetic AROUND shapely is the reference's own."""
+    from oracle import boxes_ref as B
+    g = _box_goldens()
+    boxes, areas = g["geom_boxes"], g["geom_pair_area"]
+    for k, area in enumerate(areas):
+        b1, b2 = list(boxes[2 * k]), list(boxes[2 * k + 1])
+        inter = B.intersection_volume(b1, b2, float(area))
+        assert inter == g["geom_pair_intersection"][k]
+        assert B.union_volume(b1, b2, inter) == g["geom_pair_union"][k]
+        assert B.calculate_iou(b1, b2, area=float(area)) == g["geom_pair_iou"][k]
+    assert (g["geom_pair_intersection"] < 0).any()          # the unclamped z extent does go negative on these boxes
+
+
+def test_apply_regression_and_decode_match_the_reference():
+    """applyRegrssionNP (rpnToRegion.py:90-113) and the boxInfo / probInfo rpnToRegion hands to nonMaxSuppressionFast
+    (:118-162), recorded from a run of the reference on seeded float32 maps."""
+    from oracle import boxes_ref as B
+    g = _box_goldens()
+    assert np.array_equal(B.apply_regression(g["regr_X"], g["regr_t"]), g["regr_out"])
+    boxes = B.decode_boxes(g["decode_reg"].astype(np.float64))
+    assert boxes.shape == g["decode_boxInfo"].shape == (40000, 7)
+    assert np.allclose(boxes, g["decode_boxInfo"], rtol=1e-15, atol=1e-15)
+    probs = g["decode_cls"].astype(np.float64).transpose(2, 0, 1).reshape(-1)
+    assert np.array_equal(probs, g["decode_probInfo"])
+    assert list(g["decode_nms_args"]) == [20.0, 0.0]       # maxBoxes=20, overlapThresh=0. (rpnToRegion.py:162)
