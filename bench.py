@@ -39,13 +39,17 @@ PEAK_HBM_GBS = 8000.0            # HBM3E spec (6.3 TB/s achievable per the same 
 def pmc_dominant():
     """Counters of the dominant kernel's own launch from the committed PMC summary (rocprofv3 --pmc passes of this file,
     one counter set per pass, gfx950 correction FETCH_SIZE x2 applied by tools/pmc_summary.py): clock_ghz, traffic_bytes."""
-    path = os.path.join(ROOT, "profiles", "r03_pmc_dominant.json")
-    try:
-        with open(path) as f:
-            d = json.load(f)
-        return d
-    except (OSError, ValueError):
-        return {}
+    import glob
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_dominant.json")))
+    for path in reversed(paths):                     # the newest committed round
+        try:
+            with open(path) as f:
+                d = json.load(f)
+            d.setdefault("file", os.path.relpath(path, ROOT))
+            return d
+        except (OSError, ValueError):
+            continue
+    return {}
 
 
 def u20k_cloud(seed, n=20000):
@@ -87,7 +91,8 @@ def event_time_ms(fn, iters):
 
 
 def voxelizer_leg(vox, dev, skip_cpu=False):
-    """BASELINE.md plan item 1: the HIP voxeliser (lisec_voxelize: 6 launches + 2 memsets) on both synthetic sweeps,
+    """BASELINE.md plan item 1: the HIP voxeliser (lisec_voxelize: 7 launches -- zero, key + count, three scan kernels,
+    place, features) on both synthetic sweeps,
     points/s and algorithmic bytes/s against the HBM peak, next to the CPU restatement (oracle/voxel_ref.py, numpy,
     one core) on the same U20k cloud and the reference's own Python loop (2.62 s for 20 000 points measured in the
     build container, "~15 sec" for ~200 000 in its source, model_training.py:116)."""
@@ -134,10 +139,36 @@ def voxelizer_leg(vox, dev, skip_cpu=False):
     return out
 
 
+def host_ram_gb():
+    """(total, available) host RAM in GB from /proc/meminfo (printed beside the core count)."""
+    tot = avail = None
+    try:
+        for ln in open("/proc/meminfo"):
+            f = ln.split()
+            if f[0] == "MemTotal:":
+                tot = int(f[1]) / 1e6
+            elif f[0] == "MemAvailable:":
+                avail = int(f[1]) / 1e6
+    except OSError:
+        pass
+    return tot, avail
+
+
 def cpu_baseline(seconds_budget=12.0):
-    """Dense torch-CPU oracle (fwd + bwd + update) on a shrunken grid, extrapolated to the Lyft grid."""
+    """Dense torch-CPU oracle (fwd + bwd + update): at the FULL Lyft grid when the host has the RAM for the dense rank-6
+    tensors (BASELINE.md plan item 3: >= ~96 GB; one step), otherwise on a shrunken grid, extrapolated by dense row count."""
     from oracle import model_ref as M
     from oracle import voxel_ref
+    ram_total, ram_avail = host_ram_gb()
+    if ram_avail is not None and ram_avail >= 160.0 and os.environ.get("LISEC_CPU_BASELINE_GRID", "full") == "full":
+        try:
+            return cpu_baseline_grid(M, voxel_ref, 8, 200, 400, 20000, 1, ram_total, ram_avail)
+        except MemoryError:
+            pass
+    return cpu_baseline_grid(M, voxel_ref, 8, 48, 96, None, None, ram_total, ram_avail, seconds_budget)
+
+
+def cpu_baseline_grid(M, voxel_ref, D, H, W, n_points, max_steps, ram_total, ram_avail, seconds_budget=12.0):
     # the GPU box gives one job a 16-core share of a much larger host: more threads only oversubscribe
     try:
         avail = len(os.sched_getaffinity(0))
@@ -145,10 +176,11 @@ def cpu_baseline(seconds_budget=12.0):
         avail = os.cpu_count() or 1
     cores = max(1, min(avail, 16))
     torch.set_num_threads(cores)
-    D, H, W = 8, 48, 96                 # 1/17.4 of the Lyft grid's dense rows: ~2 s per step on 16 cores, ~5 GB of RAM
+    # shrunken: 8 x 48 x 96 = 1/17.4 of the Lyft grid's dense rows: ~2 s per step on 16 cores, ~5 GB of RAM
+    full = (H, W) == (200, 400)
     cfg = dict(xSize=0.5, ySize=0.25, zSize=0.25, sampleSize=35, maxVoxelX=H // 2, maxVoxelY=W // 2, maxVoxelZ=8)
     rng = np.random.default_rng(0)
-    n = 20000 * (H * W) // (200 * 400)
+    n = n_points or 20000 * (H * W) // (200 * 400)
     ext = 0.5 * (H // 2) * 1.1          # the same 10 % of points beyond the grid as the U20k cloud
     pts = np.stack([rng.uniform(-ext, ext, n), rng.uniform(-ext, ext, n), rng.uniform(-0.5, 2.5, n)], 1)
     vox = voxel_ref.voxelize_ref(pts.astype(np.float32).astype(np.float64), **cfg)
@@ -162,13 +194,21 @@ def cpu_baseline(seconds_budget=12.0):
     while True:
         _, _, p, vel, _ = M.train_step(p, vel, dense, yc, yr, steps)
         steps += 1
+        if max_steps is not None and steps >= max_steps:
+            break
         if steps >= 2 and (time.time() - t0 > seconds_budget or steps >= 6):
             break
     per_step = (time.time() - t0) / steps
     scale = (200 * 400) / float(H * W)
-    return dict(value=1.0 / (per_step * scale), unit="samples/s", cores=cores, kind="port",
+    ram = dict(ram_total_gb=round(ram_total, 1) if ram_total else None, ram_available_gb=round(ram_avail, 1) if ram_avail else None)
+    if full:
+        return dict(value=1.0 / per_step, unit="samples/s", cores=cores, kind="port", extrapolated=False,
+                    sample=f"dense torch-CPU oracle, fwd+bwd+SGD, the FULL grid {D}x{H}x{W}x35x6 ({steps} step, "
+                           f"{per_step:.1f} s/step, {cores} threads)", **ram)
+    return dict(value=1.0 / (per_step * scale), unit="samples/s", cores=cores, kind="port", extrapolated=True,
                 sample=f"dense torch-CPU oracle, fwd+bwd+SGD, grid {D}x{H}x{W}x35x6 ({steps} steps, "
-                       f"{per_step:.2f} s/step), extrapolated x{scale:.1f} by dense row count to 8x200x400")
+                       f"{per_step:.2f} s/step), extrapolated x{scale:.1f} by dense row count to 8x200x400 "
+                       f"(full grid needs >= 160 GB of available host RAM)", **ram)
 
 
 def _free_port():
@@ -348,7 +388,7 @@ def main():
             ops.conv_forward(dg2, dz2, net.packed_t[c2.name][0], du1, flags=ops.TAG_ROOFLINE)
         ms = event_time_ms(run_mid2_dgrad, 20)
         pmc = pmc_dominant()
-        pmc_src = "PMC passes of this file: " + pmc.get("source", "profiles/r03_pmc_dominant.json absent")
+        pmc_src = "PMC passes of this file: " + pmc.get("source", "profiles/r*_pmc_dominant.json absent")
         # algorithmic FLOPs: 2 * output positions of the layer * 27 taps * 64 * 64 -- every (position, tap)
         # pair of the forward contraction is one pair of its transpose; the kernel runs exactly those (depth taps that
         # fall outside are skipped per tile), so executed == algorithmic here
@@ -360,7 +400,12 @@ def main():
                         clock_ghz=pmc.get("clock_ghz"), clock_note="GRBM_GUI_ACTIVE/8/duration, " + pmc_src,
                         traffic=pmc.get("traffic_bytes"), traffic_unit="bytes/launch, " + pmc_src,
                         mfma_busy=pmc.get("mfma_busy"),
-                        us_per_launch=ms * 1e3, flops_per_launch=flops)
+                        us_per_launch=ms * 1e3, flops_per_launch=flops,
+                        # the same launch INSIDE the step, beside the weight gradients of the second stream (kernel trace of
+                        # this command, tools/profile_round.sh): what the step pays, next to what the kernel takes alone
+                        in_step_us=pmc.get("in_step_us"),
+                        in_step_frac=(flops / (pmc["in_step_us"] * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS
+                                      if pmc.get("in_step_us") else None))
         # the other large contractions, same clock: mid2 forward, and the dense form of the first Conv3D (the dominant
         # kernel of rounds 1-2; sweeps beyond LISEC_FIELD_MAX_VOXELS still take it)
         grid = net.dense_grid()
@@ -396,10 +441,12 @@ def main():
         ms_g = event_time_ms(lambda: net.vfe.rewrite_grid(grid), 50)
         grid_bytes = 4.0 * 64 * net.D * net.H * net.W
         gbs = grid_bytes / (ms_g * 1e-3) / 1e9
-        # traffic from PMC: WRITE_SIZE 160 000 KiB (= the algorithmic bytes) + FETCH_SIZE 4 875 KiB x2
+        # traffic from the committed PMC passes (WRITE_SIZE + 2 x FETCH_SIZE of k_vfe_grid's launches WITH the dense grid)
+        vfe_pmc = pmc.get("vfe_grid", {})
         roofline_vfe = dict(bound="hbm", kernel="k_vfe_grid (dense (8,200,400,64) VFE output writer; lisec_vfe_forward with a grid)", achieved=gbs,
                             peak=PEAK_HBM_GBS, unit="GB/s", frac=gbs / PEAK_HBM_GBS,
-                            traffic=(160000.0 + 2 * 4875.125) * 1024, traffic_unit="bytes/launch (PMC, offline)",
+                            traffic=vfe_pmc.get("traffic_bytes"),
+                            traffic_unit="bytes/launch, " + pmc.get("file", "profiles/r*_pmc_dominant.json absent") + " (vfe_grid)",
                             us_per_launch=ms_g * 1e3, bytes_per_launch=grid_bytes,
                             whole_vfe_forward=dict(us_per_call=ms_v * 1e3, bytes_per_call=vfe_bytes,
                                                    achieved=vfe_bytes / (ms_v * 1e-3) / 1e9,

@@ -679,7 +679,21 @@ typedef struct lisec_tuning {
     int wgrad_ring_slots;   /* workgroups a ring launch fills, 0 = one per CU                      (0)         */
 } lisec_tuning;
 int lisec_tuning_get(lisec_tuning* t);        /* fills *t with the current record (t->struct_bytes set)          */
-int lisec_tuning_set(const lisec_tuning* t);  /* t->struct_bytes must be sizeof(lisec_tuning)                    */
+int lisec_tuning_set(const lisec_tuning* t);  /* t->struct_bytes must be sizeof(lisec_tuning); every field is range-checked */
+/* STATE OF THE LIBRARY BEYOND ITS ARGUMENTS -- all of it:
+ *   1. the tuning record above: ONE per process, unsynchronised; read when a call is PLANNED (so a recorded step plan keeps
+ *      the launches it recorded: re-record it after lisec_tuning_set);
+ *   2. step-plan recording (5b): per THREAD -- between lisec_step_plan_begin and _end every launch, event edge, host call and
+ *      lisec_allreduce_grads of that thread is also appended to the plan;
+ *   3. lisec_last_error(): per thread;
+ *   4. the lisec_debug_*_stamps pointers: __device__ variables of the code object, NULL unless a diagnostic tool sets them.
+ * Everything else -- tensors, workspaces, counters, statistics sinks, communicators, events, streams -- belongs to the caller
+ * and is passed in. */
+/* Zero-fills a workspace whose head holds arrival counters (the K-sliced contractions of lisec_conv_forward*, every
+ * lisec_conv_wgrad*) before its FIRST use; every call leaves those counters at zero again.  Non-zero counters (scratch that
+ * was never cleared, a call that was interrupted, two streams sharing one workspace) make slices wait for arrivals that
+ * never come: tiles stay unwritten, with no error. */
+int lisec_workspace_init(void* workspace, size_t bytes, lisec_stream_t stream);
 
 /* 100 MHz s_memrealtime stamps of thread 0 of every workgroup at the kernels' phase boundaries (tools: igemm_stamps.py, wgrad_stamps.py, vfe_stamps.py, field_stamps.py).
  * buf: device uint64[8192 x 8] (igemm); see the tools for the others; NULL (the default) turns them off -- no stamp

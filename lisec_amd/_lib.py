@@ -213,6 +213,8 @@ def _declare(lib):
     lib.lisec_head_compose_backward.argtypes = [P, LL, LL, P, P, P, P, c_int, c_int, c_int, P, P, P, P]
     lib.lisec_head_shuffle.restype = c_int
     lib.lisec_head_shuffle.argtypes = [P, c_int, c_int, c_int, POINTER(c_void_p), POINTER(c_int), c_int, P]
+    lib.lisec_workspace_init.restype = c_int
+    lib.lisec_workspace_init.argtypes = [P, c_size_t, P]
     lib.lisec_rpn_decode.restype = c_int
     lib.lisec_rpn_decode.argtypes = [POINTER(RpnCfg), P, c_int, P, c_int, P, P, P, P]
     lib.lisec_box_geometry.restype = c_int

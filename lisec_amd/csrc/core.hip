@@ -27,7 +27,22 @@ extern "C" int lisec_tuning_set(const lisec_tuning* t) {
     LISEC_CHECK_ARG(t && t->struct_bytes == (int)sizeof(lisec_tuning), "tuning record of another ABI version");
     LISEC_CHECK_ARG(t->max_splitk >= 1 && t->splitk_min_steps >= 1 && t->min_splitk >= 2 && t->wgrad_blocks >= 1 && t->wgrad_batch_blocks >= 1,
                     "tuning: max_splitk, splitk_min_steps, wgrad_blocks >= 1, min_splitk >= 2");
+    LISEC_CHECK_ARG((t->wgrad_per_cu == 2 || t->wgrad_per_cu == 3) && t->wgrad_combine_max >= 0 && t->wgrad_combine_max <= 4096 &&
+                    (t->lone_db == 0 || t->lone_db == 1) && (t->wgrad_ring == 0 || t->wgrad_ring == 1) &&
+                    t->wgrad_ring_slots >= 0 && t->force_splitk >= 0 && (t->plane_pair == 0 || t->plane_pair == 1) &&
+                    (t->dense64 == 0 || t->dense64 == 1) && (t->half_n == 0 || t->half_n == 1) && t->field_seg >= 0 &&
+                    t->field_tpw >= 0 && t->vfe_shape >= -1,
+                    "tuning: wgrad_per_cu 2|3, wgrad_combine_max 0..4096, flags 0|1, wgrad_ring_slots / force_splitk / "
+                    "field_seg / field_tpw >= 0, vfe_shape >= -1");
     lisec::g_tuning = *t;
+    return LISEC_OK;
+}
+
+// Workspaces whose head holds arrival counters (lisec_conv_forward* with K slices, lisec_conv_wgrad*) must start zero-filled;
+// every call leaves the counters at zero.  This is that first fill, for callers that do not have a memset of their own.
+extern "C" int lisec_workspace_init(void* workspace, size_t bytes, lisec_stream_t stream) {
+    LISEC_CHECK_ARG(workspace || bytes == 0, "NULL workspace");
+    if (bytes) LISEC_HIP_TRY(hipMemsetAsync(workspace, 0, bytes, static_cast<hipStream_t>(stream)));
     return LISEC_OK;
 }
 

@@ -122,25 +122,6 @@ k_rows_colsum(const int* __restrict__ info, int cap, const float* __restrict__ d
     if (ry == 0) parts[(size_t)blockIdx.x * 64 + c] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
 }
 
-// virtual voxel: (sum of the grid gradient over ALL cells) - (sum over the occupied cells)
-__global__ void __launch_bounds__(1024)
-k_virtual_from_total(const int* __restrict__ info, int cap, const double* __restrict__ parts, int nparts,
-                     const float* __restrict__ g_all, float* __restrict__ dout) {
-    __shared__ double red[16][64];
-    int V = info[LISEC_VI_NVOX];
-    if (V > cap) V = cap;
-    const int c = threadIdx.x & 63, ry = threadIdx.x >> 6;
-    double a = 0.0;
-    for (int b = ry; b < nparts; b += 16) a += parts[(size_t)b * 64 + c];
-    red[ry][c] = a;
-    __syncthreads();
-    for (int o = 8; o > 0; o >>= 1) {
-        if (ry < o) red[ry][c] += red[ry + o][c];
-        __syncthreads();
-    }
-    if (ry == 0) dout[(size_t)V * 64 + c] = (float)((double)g_all[c] - red[0][c]);
-}
-
 __device__ __forceinline__ void block_stats_out(double s1, double s2, int C, double* parts, int w, int lane) {
     __shared__ double red[2][4][64];
     red[0][w][lane] = s1; red[1][w][lane] = s2;
@@ -153,9 +134,14 @@ __device__ __forceinline__ void block_stats_out(double s1, double s2, int C, dou
 
 // dbeta3/dgamma3: only the row attaining the per-voxel max of a3 carries gradient, and that row's
 // pre-BN value is ymax3 (scale >= 0) or ymin3 (scale < 0)
+// vparts (compact form, optional): the fp64 column-sum parts of the occupied rows (k_rows_colsum).  The wave that meets the
+// virtual voxel (row V) forms its gradient row itself -- (sum of the grid gradient over ALL cells, g_all) - (sum over the
+// occupied cells) -- and stores it for the kernels behind this one: what k_virtual_from_total did as a launch of ONE
+// workgroup between two others (7 - 26 us on the serial tail of the step).
 __global__ void __launch_bounds__(256)
 k_l3_stats(VfeIn in, const float* __restrict__ bn3, const float* __restrict__ ymm3,
-           const float* __restrict__ dout, double* __restrict__ parts) {
+           float* __restrict__ dout, double* __restrict__ parts, const double* __restrict__ vparts, int nvparts,
+           const float* __restrict__ g_all) {
     const int lane = lane_id(), w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int V = in.info[LISEC_VI_NVOX];
     if (V > in.cap) V = in.cap;
@@ -165,7 +151,24 @@ k_l3_stats(VfeIn in, const float* __restrict__ bn3, const float* __restrict__ ym
 #pragma unroll 4
     for (int v = blockIdx.x * 4 + w; v < nvox; v += gridDim.x * 4) {
         const float ys = sc >= 0.f ? ymm3[(size_t)v * 128 + lane] : ymm3[(size_t)v * 128 + 64 + lane];
-        const float gz = fmaf(ys, sc, sh) > 0.f ? dout[(size_t)v * 64 + lane] : 0.f;
+        float dv;
+        if (vparts && v == V) {
+            double a = 0.0;
+            int b = 0;
+            for (; b + 8 <= nvparts; b += 8) {               // eight loads in flight, added in index order
+                double t[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) t[u] = vparts[(size_t)(b + u) * 64 + lane];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) a += t[u];
+            }
+            for (; b < nvparts; ++b) a += vparts[(size_t)b * 64 + lane];
+            dv = (float)((double)g_all[lane] - a);
+            dout[(size_t)V * 64 + lane] = dv;
+        } else {
+            dv = dout[(size_t)v * 64 + lane];
+        }
+        const float gz = fmaf(ys, sc, sh) > 0.f ? dv : 0.f;
         s1 += (double)gz;
         s2 += (double)gz * (double)((ys - mu) * is);
     }
@@ -814,6 +817,8 @@ extern "C" int lisec_vfe_backward(const lisec_vfe_params* p, const int32_t* info
     VfeIn in{info, npts, row_start, rows, ncells, T, cap_voxels};
     const double N = (double)ncells * (double)T;
     // 1. route the grid gradient to voxels
+    const double* vparts = nullptr;
+    int vparts_n = 0;
     if (dgrid) {
         const int gblocks = 1024;
         LISEC_LAUNCH(k_gather, dim3(gblocks), dim3(256), 0, st, info, cell_voxel, ncells, cap_voxels, dgrid,
@@ -821,15 +826,16 @@ extern "C" int lisec_vfe_backward(const lisec_vfe_params* p, const int32_t* info
         LISEC_LAUNCH(k_virtual_dout, dim3(1), dim3(1024), 0, st, info, cap_voxels, ws.parts_a, gblocks, ws.dout);
     } else {
         // rows [0,V) were computed at the occupied cells only; the virtual voxel gets total - occupied
+        // (the parts go where the tile kernels put their weight-gradient partials later; k_l3_stats writes parts_a itself)
         ws.dout = dout_rows;
-        const int cb = 256;
-        LISEC_LAUNCH(k_rows_colsum, dim3(cb), dim3(256), 0, st, info, cap_voxels, dout_rows, ws.parts_a);
-        LISEC_LAUNCH(k_virtual_from_total, dim3(1), dim3(1024), 0, st, info, cap_voxels, ws.parts_a, cb, g_all,
-                           dout_rows);
+        vparts_n = cap_voxels >= 32768 ? 256 : (cap_voxels >= 4096 ? 64 : 16);
+        vparts = ws.parts_dw;
+        LISEC_LAUNCH(k_rows_colsum, dim3(vparts_n), dim3(256), 0, st, info, cap_voxels, dout_rows, ws.parts_dw);
     }
     LISEC_LAUNCH_CHECK();
     // 2. layer 3 (fcn)
-    LISEC_LAUNCH(k_l3_stats, dim3(kBwdBlocks), dim3(256), 0, st, in, sv.bn3, sv.ymm3, ws.dout, ws.parts_a);
+    LISEC_LAUNCH(k_l3_stats, dim3(kBwdBlocks), dim3(256), 0, st, in, sv.bn3, sv.ymm3, ws.dout, ws.parts_a, vparts, vparts_n,
+                 g_all);
     LISEC_LAUNCH_CHECK();
     if (int rc = launch_bn_bwd_finalize(ws.parts_a, kBwdBlocks, 64, N, g->gamma[2], g->beta[2], ws.coef, st)) return rc;
     // lisec_tuning.debug_sync (diagnostic): synchronise and report after every launch of this call

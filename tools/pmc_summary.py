@@ -23,6 +23,7 @@ dominant_out = None
 if args and args[0] == "--dominant":
     dominant_out, args = args[1], args[2:]
 dom = {}
+vfe = {}
 for d in args:
     for f in sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)):
         agg = defaultdict(lambda: defaultdict(list))
@@ -45,6 +46,12 @@ for d in args:
                     dom[c] = sum(tail) / len(tail)
                     if c == "__dur_us":
                         dom.setdefault("__dur_by_pass", {})[os.path.basename(d)] = dom[c]
+            if label == "VFE grid writer":
+                # the launches WITH the dense grid are the long ones (the step's launches write per-voxel outputs only)
+                for c, v in cs.items():
+                    if c in ("FETCH_SIZE", "WRITE_SIZE"):
+                        big = sorted(v)[-max(1, len(v) // 4):]
+                        vfe[c] = sum(big) / len(big)
 if dominant_out:
     import json
     out = {"kernel": "k_igemm_halo<1,false,1,2,64,false> (mid2 Conv3D data gradient, bench.py's roofline launch)",
@@ -61,5 +68,19 @@ if dominant_out:
             dur_sq = dom.get("__dur_by_pass", {}).get("pmc_sq", dur)
             out["mfma_busy"] = dom["SQ_VALU_MFMA_BUSY_CYCLES"] / (out["clock_ghz"] * 1e3 * dur_sq * 1024.0)
             out["mfma_instructions"] = dom.get("SQ_INSTS_MFMA")
+    if "FETCH_SIZE" in vfe and "WRITE_SIZE" in vfe:
+        out["vfe_grid"] = {"fetch_size_kib": vfe["FETCH_SIZE"], "write_size_kib": vfe["WRITE_SIZE"],
+                           "traffic_bytes": (2.0 * vfe["FETCH_SIZE"] + vfe["WRITE_SIZE"]) * 1024.0,
+                           "note": "k_vfe_grid launches with the dense (8,200,400,64) grid (the top quarter by bytes)"}
+    tl = os.environ.get("STEP_TIMELINE")
+    if tl and os.path.exists(tl):
+        # the dominant layer inside the step: the longest 1250-workgroup launch of the mode-1 two-line halo kernel
+        best = None
+        for ln in open(tl):
+            f = ln.split()
+            if "k_igemm_halo<1, false, 0, 2, 64" in ln and ln.rstrip().endswith("1250"):
+                best = max(best or 0.0, float(f[1]))
+        if best:
+            out["in_step_us"] = best
     json.dump(out, open(dominant_out, "w"), indent=1)
     print("wrote", dominant_out, out)

@@ -3,7 +3,7 @@
 # 1. rocprofv3 --kernel-trace --stats of the default bench  -> gpurun_out/<tag>_stats/
 # 2. kernel trace of a few steps                            -> gpurun_out/<tag>_trace/  (tools/trace_csv.py)
 # 3. PMC passes, one counter set per pass (never together with trace domains other than --kernel-trace)
-tag=${1:-r03}
+tag=${1:-r04}
 R=$(pwd)
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${tag}_stats -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $R/gpurun_out/${tag}_stats.json 2> $R/gpurun_out/${tag}_stats.err || exit 1
@@ -16,5 +16,5 @@ cd $R
 f=$(ls -t gpurun_out/${tag}_trace/*/*kernel_trace.csv | head -1)
 python tools/trace_csv.py $f 8 > gpurun_out/${tag}_step_timeline.txt
 python tools/trace_csv.py $f 8 --sum > gpurun_out/${tag}_step_anatomy.txt
-python tools/pmc_summary.py --dominant gpurun_out/${tag}_pmc_dominant.json gpurun_out/${tag}_pmc/pmc_fetch gpurun_out/${tag}_pmc/pmc_write gpurun_out/${tag}_pmc/pmc_clk gpurun_out/${tag}_pmc/pmc_sq > gpurun_out/${tag}_pmc_summary.txt
+STEP_TIMELINE=gpurun_out/${tag}_step_timeline.txt python tools/pmc_summary.py --dominant gpurun_out/${tag}_pmc_dominant.json gpurun_out/${tag}_pmc/pmc_fetch gpurun_out/${tag}_pmc/pmc_write gpurun_out/${tag}_pmc/pmc_clk gpurun_out/${tag}_pmc/pmc_sq > gpurun_out/${tag}_pmc_summary.txt
 cp $(ls -t gpurun_out/${tag}_stats/*/*kernel_stats.csv | head -1) gpurun_out/${tag}_bench_kernel_stats.csv
