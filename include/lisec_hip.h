@@ -308,10 +308,11 @@ enum { LISEC_KERNEL_IGEMM = 0,   /* generic gather, 128 x 64 tile               
        LISEC_KERNEL_HALO2 = 1,   /* w-halo staging, at most two output lines per tile (Wo >= 126)             */
        LISEC_KERNEL_HALO3 = 2,   /* w-halo staging, three lines per tile (64 <= Wo < 126)                     */
        LISEC_KERNEL_DENSE64 = 3, /* resident workgroups, 1x1 64 -> 64                                         */
-       LISEC_KERNEL_QUEUE = 4 }; /* resident workgroups drawing row-list tiles from a counter                 */
+       LISEC_KERNEL_QUEUE = 4,   /* resident workgroups drawing row-list tiles from a counter                 */
+       LISEC_KERNEL_WIDE = 5 };  /* 128 x 128 tiles, 512-thread workgroups, two-line w-halo staging           */
 typedef struct lisec_conv_plan {
     int kernel;          /* LISEC_KERNEL_*                                                                    */
-    int cols;            /* output columns per workgroup: 64, or 32 (instead of two K slices)                 */
+    int cols;            /* output columns per workgroup: 64, 32 (instead of two K slices) or 128 (wide tile) */
     int tiles;           /* 128-row tiles of the call (parity-class order pads every class to whole tiles)    */
     int tail_tile0;      /* first tile of the K-sliced tail (0: the whole layer is sliced, == tiles: none)    */
     int k_slices;        /* K slices of the tail, combined in-kernel by the last slice to arrive              */
@@ -677,6 +678,8 @@ typedef struct lisec_tuning {
                             /* data-gradient chain on the other stream (default), 3 = as many as fit            */
     int wgrad_ring;         /* ring kernel for the 3 x 3 stride-1 weight gradients                 (1)         */
     int wgrad_ring_slots;   /* workgroups a ring launch fills, 0 = one per CU                      (0)         */
+    int wide_tile;          /* 128 x 128 tiles (512-thread workgroups) for 128-channel w-halo layers of few tiles (0:  */
+                            /* measured equal to the 128 x 32 plan alone, 0.8 % slower in the step -- kept for study)   */
 } lisec_tuning;
 int lisec_tuning_get(lisec_tuning* t);        /* fills *t with the current record (t->struct_bytes set)          */
 int lisec_tuning_set(const lisec_tuning* t);  /* t->struct_bytes must be sizeof(lisec_tuning); every field is range-checked */

@@ -58,10 +58,10 @@ class Tuning(Structure):                       # lisec_tuning
     _fields_ = [(n, c_int) for n in ("struct_bytes", "max_splitk", "splitk_min_steps", "min_splitk", "plane_pair", "dense64",
                                      "half_n", "vfe_shape", "field_seg", "field_tpw", "wgrad_blocks", "debug_sync",
                                      "force_splitk", "wgrad_combine_max", "wgrad_batch_blocks", "lone_db", "wgrad_per_cu",
-                                     "wgrad_ring", "wgrad_ring_slots")]
+                                     "wgrad_ring", "wgrad_ring_slots", "wide_tile")]
 
 
-KERNEL_NAMES = {0: "igemm", 1: "halo2", 2: "halo3", 3: "dense64", 4: "queue"}
+KERNEL_NAMES = {0: "igemm", 1: "halo2", 2: "halo3", 3: "dense64", 4: "queue", 5: "wide"}
 
 
 class CopyDesc(Structure):                     # lisec_copy_desc

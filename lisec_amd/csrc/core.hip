@@ -13,7 +13,7 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-static lisec_tuning g_tuning = {(int)sizeof(lisec_tuning), 12, 3, 2, 1, 1, 1, -1, 0, 0, 1024, 0, 0, 32, 1024, 1, 2, 1, 0};
+static lisec_tuning g_tuning = {(int)sizeof(lisec_tuning), 12, 3, 2, 1, 1, 1, -1, 0, 0, 1024, 0, 0, 32, 1024, 1, 2, 1, 0, 0};
 const lisec_tuning& tuning() { return g_tuning; }
 }  // namespace lisec
 
@@ -29,7 +29,7 @@ extern "C" int lisec_tuning_set(const lisec_tuning* t) {
                     "tuning: max_splitk, splitk_min_steps, wgrad_blocks >= 1, min_splitk >= 2");
     LISEC_CHECK_ARG((t->wgrad_per_cu == 2 || t->wgrad_per_cu == 3) && t->wgrad_combine_max >= 0 && t->wgrad_combine_max <= 4096 &&
                     (t->lone_db == 0 || t->lone_db == 1) && (t->wgrad_ring == 0 || t->wgrad_ring == 1) &&
-                    t->wgrad_ring_slots >= 0 && t->force_splitk >= 0 && (t->plane_pair == 0 || t->plane_pair == 1) &&
+                    (t->wide_tile == 0 || t->wide_tile == 1) && t->wgrad_ring_slots >= 0 && t->force_splitk >= 0 && (t->plane_pair == 0 || t->plane_pair == 1) &&
                     (t->dense64 == 0 || t->dense64 == 1) && (t->half_n == 0 || t->half_n == 1) && t->field_seg >= 0 &&
                     t->field_tpw >= 0 && t->vfe_shape >= -1,
                     "tuning: wgrad_per_cu 2|3, wgrad_combine_max 0..4096, flags 0|1, wgrad_ring_slots / force_splitk / "

@@ -892,6 +892,270 @@ k_igemm_halo(ConvGeom g, const float* __restrict__ in, const float* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Wide tile (round 4): 128 positions x 128 channels per 512-thread workgroup, w-halo staging (two lines per tile).
+// The 128-channel stride-1 layers of the first RPN block (model_training.py:203-206: 20 000 positions, 157 tiles) ran as 628
+// workgroups of 128 x 32 -- the A tile was staged for 32 MFMAs per wave and step and the layer sat at ~4 us of staging
+// latency per step (80 us for 5.9 GFLOP, 0.47).  Here eight waves share one A tile: wave (rg, ch) owns rows 32 rg .. and
+// columns 64 ch .. (two accumulators, the inner loop of halo_tile), the W slab is 64 x 128, and two workgroups per CU
+// (68 KB of LDS each) put four waves on every SIMD, so one wave's staging hides behind the others' MFMAs.  K is sliced by
+// whole A tiles as in halo_tile; the slices meet through splitk_arrive_wide.
+constexpr int kWideThreads = 512;
+constexpr int WB_FLOATS = BK * 128;
+constexpr int kWideSlabF4 = 8 * 8 * 64;          // float4 per (slice, tile): 8 waves x 8 x 64 lanes = 128 x 128 floats
+constexpr size_t wide_lds_bytes() { return (size_t)(halo_rows(2) * LDA + WB_FLOATS) * sizeof(float); }   // 68 672 B: 2 per CU
+
+__device__ __forceinline__ bool splitk_arrive_wide(f32x16& acc0, f32x16& acc1, float* partial, int nsplit, int slot, int nslots,
+                                                   int wave, int lane) {
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    __shared__ int splitk_last_w;
+    int* counters = reinterpret_cast<int*>(partial);
+    float* slabs = partial + kSplitCounters;
+    const size_t bytes = (size_t)nsplit * nslots * kWideSlabF4 * 16;
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(slabs, 0, (int)bytes, 0x00020000);
+    const unsigned lane_off = (unsigned)((wave * 8) * 64 + lane) * 16u;
+    const unsigned mine = (unsigned)(((size_t)blockIdx.z * nslots + slot) * kWideSlabF4 * 16) + lane_off;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const f32x16& a = q < 4 ? acc0 : acc1;
+        const int r = (q & 3) * 4;
+        u32x4 v;
+        v.x = __float_as_uint(a[r]); v.y = __float_as_uint(a[r + 1]); v.z = __float_as_uint(a[r + 2]); v.w = __float_as_uint(a[r + 3]);
+        __builtin_amdgcn_raw_buffer_store_b128(v, rs, mine + q * 64 * 16, 0, 16);          // aux 16 = sc1
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0)
+        splitk_last_w = __hip_atomic_fetch_add(counters + slot, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nsplit - 1;
+    __syncthreads();
+    if (!splitk_last_w) return false;
+    if (threadIdx.x == 0) __hip_atomic_store(counters + slot, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    f32x16 s0 = {0}, s1 = {0};
+    const unsigned zstride = (unsigned)((size_t)nslots * kWideSlabF4 * 16);
+    unsigned off = (unsigned)((size_t)slot * kWideSlabF4 * 16) + lane_off;
+    for (int z = 0; z < nsplit; ++z, off += zstride) {
+        u32x4 v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, off + q * 64 * 16, 0, 16);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            f32x16& a = q < 4 ? s0 : s1;
+            const int r = (q & 3) * 4;
+            a[r] += __uint_as_float(v[q].x); a[r + 1] += __uint_as_float(v[q].y);
+            a[r + 2] += __uint_as_float(v[q].z); a[r + 3] += __uint_as_float(v[q].w);
+        }
+    }
+    acc0 = s0; acc1 = s1;
+    return true;
+}
+
+template <int MODE, bool XF>
+__global__ void __launch_bounds__(kWideThreads, 4)      // two workgroups per CU = four waves per SIMD: <= 128 registers
+k_igemm_wide(ConvGeom g, const float* __restrict__ in, const float* __restrict__ wp, const float* __restrict__ bias,
+             const float* __restrict__ in_bn, int flags, float* __restrict__ out, double* __restrict__ stats, int nsplit,
+             float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    unsigned long long* stamps = g_igemm_stamps;
+    const unsigned stamp_wg = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    IGEMM_STAMP(0);
+    constexpr int HALO_MAX_ROWS = halo_rows(2);
+    float* sA = smem;
+    float* sB = smem + HALO_MAX_ROWS * LDA;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rg = wave & 3, ch = wave >> 2;                     // 32-row group, 64-column half
+    const int mb = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = mb * BM;
+    const int n0 = blockIdx.y * 128;
+    const int mlimit = g.M;
+
+    const int L0 = m0 / g.Wo, w0 = m0 - L0 * g.Wo;
+    const int a = g.Wo - w0 < BM ? g.Wo - w0 : BM;               // rows on line L0
+    const int nlines = g.Do * g.Ho;
+    const int nseg = a < BM ? 2 : 1;                             // Wo >= 126: at most two lines per tile
+    const int nrows = BM + 2 * nseg;
+
+    // staging map: halo row j = p * 32 + tid / 16, 16-byte piece tid % 16
+    const int piece = tid & 15;
+    int woff[5];
+    unsigned segbits = 0;
+#pragma unroll
+    for (int p = 0; p < 5; ++p) {
+        const int j = p * 32 + (tid >> 4);
+        int sg = 0, w_in = w0 - 1 + j;
+        if (j >= a + 2) { sg = 1; w_in = j - (a + 2) - 1; }
+        const bool ok = j < nrows && w_in >= 0 && w_in < g.Wi;
+        woff[p] = ok ? w_in * g.in_stride + piece * 4 : -1;
+        segbits |= (unsigned)sg << p;
+    }
+    const int ncc = (g.Cin + BK - 1) / BK;
+    const int ngroups = g.KD * g.KH;
+    const int nsteps = ngroups * ncc * 3;
+    const int KpQ = ncc * (BK / 4);
+    int seg_d[2], seg_h[2];
+    bool seg_ok[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int L = L0 + k;
+        seg_d[k] = L / g.Ho; seg_h[k] = L - seg_d[k] * g.Ho;
+        seg_ok[k] = k < nseg && L < nlines;
+    }
+    auto seg_base = [&](int k, int kd, int kh) -> int {          // source line of segment k, or -1
+        bool ok = seg_ok[k];
+        const int din = src_coord(seg_d[k], kd, g.ls_d, g.pd, g.Di, MODE, ok);
+        const int hin = src_coord(seg_h[k], kh, g.ls_h, g.ph, g.Hi, MODE, ok);
+        return ok ? ((din * g.Hi + hin) * g.Wi) * g.in_stride : -1;
+    };
+    struct HStep { int s, kd, kh, cc, kw; };
+    auto group_live = [&](const HStep& t) -> bool { return seg_base(0, t.kd, t.kh) >= 0 || seg_base(1, t.kd, t.kh) >= 0; };
+
+    float4 ra[5];
+    float4 rb[4];
+    float4 tsc = make_float4(1, 1, 1, 1), tsh = make_float4(0, 0, 0, 0);
+    unsigned valid_mask = 0;
+    bool staged_a = false;
+    auto issue_loads = [&](const HStep& t) {
+        const int kd = t.kd, kh = t.kh, cc = t.cc, kw = t.kw;
+        staged_a = kw == 0;
+        if (staged_a) {
+            const int c = cc * BK + piece * 4;
+            const bool cok = c < g.Cin;
+            const int sb0 = seg_base(0, kd, kh), sb1 = seg_base(1, kd, kh);
+            valid_mask = 0;
+#pragma unroll
+            for (int p = 0; p < 5; ++p) {
+                const int lb = (segbits >> p) & 1 ? sb1 : sb0;
+                const bool ok = cok && woff[p] >= 0 && lb >= 0;
+                const int off = ok ? lb + woff[p] + cc * BK : 0;
+                ra[p] = *reinterpret_cast<const float4*>(in + off);
+                valid_mask |= ok ? (1u << p) : 0u;
+            }
+            if (XF) {
+                const int cs = cok ? c : 0;
+                tsc = *reinterpret_cast<const float4*>(in_bn + cs);
+                tsh = *reinterpret_cast<const float4*>(in_bn + g.Cin + cs);
+            }
+        }
+        // W slab: 16 k-quads x 128 columns of float4, four per thread
+        const int tap = (kd * g.KH + kh) * 3 + kw;
+        const float* wb = wp + ((size_t)(tap * KpQ + cc * (BK / 4)) * g.CoutP + n0) * 4;
+        const float* wl = wb + (size_t)(tid >> 7) * g.CoutP * 4 + (tid & 127) * 4;
+        const size_t wstep = (size_t)4 * g.CoutP * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rb[i] = *reinterpret_cast<const float4*>(wl + i * wstep);
+    };
+    const float relu_lo = (flags & LISEC_CONV_IN_RELU) ? 0.f : -INFINITY;
+    auto store_lds = [&]() {
+        if (staged_a) {
+#pragma unroll
+            for (int p = 0; p < 5; ++p) {
+                float4 v = ra[p];
+                const bool ok = (valid_mask >> p) & 1;
+                if (XF) {
+                    v.x = ok ? fmaxf(fmaf(v.x, tsc.x, tsh.x), relu_lo) : 0.f;
+                    v.y = ok ? fmaxf(fmaf(v.y, tsc.y, tsh.y), relu_lo) : 0.f;
+                    v.z = ok ? fmaxf(fmaf(v.z, tsc.z, tsh.z), relu_lo) : 0.f;
+                    v.w = ok ? fmaxf(fmaf(v.w, tsc.w, tsh.w), relu_lo) : 0.f;
+                } else {
+                    v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+                }
+                const int j = p * 32 + (tid >> 4);
+                if (j < HALO_MAX_ROWS) *reinterpret_cast<float4*>(sA + j * LDA + piece * 4) = v;
+            }
+        }
+        float* bl = sB + ((tid >> 7) * 128 + (tid & 127)) * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(bl + i * 4 * 128 * 4) = rb[i];
+    };
+
+    f32x16 acc0 = {0}, acc1 = {0};
+    const int r_lane = rg * 32 + (lane & 31);
+    const int seg_lane = r_lane < a ? 0 : 1;
+    const float* aLane = sA + (r_lane + 2 * seg_lane) * LDA + 4 * (lane >> 5);
+    const float* bCol = sB + ((lane >> 5) * 128 + ch * 64 + (lane & 31)) * 4;
+
+    const int nstage = ngroups * ncc;
+    const int s_end = nsplit > 1 ? 3 * (int)(((long long)(blockIdx.z + 1) * nstage) / nsplit) : nsteps;
+    const int s_begin = nsplit > 1 ? 3 * (int)(((long long)blockIdx.z * nstage) / nsplit) : 0;
+    auto next_group = [&](HStep& t) { if (++t.kh == g.KH) { t.kh = 0; ++t.kd; } };
+    auto settle = [&](HStep t) -> HStep {
+        while (t.s < s_end && !group_live(t)) {
+            t.s += 3 * (ncc - t.cc); t.cc = 0;
+            next_group(t);
+        }
+        if (t.s >= s_end) t.s = nsteps;
+        return t;
+    };
+    auto next_of = [&](HStep t) -> HStep {
+        ++t.s;
+        if (++t.kw < 3) return t;
+        t.kw = 0;
+        if (++t.cc < ncc) {
+            if (t.s >= s_end) t.s = nsteps;
+            return t;
+        }
+        t.cc = 0;
+        next_group(t);
+        return settle(t);
+    };
+    HStep cur;
+    {
+        const int st = s_begin / 3, gi = st / ncc;
+        cur.s = s_begin; cur.kw = 0; cur.cc = st - gi * ncc; cur.kd = gi / g.KH; cur.kh = gi - cur.kd * g.KH;
+        cur = settle(cur);
+    }
+    IGEMM_STAMP(1);
+    if (cur.s < nsteps) { issue_loads(cur); store_lds(); }
+    __syncthreads();
+    IGEMM_STAMP(2);
+    int stamp_steps = 0;
+    while (cur.s < nsteps) {
+        ++stamp_steps;
+        const int kw = cur.kw;
+        const HStep nxt = next_of(cur);
+        if (nxt.s < nsteps) issue_loads(nxt);
+        const float* aRow = aLane + (MODE == 0 ? kw : 2 - kw) * LDA;
+        float4 av = *reinterpret_cast<const float4*>(aRow);
+        float4 b0 = *reinterpret_cast<const float4*>(bCol);
+        float4 b1 = *reinterpret_cast<const float4*>(bCol + 32 * 4);
+#pragma unroll
+        for (int kc = 0; kc < BK / 8; ++kc) {
+            float4 an = av, b0n = b0, b1n = b1;
+            if (kc + 1 < BK / 8) {
+                an = *reinterpret_cast<const float4*>(aRow + (kc + 1) * 8);
+                b0n = *reinterpret_cast<const float4*>(bCol + (kc + 1) * 2 * 128 * 4);
+                b1n = *reinterpret_cast<const float4*>(bCol + (kc + 1) * 2 * 128 * 4 + 32 * 4);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b0.x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b1.x, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b0.y, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b1.y, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b0.z, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b1.z, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b0.w, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b1.w, acc1, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            av = an; b0 = b0n; b1 = b1n;
+        }
+        __syncthreads();
+        if (nxt.s < nsteps) store_lds();
+        __syncthreads();
+        cur = nxt;
+    }
+    IGEMM_STAMP(3);
+    if (stamps && threadIdx.x == 0 && stamp_wg < 8192) stamps[(size_t)stamp_wg * 8 + 5] = (unsigned long long)stamp_steps;
+    if (nsplit > 1) {
+        const bool last = splitk_arrive_wide(acc0, acc1, partial, nsplit, mb * gridDim.y + blockIdx.y, gridDim.x * gridDim.y, wave, lane);
+        IGEMM_STAMP(7);
+        if (!last) { IGEMM_STAMP(4); return; }
+    }
+    // each column half is a 4-wave tile of its own for the store and the statistics; the halves use separate scratch and the
+    // workgroup makes ONE sink arrival for both (g.sink.total counts workgroups)
+    store_tile(g, acc0, acc1, smem + ch * 512, m0 + rg * 32, n0 + ch * 64, mb, mlimit, rg, lane, tid & 255, bias, flags, out, stats);
+    IGEMM_STAMP(4);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Dense(64) on the last axis (model_training.py:195) and its data gradient: 1x1x1, 64 -> 64, row m reads position m.
 // One K step per tile, so k_igemm spends its time in phases (2500 workgroups load, then multiply, then store: 2.6 TB/s
 // on a layer that moves 164 / 246 MB).  Here 768 workgroups stay resident and walk the tiles: the weights sit in LDS for
@@ -1211,13 +1475,13 @@ const float* identity_bnstate(int C) {
 // rounds unsplit and only the LAST, partially filled round is K-sliced (otherwise e.g. mid1's 2500 tiles take 4 rounds of
 // 768 resident workgroups for 3.25 rounds of work).  The slices of a tile are combined inside the kernel by the last one
 // to arrive (splitk_arrive): the workspace holds kSplitCounters arrival counters (zero between calls) and the slabs.
-enum { KERN_IGEMM = 0, KERN_HALO2 = 1, KERN_HALO3 = 2, KERN_DENSE64 = 3, KERN_QUEUE = 4 };
+enum { KERN_IGEMM = 0, KERN_HALO2 = 1, KERN_HALO3 = 2, KERN_DENSE64 = 3, KERN_QUEUE = 4, KERN_WIDE = 5 };
 struct ConvCall {
     ConvGeom g;
     int ntiles, nnb;
     int tile0_tail, nsplit;      // first tile of the K-sliced tail (== ntiles: none); slices
     size_t ws_bytes;
-    bool xf, halo, halo3, dense64, half_n, roofline;
+    bool xf, halo, halo3, dense64, half_n, roofline, wide;
     bool db;                     // the K-sliced launch runs the two-image (double-buffered) kernels, one workgroup per CU
     int kernel;                  // KERN_*
     int launch_tiles;            // workgroups along x of an every-tile launch (half the tiles with plane_pair)
@@ -1261,6 +1525,26 @@ void plan_slices(const ConvGeom& g, ConvCall* p) {
     p->tile0_tail = ntiles - tail_tiles;
     p->nsplit = ns;
     p->ws_bytes = align_up(sizeof(int) * kSplitCounters + sizeof(float) * (size_t)ns * tail_tiles * nnb * BM * BN, 256);
+}
+
+// The 128 x 128 tile (k_igemm_wide): layers of 128 (256, ...) output channels on the two-line w-halo geometry whose 128-row
+// tiles leave the chip under-filled (the stride-1 layers of the first RPN block and their data gradients: 157 tiles).  Two
+// workgroups per CU; K sliced by whole A tiles so that the launch is one round of them.
+bool plan_wide(const ConvGeom& g, int* nsplit, size_t* ws_bytes) {
+    if (!tuning().wide_tile || g.row_coords || g.ps || g.pc_span || g.queue || g.tail_w) return false;
+    if (!(g.ls_w == 0 && g.KW == 3 && g.pw == 1 && g.Wi == g.Wo && g.Wo >= BM - 2 && g.in_stride % 4 == 0)) return false;
+    if (g.CoutP % 128 != 0 || g.Cout % 4 != 0 || g.out_stride % 4 != 0) return false;
+    const long long blocks = (long long)cdiv(g.M, BM) * (g.CoutP / 128);
+    const int slots = 2 * (resident_slots() / 3);                       // two workgroups per CU
+    if (blocks > 2LL * slots || blocks > kSplitCounters) return false;  // big layers fill the chip with 128 x 64 tiles
+    const int nstage = g.KD * g.KH * cdiv(g.Cin, BK);
+    int ns = (int)(slots / blocks);
+    if (ns > nstage) ns = nstage;
+    if (ns > tuning().max_splitk) ns = tuning().max_splitk;
+    if (ns < 1) ns = 1;
+    *nsplit = ns;
+    *ws_bytes = ns > 1 ? align_up(sizeof(int) * kSplitCounters + (size_t)ns * blocks * kWideSlabF4 * 16, 256) : 0;
+    return true;
 }
 
 int plan_conv(const lisec_conv_geom* c, bool has_in_bn, int flags, const lisec_conv_extras* extras, double* stats_partials,
@@ -1362,6 +1646,20 @@ int plan_conv(const lisec_conv_geom* c, bool has_in_bn, int flags, const lisec_c
         p->kernel = KERN_HALO2;
         return LISEC_OK;
     }
+    p->wide = false;
+    {
+        int wns = 1;
+        size_t wws = 0;
+        if (!table_stats && !g.out_mask && plan_wide(g, &wns, &wws) && (wns == 1 || (workspace && workspace_bytes >= wws))) {
+            p->wide = true;
+            p->kernel = KERN_WIDE;
+            p->nsplit = wns; p->tile0_tail = wns > 1 ? 0 : ntiles; p->ws_bytes = wws; p->db = false;
+            p->halo = true; p->dense64 = false; p->half_n = false; g.plane_pair = 0;
+            p->launch_tiles = ntiles;
+            if (sk) g.sink.total = (unsigned)ntiles * (unsigned)(g.CoutP / 128);
+            return LISEC_OK;
+        }
+    }
     // Dense(64) and its data gradient: the resident-workgroup kernel
     if (tn.dense64 && g.pointwise && g.Cin == 64 && g.Cout == 64 && g.in_stride == 64 && g.out_stride == 64 && !g.row_coords &&
         !g.out_mask && !(flags & (LISEC_CONV_ACCUMULATE | LISEC_CONV_TAG_ROOFLINE)) && !table_stats &&
@@ -1397,7 +1695,12 @@ extern "C" size_t lisec_conv_forward_workspace_bytes(const lisec_conv_geom* c) {
     const size_t plain = p.ws_bytes;
     parity_order(c, &p.g);                            // the order a statistics-free call would use
     plan_slices(p.g, &p);
-    return plain > p.ws_bytes ? plain : p.ws_bytes;
+    size_t w = plain > p.ws_bytes ? plain : p.ws_bytes;
+    ConvGeom gw;
+    int wns = 1;
+    size_t wws = 0;
+    if (!conv_geom_check(c, &gw) && plan_wide(gw, &wns, &wws) && wws > w) w = wws;
+    return w;
 }
 
 extern "C" size_t lisec_conv_forward_rows_workspace_bytes(const lisec_conv_geom* c, int row_capacity) {
@@ -1420,7 +1723,7 @@ extern "C" int lisec_conv_plan_query(const lisec_conv_geom* c, int has_in_bnstat
                            has_row_list ? dummy_rows + 3 : nullptr, row_capacity, &p))
         return rc;
     out->kernel = p.kernel;
-    out->cols = p.half_n ? 32 : 64;
+    out->cols = p.wide ? 128 : (p.half_n ? 32 : 64);
     out->tiles = p.ntiles;
     out->tail_tile0 = p.tile0_tail;
     out->k_slices = p.nsplit;
@@ -1430,6 +1733,7 @@ extern "C" int lisec_conv_plan_query(const lisec_conv_geom* c, int has_in_bnstat
     const int ycols = p.half_n ? cdiv(p.g.Cout, 32) : p.nnb;
     int wgs = 0, launches = 0;
     if (p.kernel == KERN_DENSE64 || p.kernel == KERN_QUEUE) { wgs = resident_slots(); launches = 1; }
+    else if (p.wide) { wgs = p.ntiles * (p.g.CoutP / 128) * p.nsplit; launches = 1; }
     else {
         if (p.tile0_tail > 0) { wgs += (p.g.plane_pair ? p.launch_tiles : p.tile0_tail) * ycols; ++launches; }
         if (p.tile0_tail < p.ntiles) { wgs += (p.ntiles - p.tile0_tail) * p.nnb * p.nsplit; ++launches; }
@@ -1557,6 +1861,18 @@ extern "C" int lisec_conv_forward_ex(const lisec_conv_geom* c, const float* in, 
         if (c->mode == 0) { if (xf) LISEC_IQ(0, true); else LISEC_IQ(0, false); }
         else              { if (xf) LISEC_IQ(1, true); else LISEC_IQ(1, false); }
 #undef LISEC_IQ
+        LISEC_LAUNCH_CHECK();
+        return LISEC_OK;
+    }
+    if (p.wide) {
+        LISEC_CHECK_ARG(p.nsplit == 1 || ((uintptr_t)workspace & 15) == 0, "split-K needs a 16-byte aligned workspace");
+        dim3 grid(ntiles, g.CoutP / 128, p.nsplit);
+        float* partial = static_cast<float*>(workspace);
+#define LISEC_IW(M_, X_) LISEC_LAUNCH((k_igemm_wide<M_, X_>), grid, dim3(kWideThreads), wide_lds_bytes(), st, g, in, packed_w, bias, \
+        in_bnstate, flags, out, stats_partials, p.nsplit, partial)
+        if (c->mode == 0) { if (xf) LISEC_IW(0, true); else LISEC_IW(0, false); }
+        else              { if (xf) LISEC_IW(1, true); else LISEC_IW(1, false); }
+#undef LISEC_IW
         LISEC_LAUNCH_CHECK();
         return LISEC_OK;
     }

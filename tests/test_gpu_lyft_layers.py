@@ -62,6 +62,8 @@ FORWARD = [
      dict(kernel="igemm", cols=32, k_slices=1, workgroups=628)),
     ("rpn1.conv1", 0, (1, 100, 200), (1, 100, 200), (1, 3, 3), (1, 1, 1), (0, 1, 1), 128, 128, True,
      dict(kernel="halo2", cols=32, k_slices=1, workgroups=628)),
+    ("rpn1.conv1 [wide_tile=1]", 0, (1, 100, 200), (1, 100, 200), (1, 3, 3), (1, 1, 1), (0, 1, 1), 128, 128, True,
+     dict(kernel="wide", cols=128, k_slices=3, workgroups=471)),          # 128 x 128 tiles, 512-thread workgroups (opt-in)
     ("rpn2.conv0", 0, (1, 100, 200), (1, 50, 100), (1, 3, 3), (1, 2, 2), (0, 1, 1), 128, 128, True,
      dict(kernel="igemm", cols=64, k_slices=3, tail_tile0=0, workgroups=240, double_buffered=1)),
     ("rpn2.conv1", 0, (1, 50, 100), (1, 50, 100), (1, 3, 3), (1, 1, 1), (0, 1, 1), 128, 128, True,
@@ -80,6 +82,8 @@ def test_forward_with_batch_statistics(case):
     from lisec_amd import ops
     from oracle import conv_ref
     name, mode, ind, outd, k, s, p, cin, cout, xf, expect = case
+    from lisec_amd import _lib
+    _lib.set_tuning(wide_tile=1 if "[wide_tile=1]" in name else 0)
     dev = torch.device("cuda")
     rng = np.random.default_rng(seed_of(name))
     ntaps = k[0] * k[1] * k[2]
@@ -126,6 +130,8 @@ DGRAD = [
      dict(kernel="igemm", parity_classes=1)),
     ("rpn1.conv1", 1, (1, 100, 200), (1, 100, 200), (1, 3, 3), (1, 1, 1), (0, 1, 1), 128, 128, "bn",
      dict(kernel="halo2", cols=32, k_slices=1, workgroups=628)),
+    ("rpn1.conv1 [wide_tile=1]", 1, (1, 100, 200), (1, 100, 200), (1, 3, 3), (1, 1, 1), (0, 1, 1), 128, 128, "bn",
+     dict(kernel="wide", cols=128, k_slices=3, workgroups=471)),
     ("rpn2.conv0", 1, (1, 50, 100), (1, 100, 200), (1, 3, 3), (1, 2, 2), (0, 1, 1), 128, 128, "bn",
      dict(kernel="igemm", parity_classes=1)),
     ("rpn2.conv1", 1, (1, 50, 100), (1, 50, 100), (1, 3, 3), (1, 1, 1), (0, 1, 1), 128, 128, "bn",
@@ -145,6 +151,8 @@ def test_data_gradient(case):
     from lisec_amd import ops
     from oracle import conv_ref
     name, mode, ind, outd, k, s, p, cin, cout, kind, expect = case
+    from lisec_amd import _lib
+    _lib.set_tuning(wide_tile=1 if "[wide_tile=1]" in name else 0)
     dev = torch.device("cuda")
     rng = np.random.default_rng(seed_of("d" + name))
     ntaps = k[0] * k[1] * k[2]
