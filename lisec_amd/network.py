@@ -172,7 +172,10 @@ class LisecNet:
         # ROCm multiplexes same-priority streams onto a few hardware queues round-robin, so a plain second stream
         # can land on the main stream's queue (it does once RCCL has made its own streams) and then nothing
         # overlaps; a different priority level always gets its own hardware queue.
-        self.side = torch.cuda.Stream(device=dev, priority=_lib.knob("side_priority", -1))
+        # (Round 4: with GPU_MAX_HW_QUEUES=8 -- set when lisec_amd is imported -- a stream of the SAME priority gets a queue
+        # of its own, and that is the faster arrangement: the high-priority queue was served first whenever it held a ready
+        # packet, which starved the chain during the head phase; one rank through RCCL 5.13 -> 4.25 ms, one GPU +0.8 %.)
+        self.side = torch.cuda.Stream(device=dev, priority=_lib.knob("side_priority", 0))
 
         self.branch_overlap = _lib.knob("branch_overlap", True)
         self._tail_ok = {}
