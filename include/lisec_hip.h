@@ -548,6 +548,12 @@ int lisec_sgd_nesterov_step(float* theta, const float* grad, float* velocity, lo
  * workgroup has read it. */
 int lisec_sgd_nesterov_step_dev(float* theta, const float* grad, float* velocity, long long n, double lr,
                                 double decay, float momentum, long long* state, lisec_stream_t stream);
+/* The same update for a PART of the variables, ahead of the rest of the step: state[0] (the iteration count) is read and NOT
+ * incremented -- the call that ends the step (lisec_sgd_nesterov_step_dev over the remaining variables) does that.  The
+ * RPN + head variables (94 % of them, model_training.py:245-255) have final gradients long before the middle layers and
+ * the VFE are differentiated: their update runs on the second stream under the rest of the backward pass. */
+int lisec_sgd_nesterov_step_dev_part(float* theta, const float* grad, float* velocity, long long n, double lr, double decay,
+                                     float momentum, const long long* state, lisec_stream_t stream);
 
 /* x *= s  (gradient averaging after the data-parallel all-reduce) */
 int lisec_scale(float* x, long long n, float s, lisec_stream_t stream);

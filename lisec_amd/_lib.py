@@ -195,6 +195,8 @@ def _declare(lib):
     lib.lisec_sgd_nesterov_step.argtypes = [P, P, P, LL, c_float, c_float, P]
     lib.lisec_sgd_nesterov_step_dev.restype = c_int
     lib.lisec_sgd_nesterov_step_dev.argtypes = [P, P, P, LL, c_double, c_double, c_float, P, P]
+    lib.lisec_sgd_nesterov_step_dev_part.restype = c_int
+    lib.lisec_sgd_nesterov_step_dev_part.argtypes = [P, P, P, LL, c_double, c_double, c_float, P, P]
     lib.lisec_fold_depth.restype = c_int
     lib.lisec_fold_depth.argtypes = [P, P, c_int, LL, c_int, c_int, P, P]
     lib.lisec_scale.restype = c_int

@@ -209,8 +209,9 @@ __global__ void k_sgd_nesterov(float* __restrict__ w, const float* __restrict__ 
 // The same update with the iteration count on the device (a captured HIP graph of the step bakes kernel arguments in):
 // state[0] = iterations, state[1] = ticket (0 between launches).  Every workgroup reads state[0] before it takes its
 // ticket; the workgroup that takes the last one increments the count, i.e. after all of them have read it.
+// advance == 0: the update of a PART of the variables ahead of the rest (same iteration count: it is not incremented).
 __global__ void k_sgd_nesterov_dev(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ v,
-                                   long long n4, double lr, double decay, float mom, long long* __restrict__ state) {
+                                   long long n4, double lr, double decay, float mom, long long* __restrict__ state, int advance) {
     const long long it = __hip_atomic_load(&state[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const float lr_t = (float)(lr / (1.0 + decay * (double)it));       // what the host computes in double, then rounds
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
@@ -222,6 +223,7 @@ __global__ void k_sgd_nesterov_dev(float* __restrict__ w, const float* __restric
         reinterpret_cast<float4*>(w)[i] = W;
         reinterpret_cast<float4*>(v)[i] = V;
     }
+    if (!advance) return;
     __syncthreads();                                                   // every wave of this workgroup has read `it`
     if (threadIdx.x == 0) {
         const unsigned long long t = atomicAdd(reinterpret_cast<unsigned long long*>(&state[1]), 1ULL);
@@ -434,7 +436,17 @@ extern "C" int lisec_sgd_nesterov_step_dev(float* theta, const float* grad, floa
     LISEC_CHECK_ARG(theta && grad && velocity && state && n >= 0 && n % 4 == 0, "sgd: n must be a multiple of 4");
     if (n == 0) return LISEC_OK;
     LISEC_LAUNCH(k_sgd_nesterov_dev, dim3(ew_blocks(n / 4)), dim3(kEwThreads), 0, static_cast<hipStream_t>(stream_),
-                       theta, grad, velocity, n / 4, lr, decay, momentum, state);
+                       theta, grad, velocity, n / 4, lr, decay, momentum, state, 1);
+    LISEC_LAUNCH_CHECK();
+    return LISEC_OK;
+}
+
+extern "C" int lisec_sgd_nesterov_step_dev_part(float* theta, const float* grad, float* velocity, long long n, double lr,
+                                                double decay, float momentum, const long long* state, lisec_stream_t stream_) {
+    LISEC_CHECK_ARG(theta && grad && velocity && state && n >= 0 && n % 4 == 0, "sgd: n must be a multiple of 4");
+    if (n == 0) return LISEC_OK;
+    LISEC_LAUNCH(k_sgd_nesterov_dev, dim3(ew_blocks(n / 4)), dim3(kEwThreads), 0, static_cast<hipStream_t>(stream_),
+                       theta, grad, velocity, n / 4, lr, decay, momentum, const_cast<long long*>(state), 0);
     LISEC_LAUNCH_CHECK();
     return LISEC_OK;
 }

@@ -345,7 +345,8 @@ class Model:
                                           rpn_grads_ready=lambda lo, hi, avg=avg: avg.start_tail(self.net.grad, lo, hi))
                         avg.finish(self.net.grad)
                     else:
-                        self.net.backward(yc, yr, loss=self.loss)
+                        self.net.backward(yc, yr, loss=self.loss, rpn_grads_ready=lambda lo, hi: self.net.early_update(
+                            lo, hi, lr=o.lr, decay=o.decay, momentum=o.momentum))
                     self.net.apply_gradients(lr=o.lr, decay=o.decay, momentum=o.momentum)
                 tot_dev += self.net.loss_out
                 if verbose and ((st + 1) % every == 0 or st + 1 == steps):

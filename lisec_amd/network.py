@@ -179,6 +179,8 @@ class LisecNet:
 
         self.branch_overlap = _lib.knob("branch_overlap", True)
         self._tail_ok = {}
+        self.early_sgd = _lib.knob("early_sgd", True)           # RPN + head variables updated under the rest of the backward pass
+        self._early_from = None
         self.mid_wgrad_first = _lib.knob("mid_wgrad_first", True)   # ring weight gradient enqueued before the block's data gradient
         self.fuse_dense_bwd = _lib.knob("fuse_dense_bwd", True)   # Dense(64) data gradients ride on the tile of the block above
         self.chain_first = _lib.knob("chain_first", True)      # head phase: the chain's contraction is enqueued before the leaves
@@ -888,10 +890,32 @@ class LisecNet:
         self._wait(self._join_event, main)     # every weight gradient has landed before the optimizer reads G
         return self.loss_out
 
+    def early_update(self, lo, hi, lr=0.01, decay=1e-6, momentum=0.9):
+        """SGD-Nesterov of theta[lo:hi] AHEAD of the rest of the step (backward's rpn_grads_ready hook, on the second stream):
+        the RPN + head variables -- 94 % of the parameters -- have final gradients while the middle layers and the VFE are
+        still being differentiated, and nothing in the rest of the backward pass reads theta itself (the contractions read
+        the packed copies), so their 26 MB update runs under the MFMA-bound kernels instead of at the serial end of the
+        step.  Elementwise, hence the same values whichever call updates an element.  apply_gradients() then updates
+        theta[:lo] and advances the iteration count."""
+        if not self.early_sgd or lo % 4 or hi != self.params.n_theta:
+            return
+        p = self.params
+        n = (hi - lo) // 4 * 4
+        ops.sgd_nesterov_step_dev(p.theta[lo:lo + n], self.grad[lo:lo + n], self.velocity[lo:lo + n], lr, decay, momentum,
+                                  self._iter_dev, advance=False)
+        self._early_from = lo
+
     def apply_gradients(self, lr=0.01, decay=1e-6, momentum=0.9):
         """optimizers.SGD(lr=0.01, decay=1e-6, momentum=0.9, nesterov=True) (model_training.py:295)."""
         # lr_t = lr / (1 + decay * iterations), derived on the device from its own iteration counter
-        ops.sgd_nesterov_step_dev(self.params.theta, self.grad, self.velocity, lr, decay, momentum, self._iter_dev)
+        lo = getattr(self, "_early_from", None)
+        self._early_from = None
+        if lo is not None:
+            # the tail of the buffer was updated by early_update() during the backward pass
+            ops.sgd_nesterov_step_dev(self.params.theta[:lo], self.grad[:lo], self.velocity[:lo], lr, decay, momentum,
+                                      self._iter_dev)
+        else:
+            ops.sgd_nesterov_step_dev(self.params.theta, self.grad, self.velocity, lr, decay, momentum, self._iter_dev)
         self._iterations += 1
         self.params_version += 1
         if self._train_ready and self.early_pack:
@@ -919,10 +943,11 @@ class LisecNet:
             # two buckets: the RPN + head gradients (the tail of theta) are reduced under the rest of the backward
             self.backward(y_cls, y_reg, loss=loss, rpn_grads_ready=lambda lo, hi: allreduce.start_tail(self.grad, lo, hi))
             allreduce.finish(self.grad)
-        else:
+        elif allreduce is not None:
             self.backward(y_cls, y_reg, loss=loss)
-            if allreduce is not None:
-                allreduce(self.grad)
+            allreduce(self.grad)
+        else:
+            self.backward(y_cls, y_reg, loss=loss, rpn_grads_ready=lambda lo, hi: self.early_update(lo, hi))
         self.apply_gradients()
         return self.loss_out
 
@@ -1033,10 +1058,12 @@ class RecordedStep:
             net.backward(self.ycls, self.yreg, loss=self.loss,
                          rpn_grads_ready=lambda lo, hi: ar.start_tail(net.grad, lo, hi))
             ar.finish(net.grad)
-        else:
+        elif ar is not None:
             net.backward(self.ycls, self.yreg, loss=self.loss)
-            if ar is not None:
-                ar(net.grad)
+            ar(net.grad)
+        else:
+            net.backward(self.ycls, self.yreg, loss=self.loss,
+                         rpn_grads_ready=lambda lo, hi: net.early_update(lo, hi, *self.hyper))
         net.apply_gradients(*self.hyper)
 
     def _check_stream(self):
@@ -1161,10 +1188,12 @@ class PipelinedStep:
             net.backward(self.ycls[j], self.yreg[j], loss=self.loss, side_filler=filler,
                          rpn_grads_ready=lambda lo, hi: ar.start_tail(net.grad, lo, hi))
             ar.finish(net.grad)
-        else:
+        elif ar is not None:
             net.backward(self.ycls[j], self.yreg[j], loss=self.loss, side_filler=filler)
-            if ar is not None:
-                ar(net.grad)
+            ar(net.grad)
+        else:
+            net.backward(self.ycls[j], self.yreg[j], loss=self.loss, side_filler=filler,
+                         rpn_grads_ready=lambda lo, hi: net.early_update(lo, hi, *self.hyper))
         net.apply_gradients(*self.hyper)
 
     def _check_stream(self):

@@ -298,11 +298,12 @@ def sgd_nesterov_step(theta, grad, velocity, lr_t, momentum):
                                                    theta.numel(), lr_t, momentum, _lib.current_stream()))
 
 
-def sgd_nesterov_step_dev(theta, grad, velocity, lr, decay, momentum, state):
-    """state: int64[2] device tensor {iterations, 0}; lr_t is derived on the device (graph-replayable)."""
-    _lib.check(_lib.load().lisec_sgd_nesterov_step_dev(_lib.ptr(theta), _lib.ptr(grad), _lib.ptr(velocity),
-                                                       theta.numel(), float(lr), float(decay), momentum,
-                                                       _lib.ptr(state), _lib.current_stream()))
+def sgd_nesterov_step_dev(theta, grad, velocity, lr, decay, momentum, state, advance=True):
+    """state: int64[2] device tensor {iterations, 0}; lr_t is derived on the device (graph-replayable).
+    advance=False: a part of the variables ahead of the rest of the step (the iteration count is left alone)."""
+    fn = _lib.load().lisec_sgd_nesterov_step_dev if advance else _lib.load().lisec_sgd_nesterov_step_dev_part
+    _lib.check(fn(_lib.ptr(theta), _lib.ptr(grad), _lib.ptr(velocity), theta.numel(), float(lr), float(decay), momentum,
+                  _lib.ptr(state), _lib.current_stream()))
 
 
 def fold_depth(x, out, D, HW, C, inverse=False, mask=None):
