@@ -298,6 +298,16 @@ typedef struct lisec_conv_extras {
      * Needs the two-line w-halo kernel (3 taps along w, stride 1, Wo >= 126), Cout = out_stride = 64; LISEC_EINVAL otherwise. */
     const float* tail_w;
     float* tail_out;
+    /* optional BatchNormalization-backward APPLY ON LOAD (model_training.py:204-206 backwards): `in` is a gradient w.r.t. the
+     * output of BatchNormalization(+ReLU) over the raw map in_y (same layout as `in`), whose backward statistics a sink has
+     * already finalised: every gathered element becomes  scale * (gate(y) * g - mean(dz) - yhat * mean(dz * yhat))  -- what
+     * lisec_bn_backward_apply_coef would have written -- so the data gradient of a layer runs straight behind the one above it.
+     * in_fold_bnstate: the layer's bnstate float[4*Cin]; in_fold_coef: float[2*Cin] (lisec_bn_sink.coef); in_fold_relu: gate.
+     * Transposed gathers (mode 1) without in_bnstate / LISEC_CONV_IN_RELU only. */
+    const float* in_y;
+    const float* in_fold_bnstate;
+    const float* in_fold_coef;
+    int in_fold_relu;
 } lisec_conv_extras;
 int lisec_conv_num_mblocks_bwd(const lisec_conv_geom* g);
 

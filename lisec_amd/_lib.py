@@ -40,7 +40,9 @@ class BnSinkDesc(ctypes.Structure):           # lisec_bn_sink
 class ConvExtras(ctypes.Structure):           # lisec_conv_extras
     _fields_ = [("out_mask", ctypes.c_void_p), ("bwd_y", ctypes.c_void_p), ("bwd_bnstate", ctypes.c_void_p),
                 ("bwd_relu", ctypes.c_int), ("sink", POINTER(BnSinkDesc)), ("queue", ctypes.c_void_p),
-                ("tail_w", ctypes.c_void_p), ("tail_out", ctypes.c_void_p)]
+                ("tail_w", ctypes.c_void_p), ("tail_out", ctypes.c_void_p),
+                ("in_y", ctypes.c_void_p), ("in_fold_bnstate", ctypes.c_void_p), ("in_fold_coef", ctypes.c_void_p),
+                ("in_fold_relu", ctypes.c_int)]
 
 
 class ConvPlan(Structure):                     # lisec_conv_plan
@@ -392,6 +394,7 @@ def _hiprt():
         _hip = ctypes.CDLL("libamdhip64.so")
         _hip.hipEventCreateWithFlags.argtypes = [POINTER(c_void_p), ctypes.c_uint]
         _hip.hipEventDestroy.argtypes = [c_void_p]
+        _hip.hipEventElapsedTime.argtypes = [POINTER(ctypes.c_float), c_void_p, c_void_p]
     return _hip
 
 
@@ -443,9 +446,9 @@ class DeviceEvent:
     torch's Stream.cuda_stream gives."""
     FLAGS = 0x2 | 0x40000000          # hipEventDisableTiming | hipEventReleaseToDevice
 
-    def __init__(self):
+    def __init__(self, timing=False):
         h = c_void_p()
-        rc = _hiprt().hipEventCreateWithFlags(ctypes.byref(h), self.FLAGS)
+        rc = _hiprt().hipEventCreateWithFlags(ctypes.byref(h), 0 if timing else self.FLAGS)
         if rc != 0:
             raise LisecError(f"hipEventCreateWithFlags failed ({rc})")
         self.handle = h
@@ -456,6 +459,14 @@ class DeviceEvent:
 
     def wait(self, stream_handle):
         check(load().lisec_stream_wait_event(c_void_p(stream_handle), self.handle))
+
+    def elapsed_ms(self, later):
+        """Milliseconds from this event to `later` (both created with timing=True and complete)."""
+        ms = ctypes.c_float(0)
+        rc = _hiprt().hipEventElapsedTime(ctypes.byref(ms), self.handle, later.handle)
+        if rc != 0:
+            raise LisecError(f"hipEventElapsedTime failed ({rc})")
+        return ms.value
 
     def __del__(self):
         try:

@@ -53,6 +53,11 @@ struct ConvGeom {
     // 64 -> 64; the backward statistics / sink then belong to tail_out
     const float* tail_w;
     float* tail_out;
+    // optional BatchNormalization-backward apply ON LOAD of the gathered operand (lisec_conv_extras.in_y): see igemm_tile FOLD
+    const float* in_y;       // raw output of the layer the gathered gradient belongs to, laid out like `in`
+    const float* fold_bn;    // its bnstate float[4*Cin]
+    const float* fold_coef;  // float[2*Cin]: mean(dz), mean(dz * yhat) (a backward sink's coef)
+    int fold_relu;
 };
 
 int conv_geom_check(const lisec_conv_geom* c, ConvGeom* g);

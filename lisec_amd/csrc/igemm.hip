@@ -222,7 +222,11 @@ __device__ __forceinline__ void store_tile(const ConvGeom& g, const f32x16& acc0
 // between the MFMA runs but the stores' issue slots.  For launches of at most one workgroup per CU (the K-sliced 1 250- and
 // 5 000-position RPN maps), where no second workgroup covers the store -> barrier -> fragment-read sequence of the
 // single-image loop (2.65-2.9 us per step against 1.7 us of MFMA time, tools/rpn_stamps.py).
-template <int MODE, bool XF, int NW = 64, bool DB = false>
+// FOLD: the gathered operand is a gradient about to cross a BatchNormalization(+ReLU) backwards: the apply pass of that
+// backward -- dy = scale (gate(y) g - mean(dz) - yhat mean(dz yhat)), k_bn_bwd_apply -- runs on load, from g (`in`), the
+// layer's raw output y (g.in_y, same layout) and the per-channel constants (g.fold_bn = its bnstate, g.fold_coef = the
+// backward sink's means): the chain of data gradients of the RPN no longer stops for a launch between every two of them.
+template <int MODE, bool XF, int NW = 64, bool DB = false, bool FOLD = false>
 __device__ __forceinline__ void
 igemm_tile(const ConvGeom& g, const float* __restrict__ in, const float* __restrict__ wp,
            const float* __restrict__ bias, const float* __restrict__ in_bn, int flags,
@@ -300,6 +304,8 @@ igemm_tile(const ConvGeom& g, const float* __restrict__ in, const float* __restr
     };
 
     float4 ra[8];
+    float4 ry[FOLD ? 8 : 1];
+    float4 fmu = make_float4(0, 0, 0, 0), fis = fmu, fm1 = fmu, fm2 = fmu;     // FOLD: mean, 1/std, mean(dz), mean(dz yhat)
     float4 rb0, rb1, rb2, rb3;
     float4 tsc = make_float4(1, 1, 1, 1), tsh = make_float4(0, 0, 0, 0);
     unsigned valid_mask = 0;
@@ -317,7 +323,17 @@ igemm_tile(const ConvGeom& g, const float* __restrict__ in, const float* __restr
             const bool ok = (rows[p].mask & tbits) == tbits;
             const int off = ok ? rows[p].off + soff : 0;                // branch-free: invalid rows read element 0
             ra[p] = *reinterpret_cast<const float4*>(in + off);
+            if (FOLD) ry[p] = *reinterpret_cast<const float4*>(g.in_y + off);
             valid_mask |= ok ? (1u << p) : 0u;
+        }
+        if (FOLD) {
+            const int cs = cok ? c : 0;
+            tsc = *reinterpret_cast<const float4*>(g.fold_bn + cs);
+            tsh = *reinterpret_cast<const float4*>(g.fold_bn + g.Cin + cs);
+            fmu = *reinterpret_cast<const float4*>(g.fold_bn + 2 * g.Cin + cs);
+            fis = *reinterpret_cast<const float4*>(g.fold_bn + 3 * g.Cin + cs);
+            fm1 = *reinterpret_cast<const float4*>(g.fold_coef + cs);
+            fm2 = *reinterpret_cast<const float4*>(g.fold_coef + g.Cin + cs);
         }
         if (XF) {
             // unconditional (in_bn is never NULL here, see lisec_conv_forward_ex): with these two loads under a branch the
@@ -347,7 +363,17 @@ igemm_tile(const ConvGeom& g, const float* __restrict__ in, const float* __restr
         for (int p = 0; p < 8; ++p) {
             float4 v = ra[p];
             const bool ok = (valid_mask >> p) & 1;
-            if (XF) {
+            if (FOLD) {
+                const float4 y = ry[p];
+#define LISEC_FOLD(f)                                                                                          \
+                {                                                                                              \
+                    float dz = v.f;                                                                            \
+                    if (g.fold_relu && !(fmaf(y.f, tsc.f, tsh.f) > 0.f)) dz = 0.f;                             \
+                    v.f = ok ? tsc.f * (dz - fm1.f - (y.f - fmu.f) * fis.f * fm2.f) : 0.f;                     \
+                }
+                LISEC_FOLD(x) LISEC_FOLD(y) LISEC_FOLD(z) LISEC_FOLD(w)
+#undef LISEC_FOLD
+            } else if (XF) {
                 v.x = ok ? fmaxf(fmaf(v.x, tsc.x, tsh.x), relu_lo) : 0.f;
                 v.y = ok ? fmaxf(fmaf(v.y, tsc.y, tsh.y), relu_lo) : 0.f;
                 v.z = ok ? fmaxf(fmaf(v.z, tsc.z, tsh.z), relu_lo) : 0.f;
@@ -496,7 +522,7 @@ igemm_tile(const ConvGeom& g, const float* __restrict__ in, const float* __restr
 // parity of the voxels) and the dispatcher waits for the CU whose turn it is, so one workgroup per tile kept 3/4 of the
 // slots empty (84 000 voxels: starts spread over 183 us, 278 us for 82 us of work).  queue[0] = next tile, queue[1] =
 // workgroups that have drawn past the end; the last of those leaves both zero for the next call.
-template <int MODE, bool XF, int TAG = 0, int NW = 64, bool DB = false>
+template <int MODE, bool XF, int TAG = 0, int NW = 64, bool DB = false, bool FOLD = false>
 __global__ void __launch_bounds__(kThreads)
 k_igemm(ConvGeom g, const float* __restrict__ in, const float* __restrict__ wp,
         const float* __restrict__ bias, const float* __restrict__ in_bn, int flags,
@@ -506,7 +532,7 @@ k_igemm(ConvGeom g, const float* __restrict__ in, const float* __restrict__ wp,
     const unsigned stamp_wg = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
     IGEMM_STAMP(0);
     // XCD-aware tile order: consecutive M tiles (which share halo rows) stay on one XCD's L2
-    igemm_tile<MODE, XF, NW, DB>(g, in, wp, bias, in_bn, flags, out, stats, nsplit, partial, tile0,
+    igemm_tile<MODE, XF, NW, DB, FOLD>(g, in, wp, bias, in_bn, flags, out, stats, nsplit, partial, tile0,
                                  tile0 + xcd_remap(blockIdx.x, gridDim.x), smem, stamps, stamp_wg);
 }
 
@@ -552,7 +578,7 @@ k_igemm_queue(ConvGeom g, const float* __restrict__ in, const float* __restrict_
 constexpr int halo_rows(int nseg) { return BM + 2 * nseg; }     // segments + two halo columns each
 constexpr size_t halo_lds_bytes(int nseg) { return (size_t)(halo_rows(nseg) * LDA + B_FLOATS) * sizeof(float); }   // <= 52 832 B: 3 per CU
 
-template <int MODE, bool XF, int NSEG, int NW = 64, bool DB = false, bool TAIL = false>
+template <int MODE, bool XF, int NSEG, int NW = 64, bool DB = false, bool TAIL = false, bool FOLD = false>
 __device__ __forceinline__ void
 halo_tile(const ConvGeom& g, const float* __restrict__ in, const float* __restrict__ wp,
           const float* __restrict__ bias, const float* __restrict__ in_bn, int flags,
@@ -627,6 +653,8 @@ halo_tile(const ConvGeom& g, const float* __restrict__ in, const float* __restri
     };
 
     float4 ra[9];
+    float4 ry[FOLD ? 9 : 1];
+    float4 fmu = make_float4(0, 0, 0, 0), fis = fmu, fm1 = fmu, fm2 = fmu;     // FOLD (see igemm_tile)
     float4 rb0, rb1, rb2, rb3;
     float4 tsc = make_float4(1, 1, 1, 1), tsh = make_float4(0, 0, 0, 0);
     unsigned valid_mask = 0;
@@ -647,7 +675,17 @@ halo_tile(const ConvGeom& g, const float* __restrict__ in, const float* __restri
                 const bool ok = cok && woff[p] >= 0 && lb >= 0;
                 const int off = ok ? lb + woff[p] + cc * BK : 0;        // branch-free: invalid pieces read element 0
                 ra[p] = *reinterpret_cast<const float4*>(in + off);
+                if (FOLD) ry[p] = *reinterpret_cast<const float4*>(g.in_y + off);
                 valid_mask |= ok ? (1u << p) : 0u;
+            }
+            if (FOLD) {
+                const int cs = cok ? c : 0;
+                tsc = *reinterpret_cast<const float4*>(g.fold_bn + cs);
+                tsh = *reinterpret_cast<const float4*>(g.fold_bn + g.Cin + cs);
+                fmu = *reinterpret_cast<const float4*>(g.fold_bn + 2 * g.Cin + cs);
+                fis = *reinterpret_cast<const float4*>(g.fold_bn + 3 * g.Cin + cs);
+                fm1 = *reinterpret_cast<const float4*>(g.fold_coef + cs);
+                fm2 = *reinterpret_cast<const float4*>(g.fold_coef + g.Cin + cs);
             }
             if (XF) {
                 const int cs = cok ? c : 0;                     // unconditional, see k_igemm
@@ -677,7 +715,17 @@ halo_tile(const ConvGeom& g, const float* __restrict__ in, const float* __restri
             for (int p = 0; p < 9; ++p) {
                 float4 v = ra[p];
                 const bool ok = (valid_mask >> p) & 1;
-                if (XF) {
+                if (FOLD) {
+                    const float4 y = ry[p];
+#define LISEC_FOLD(f)                                                                                          \
+                    {                                                                                          \
+                        float dz = v.f;                                                                        \
+                        if (g.fold_relu && !(fmaf(y.f, tsc.f, tsh.f) > 0.f)) dz = 0.f;                         \
+                        v.f = ok ? tsc.f * (dz - fm1.f - (y.f - fmu.f) * fis.f * fm2.f) : 0.f;                 \
+                    }
+                    LISEC_FOLD(x) LISEC_FOLD(y) LISEC_FOLD(z) LISEC_FOLD(w)
+#undef LISEC_FOLD
+                } else if (XF) {
                     v.x = ok ? fmaxf(fmaf(v.x, tsc.x, tsh.x), relu_lo) : 0.f;
                     v.y = ok ? fmaxf(fmaf(v.y, tsc.y, tsh.y), relu_lo) : 0.f;
                     v.z = ok ? fmaxf(fmaf(v.z, tsc.z, tsh.z), relu_lo) : 0.f;
@@ -868,7 +916,7 @@ halo_tile(const ConvGeom& g, const float* __restrict__ in, const float* __restri
 // gradient of the second middle block: 9 / 18 / 18 / 9 of 27 per plane); the hardware hands workgroups to the CUs in a
 // fixed rotation and waits for a slot on the CU whose turn it is, so a launch of mixed 9- and 18-step workgroups left
 // 40 % of the slots empty (tools/igemm_stamps.py).  Paired, every workgroup runs 27 steps.
-template <int MODE, bool XF, int TAG = 0, int NSEG = 2, int NW = 64, bool DB = false, bool TAIL = false>
+template <int MODE, bool XF, int TAG = 0, int NSEG = 2, int NW = 64, bool DB = false, bool TAIL = false, bool FOLD = false>
 __global__ void __launch_bounds__(kThreads)
 k_igemm_halo(ConvGeom g, const float* __restrict__ in, const float* __restrict__ wp,
              const float* __restrict__ bias, const float* __restrict__ in_bn, int flags,
@@ -879,8 +927,8 @@ k_igemm_halo(ConvGeom g, const float* __restrict__ in, const float* __restrict__
     IGEMM_STAMP(0);
     const int v = tile0 + xcd_remap(blockIdx.x, gridDim.x);
     if (DB || !g.plane_pair) {
-        halo_tile<MODE, XF, NSEG, NW, DB, TAIL>(g, in, wp, bias, in_bn, flags, out, stats, nsplit, partial, tile0, v, smem, stamps,
-                                                stamp_wg);
+        halo_tile<MODE, XF, NSEG, NW, DB, TAIL, FOLD>(g, in, wp, bias, in_bn, flags, out, stats, nsplit, partial, tile0, v, smem,
+                                                      stamps, stamp_wg);
         return;
     }
     const int q = v / g.plane_tiles, i = v - q * g.plane_tiles;
@@ -1366,6 +1414,7 @@ int conv_geom_check(const lisec_conv_geom* c, ConvGeom* g) {
     g->sink.acc = nullptr;
     g->plane_tiles = 0; g->plane_pair = 0; g->queue = nullptr;
     g->tail_w = nullptr; g->tail_out = nullptr;
+    g->in_y = nullptr; g->fold_bn = nullptr; g->fold_coef = nullptr; g->fold_relu = 0;
     g->pointwise = c->KD * c->KH * c->KW == 1 && ld == 0 && lh == 0 && lw == 0 && c->pd == 0 && c->ph == 0 && c->pw == 0 &&
                    c->Di == c->Do && c->Hi == c->Ho && c->Wi == c->Wo;
     return 0;
@@ -1575,6 +1624,15 @@ int plan_conv(const lisec_conv_geom* c, bool has_in_bn, int flags, const lisec_c
                         "backward statistics need y, its bnstate, a partials buffer, dense rows and Cout % 4 == 0");
         g.bwd_y = extras->bwd_y; g.bwd_bn = extras->bwd_bnstate; g.bwd_relu = extras->bwd_relu ? 1 : 0;
     }
+    if (extras && extras->in_y) {
+        LISEC_CHECK_ARG(extras->in_fold_bnstate && extras->in_fold_coef && c->mode == 1 && !has_in_bn && !(flags & LISEC_CONV_IN_RELU) &&
+                        !row_coords && c->Cin % 4 == 0 && ((uintptr_t)extras->in_y & 15) == 0 &&
+                        ((uintptr_t)extras->in_fold_bnstate & 15) == 0 && ((uintptr_t)extras->in_fold_coef & 15) == 0,
+                        "in_y (BatchNormalization backward on load): a transposed gather (mode 1) without in_bnstate / IN_RELU, "
+                        "with the layer's bnstate and the backward sink's coefficients, 16-byte aligned");
+        g.in_y = extras->in_y; g.fold_bn = extras->in_fold_bnstate; g.fold_coef = extras->in_fold_coef;
+        g.fold_relu = extras->in_fold_relu ? 1 : 0;
+    }
     p->stats = stats_partials;
     // stride 2 along h and w, transposed gather (data gradient of a stride-2 Conv2D): rows are visited in parity
     // classes so that a tile only runs the taps that divide -- 9/4 of the 9 taps on average
@@ -1589,7 +1647,7 @@ int plan_conv(const lisec_conv_geom* c, bool has_in_bn, int flags, const lisec_c
     const int ntiles = p->ntiles = cdiv(g.M, BM), nnb = p->nnb = g.CoutP / BN;
     if (!workspace || workspace_bytes < p->ws_bytes) { p->tile0_tail = ntiles; p->nsplit = 1; p->db = false; }
     p->roofline = (flags & LISEC_CONV_TAG_ROOFLINE) != 0;
-    if (row_coords && extras && extras->queue && nnb == 1 && ntiles >= resident_slots() && !stats_partials && !g.out_mask &&
+    if (row_coords && !g.in_y && extras && extras->queue && nnb == 1 && ntiles >= resident_slots() && !stats_partials && !g.out_mask &&
         !p->roofline) {
         g.queue = extras->queue;                     // one un-sliced launch of resident workgroups drawing tiles
         p->tile0_tail = ntiles; p->nsplit = 1;
@@ -1609,7 +1667,7 @@ int plan_conv(const lisec_conv_geom* c, bool has_in_bn, int flags, const lisec_c
     p->halo3 = g.Wo < BM - 2;                                        // more than two lines per tile possible
     // planes that run different numbers of depth taps: one workgroup per PAIR of planes (see k_igemm_halo) when the layer
     // runs as one launch of the halo kernel and the pairs still fill the chip
-    if (tn.plane_pair && halo_geom && g.Do % 2 == 0 && (g.Ho * g.Wo) % BM == 0 && !g.pc_span &&
+    if (tn.plane_pair && !g.in_y && halo_geom && g.Do % 2 == 0 && (g.Ho * g.Wo) % BM == 0 && !g.pc_span &&
         (p->tile0_tail == ntiles || p->roofline) && (long long)(ntiles / 2) * nnb >= resident_slots()) {
         int lo = 1 << 30, hi = 0;
         for (int d = 0; d < g.Do; ++d) {
@@ -1623,7 +1681,7 @@ int plan_conv(const lisec_conv_geom* c, bool has_in_bn, int flags, const lisec_c
         if (lo != hi) { g.plane_tiles = g.Ho * g.Wo / BM; g.plane_pair = 1; }
     }
     p->dense64 = false; p->half_n = false;
-    if (p->roofline && !p->xf) {                     // one launch, every tile, under its own symbol
+    if (p->roofline && !p->xf && !g.in_y) {          // one launch, every tile, under its own symbol
         p->halo = halo_geom && !p->halo3;
         if (!p->halo) g.plane_pair = 0;
         p->tile0_tail = ntiles; p->nsplit = 1;
@@ -1633,6 +1691,7 @@ int plan_conv(const lisec_conv_geom* c, bool has_in_bn, int flags, const lisec_c
     }
     p->roofline = false;
     if (extras && extras->tail_w) {
+        LISEC_CHECK_ARG(!g.in_y, "tail: not together with in_y");
         // second contraction on the stored tile: one un-sliced launch of the two-line halo kernel over 64 columns
         LISEC_CHECK_ARG(extras->tail_out && ((uintptr_t)extras->tail_w & 15) == 0 && ((uintptr_t)extras->tail_out & 15) == 0,
                         "tail: packed 64 x 64 kernel and an output, 16-byte aligned");
@@ -1650,7 +1709,7 @@ int plan_conv(const lisec_conv_geom* c, bool has_in_bn, int flags, const lisec_c
     {
         int wns = 1;
         size_t wws = 0;
-        if (!table_stats && !g.out_mask && plan_wide(g, &wns, &wws) && (wns == 1 || (workspace && workspace_bytes >= wws))) {
+        if (!table_stats && !g.out_mask && !g.in_y && plan_wide(g, &wns, &wws) && (wns == 1 || (workspace && workspace_bytes >= wws))) {
             p->wide = true;
             p->kernel = KERN_WIDE;
             p->nsplit = wns; p->tile0_tail = wns > 1 ? 0 : ntiles; p->ws_bytes = wws; p->db = false;
@@ -1661,7 +1720,7 @@ int plan_conv(const lisec_conv_geom* c, bool has_in_bn, int flags, const lisec_c
         }
     }
     // Dense(64) and its data gradient: the resident-workgroup kernel
-    if (tn.dense64 && g.pointwise && g.Cin == 64 && g.Cout == 64 && g.in_stride == 64 && g.out_stride == 64 && !g.row_coords &&
+    if (tn.dense64 && !g.in_y && g.pointwise && g.Cin == 64 && g.Cout == 64 && g.in_stride == 64 && g.out_stride == 64 && !g.row_coords &&
         !g.out_mask && !(flags & (LISEC_CONV_ACCUMULATE | LISEC_CONV_TAG_ROOFLINE)) && !table_stats &&
         (!sk || (sk->kind == LISEC_SINK_BACKWARD && bwd_stats)) && !(bwd_stats && !sk) && ntiles >= resident_slots()) {
         p->dense64 = true;
@@ -1757,7 +1816,7 @@ extern "C" int lisec_conv_forward_masked(const lisec_conv_geom* c, const float* 
                                          const float* out_mask, double* stats_partials, void* workspace,
                                          size_t workspace_bytes, const int32_t* row_coords,
                                          const int32_t* row_count, int row_capacity, lisec_stream_t stream_) {
-    lisec_conv_extras ex = {out_mask, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr};
+    lisec_conv_extras ex = {out_mask, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
     return lisec_conv_forward_ex(c, in, packed_w, bias, in_bnstate, flags, out, &ex, stats_partials, workspace,
                                  workspace_bytes, row_coords, row_count, row_capacity, stream_);
 }
@@ -1837,6 +1896,42 @@ extern "C" int lisec_conv_forward_ex(const lisec_conv_geom* c, const float* in, 
             else              { if (xf) LISEC_IH(1, true, GRID_, NS_, PART_, T0_); else LISEC_IH(1, false, GRID_, NS_, PART_, T0_); } \
         } else LISEC_IG_ALL(GRID_, NS_, PART_, T0_);                                                           \
     } while (0)
+    if (g.in_y) {
+        // BatchNormalization backward applied on load (FOLD instantiations; transposed gather): the same launch shapes as below
+#define LISEC_FL(KERNEL_, GRID_, LDS_, NS_, PART_, T0_) LISEC_LAUNCH(KERNEL_, GRID_, dim3(kThreads), LDS_, st, g, in, packed_w, bias, \
+        in_bnstate, flags, out, stats_partials, NS_, PART_, T0_)
+        if (p.half_n) {
+            dim3 grid(ntiles, cdiv(g.Cout, 32), 1);
+            if (!halo) LISEC_FL((k_igemm<1, false, 0, 32, false, true>), grid, lds, 1, (float*)nullptr, 0);
+            else if (halo3) LISEC_FL((k_igemm_halo<1, false, 0, 3, 32, false, false, true>), grid, lds_halo, 1, (float*)nullptr, 0);
+            else LISEC_FL((k_igemm_halo<1, false, 0, 2, 32, false, false, true>), grid, lds_halo, 1, (float*)nullptr, 0);
+            LISEC_LAUNCH_CHECK();
+            return LISEC_OK;
+        }
+        if (p.tile0_tail > 0) {
+            dim3 grid(p.tile0_tail, nnb, 1);
+            if (!halo) LISEC_FL((k_igemm<1, false, 0, 64, false, true>), grid, lds, 1, (float*)nullptr, 0);
+            else if (halo3) LISEC_FL((k_igemm_halo<1, false, 0, 3, 64, false, false, true>), grid, lds_halo, 1, (float*)nullptr, 0);
+            else LISEC_FL((k_igemm_halo<1, false, 0, 2, 64, false, false, true>), grid, lds_halo, 1, (float*)nullptr, 0);
+        }
+        if (p.tile0_tail < ntiles) {
+            LISEC_CHECK_ARG(((uintptr_t)workspace & 15) == 0, "split-K needs a 16-byte aligned workspace");
+            float* partial = static_cast<float*>(workspace);
+            dim3 grid(ntiles - p.tile0_tail, nnb, p.nsplit);
+            if (p.db) {
+                if (!halo) LISEC_FL((k_igemm<1, false, 0, 64, true, true>), grid, 2 * lds, p.nsplit, partial, p.tile0_tail);
+                else if (halo3) LISEC_FL((k_igemm_halo<1, false, 0, 3, 64, true, false, true>), grid, 2 * lds_halo, p.nsplit, partial, p.tile0_tail);
+                else LISEC_FL((k_igemm_halo<1, false, 0, 2, 64, true, false, true>), grid, 2 * lds_halo, p.nsplit, partial, p.tile0_tail);
+            } else {
+                if (!halo) LISEC_FL((k_igemm<1, false, 0, 64, false, true>), grid, lds, p.nsplit, partial, p.tile0_tail);
+                else if (halo3) LISEC_FL((k_igemm_halo<1, false, 0, 3, 64, false, false, true>), grid, lds_halo, p.nsplit, partial, p.tile0_tail);
+                else LISEC_FL((k_igemm_halo<1, false, 0, 2, 64, false, false, true>), grid, lds_halo, p.nsplit, partial, p.tile0_tail);
+            }
+        }
+#undef LISEC_FL
+        LISEC_LAUNCH_CHECK();
+        return LISEC_OK;
+    }
     if (p.half_n) {
         dim3 grid(ntiles, cdiv(g.Cout, 32), 1);       // (no workgroups for column blocks beyond Cout: the 16-column heads)
 #define LISEC_HN(KERNEL_, LDS_) LISEC_LAUNCH(KERNEL_, grid, dim3(kThreads), LDS_, st, g, in, packed_w, bias, in_bnstate, \

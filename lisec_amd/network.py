@@ -179,6 +179,10 @@ class LisecNet:
 
         self.branch_overlap = _lib.knob("branch_overlap", True)
         self._tail_ok = {}
+        self._fold_ok = {}
+        # BatchNormalization backward applied on load by the next data gradient: 0 = never (default: measured equal at best),
+        # 1 = on the w-halo kernels of the small maps (see _fold_supported), 2 = everywhere (4 % slower)
+        self.fold_bn_bwd = _lib.knob("fold_bn_bwd", 0)
         self.early_sgd = _lib.knob("early_sgd", True)           # RPN + head variables updated under the rest of the backward pass
         self._early_from = None
         self.mid_wgrad_first = _lib.knob("mid_wgrad_first", True)   # ring weight gradient enqueued before the block's data gradient
@@ -306,6 +310,19 @@ class LisecNet:
     def _wait(ev, stream):
         ev.wait(stream.cuda_stream)
 
+    def _mark(self, name):
+        """Diagnostic (tools/phase_times.py): with self.phase_marks a dict, a timing event is recorded on the main stream
+        here -- through the library, so that a step plan replays it -- and in-step phase durations can be read back
+        WITHOUT a profiler (rocprofv3's kernel trace makes the host the bottleneck wherever many small kernels are launched
+        and shows gaps that a plain run does not have)."""
+        marks = getattr(self, "phase_marks", None)
+        if marks is None:
+            return
+        ev = marks.get(name)
+        if ev is None:
+            ev = marks[name] = _lib.DeviceEvent(timing=True)
+        ev.record(_lib.current_stream())
+
     def dense_grid(self, rewrite=True):
         """The dense (D,H,W,64) VFE output; rewrite: fill it from the last forward's per-voxel values (the field form
         of the first Conv3D never writes it)."""
@@ -350,7 +367,9 @@ class LisecNet:
             self._wait(self._pack_done, torch.cuda.current_stream())
             self._pack_pending = False
         side_used = False
+        self._mark("fwd:start")
         for L in self.layers:
+            self._mark("fwd:before " + L["name"])
             if L["kind"] == "mid":
                 n = L["name"]
                 if L["src"] == "grid" and use_field:
@@ -509,13 +528,22 @@ class LisecNet:
         # the stride-1 convolutions of an RPN block (model_training.py:210-214) share ONE weight-gradient launch: maps of
         # 1 250 - 20 000 positions fill a fraction of the chip each, and as leaves of the backward pass they can wait for each
         # other (lisec_conv_wgrad_batched)
+        # BatchNormalization backward folded into the NEXT data gradient's load (fold_bn_bwd): the chain reads the raw
+        # gradient d[dst] and applies the backward on load; the weight gradient (second stream) reads the applied gradient
+        # from a buffer of its own, written by an apply launch on THAT stream -- off the chain
+        self.dyb = {}
+        if self.fold_bn_bwd:
+            for L in self.layers:
+                if L["kind"] == "conv":
+                    self.dyb[L["dst"]] = torch.empty_like(self.dact[L["dst"]])
         self.wgrad_batches = {}
         if _lib.knob("wgrad_batch", True):
             for b in range(len(RPN_BLOCKS)):
                 convs = [L for L in self.layers if L["kind"] == "conv" and L["name"].startswith(f"rpn{b+1}.conv")
                          and L["name"] != f"rpn{b+1}.conv0"]
-                items = [(L["conv"].g, self.act[L["src"]], self.dact[L["dst"]], p.grad_view(self.grad, L["conv"].wname),
-                          self.bnstate[L["conv"].in_bn], ops.IN_RELU, False) for L in convs]
+                items = [(L["conv"].g, self.act[L["src"]], self.dyb.get(L["dst"], self.dact[L["dst"]]),
+                          p.grad_view(self.grad, L["conv"].wname), self.bnstate[L["conv"].in_bn], ops.IN_RELU, False)
+                         for L in convs]
                 if 2 <= len(items) <= 6:
                     batch = ops.WgradBatch(items)
                     ws_bytes = max(ws_bytes, batch.workspace_bytes())
@@ -568,6 +596,23 @@ class LisecNet:
             return self._backward(y_cls, y_reg, loss, grad_scale, rpn_grads_ready, side_filler)
         finally:
             _lib.pin_stream(prev_pin)
+
+    def _fold_supported(self, c, dst):
+        """Does the data gradient of conv `c` take the BatchNormalization backward of its input gradient on load?  (asked of
+        the library once per layer)"""
+        ok = self._fold_ok.get(c.name)
+        if ok is None:
+            try:
+                sink = self._bwd_sink(c.bn, c.g.Cout, c.M)
+                plan = ops.conv_plan(self.dgeom[c.name], fold=(self.act[dst], self.bnstate[c.bn], sink.coef, True))
+                # measured per layer (tools/phase_times.py, round 4): the fold pays where the A tile is staged once per three
+                # K steps (w-halo kernels of the small maps: -3.5 us per layer); on the generic gather (a second operand
+                # load in EVERY step of a lone wave) and on the 3-per-CU kernels it costs 4 - 44 us per layer
+                ok = self.fold_bn_bwd == 2 or (plan["kernel"] == "halo3" and plan["double_buffered"] == 1)
+            except _lib.LisecError:
+                ok = False
+            self._fold_ok[c.name] = ok
+        return ok
 
     def _tail_supported(self, c, dst_name):
         """Can the Dense data gradient of block dst_name[:-2] ride on the data gradient of conv `c`?  (asked of the library
@@ -656,6 +701,7 @@ class LisecNet:
             pending.append((fn, torch_ops))
             flush_side()
 
+        self._mark("bwd:start")
         kind = {"mse": 0, "smoothl1_ce": 1}[loss]
         ops.rpn_loss(a["head"], y_cls, y_reg, M, kind, d["head"], self.loss_out, grad_scale=grad_scale)
         # ---- heads (model_training.py:254-255) ---------------------------------------------------
@@ -705,7 +751,7 @@ class LisecNet:
         early_dst = {}                         # gradient buffer -> event behind a contribution made on the second stream
         fused_dense = {}                       # middle block -> backward sink of a Dense data gradient that rode on a tile
 
-        def dgrad_into(c, dy, dst_name, ws_tag="main"):
+        def dgrad_into(c, dy, dst_name, ws_tag="main", fold=None):
             ev = early_dst.pop(dst_name, None) if ws_tag == "main" else None
             if ev is not None:
                 self._wait(ev, main)           # the branch's contribution is stored before this one accumulates onto it
@@ -733,7 +779,7 @@ class LisecNet:
                 tail = (self.packed_t[dn.name][0], d[n + ".z"])
                 fused_dense[n] = sink
             ops.conv_forward(self.dgeom[c.name], dy, self.packed_t[c.name][0], d[dst_name], flags=flags, out_mask=mask,
-                             bwd=bwd, sink=sink, ws_tag=ws_tag, tail=tail)
+                             bwd=bwd, sink=sink, ws_tag=ws_tag, tail=tail, fold=fold)
             first_write.add(dst_name)
 
         def branch_dy(L):
@@ -786,6 +832,7 @@ class LisecNet:
 
         for L in reversed(layers):
             c = L["conv"]
+            self._mark("bwd:before " + L["name"])
             if L["kind"] == "deconv":
                 if L["name"] in early_layers:
                     continue
@@ -808,13 +855,27 @@ class LisecNet:
                 dst = L["dst"]
                 C = c.g.Cout
                 is_first_rpn = L["name"] == "rpn1.conv0"
-                if dst in bwd_ready:
-                    # dgamma / dbeta / coefficients were finalised inside the data-gradient call that stored d[dst]
+                fold = None
+                grad_w = d[dst]                        # what the weight gradient of this layer contracts against
+                if dst in bwd_ready and self.fold_bn_bwd and dst in self.dyb and self._fold_supported(c, dst):
+                    # dgamma / dbeta / coefficients were finalised inside the data-gradient call that stored d[dst]; the apply
+                    # pass rides on the load of this layer's data gradient (no launch on the chain), and runs as a launch of
+                    # the second stream into a buffer of its own for the weight gradient
+                    coef = bwd_ready.pop(dst).coef
+                    fold = (a[dst], self.bnstate[c.bn], coef, True)
+                    grad_w = self.dyb[dst]
+                    if not skip_leaves:
+                        pending.append((lambda dst=dst, C=C, c=c, coef=coef, grad_w=grad_w: ops.bn_backward_apply_coef(
+                            d[dst], C, a[dst], self.bnstate[c.bn], c.M, C, True, coef, grad_w), False))
+                elif dst in bwd_ready:
                     ops.bn_backward_apply_coef(d[dst], C, a[dst], self.bnstate[c.bn], c.M, C, True,
                                                bwd_ready.pop(dst).coef, d[dst])
                 else:
                     ops.bn_backward(d[dst], C, a[dst], self.bnstate[c.bn], c.M, C, True,
                                     p.grad_view(G, c.bn + ".gamma"), p.grad_view(G, c.bn + ".beta"), d[dst])
+                if fold is None and dst in self.dyb and L["name"] in batched_convs:
+                    # (the batched weight gradients were built over the dyb buffers: hand them the gradient applied in place)
+                    pending.append((lambda dst=dst: self.dyb[dst].copy_(d[dst]), True))
                 # the bias of a conv feeding a training-mode BN has gradient sum(dy) == 0 identically (BN removes
                 # the mean); Keras' autograd returns rounding noise there -- the exact 0 stays in self.grad
                 if L["name"] in batched_convs:
@@ -823,13 +884,13 @@ class LisecNet:
                     if L["name"] in self.wgrad_batches:
                         on_side(lambda batch=self.wgrad_batches[L["name"]][0]: batch.run(self.wgrad_ws))
                 else:
-                    on_side(lambda L=L, c=c, dst=dst: ops.conv_wgrad(
-                        c.g, a[L["src"]], d[dst], p.grad_view(G, c.wname), self.wgrad_ws,
+                    on_side(lambda L=L, c=c, grad_w=grad_w: ops.conv_wgrad(
+                        c.g, a[L["src"]], grad_w, p.grad_view(G, c.wname), self.wgrad_ws,
                         in_bn=self.bnstate[c.in_bn] if c.in_bn else None, flags=ops.IN_RELU if c.in_relu else 0))
                 if is_first_rpn and rpn_grads_ready is not None:
                     lo = p.offsets["rpn1.conv0.kernel"][1]
                     on_side(lambda lo=lo: rpn_grads_ready(lo, p.n_theta), torch_ops=True)
-                dgrad_into(c, d[dst], L["src"])
+                dgrad_into(c, d[dst], L["src"], fold=fold)
                 if L["src"] == "fold":
                     # back through Permute + Reshape, gated by the ReLU of the last middle block's Dense (:195)
                     ops.fold_depth(d["fold"], d[self.fold_src], self.dprime, self.H * self.W, 64, inverse=True,
@@ -882,12 +943,15 @@ class LisecNet:
                         dgrad_into(c, d[n + ".z"], L["src"])
                         on_side(wg)
         # ---- VFE -----------------------------------------------------------------------------------
+        self._mark("bwd:before vfe")
         flush_side()
         self.vfe.backward(None, G, dout_rows=self.dout_rows, g_all=self.g_all)
         if self._join_event is None:
             self._join_event = self._new_event()
+        self._mark("bwd:vfe done")
         self._record(self._join_event, self.side)
         self._wait(self._join_event, main)     # every weight gradient has landed before the optimizer reads G
+        self._mark("bwd:joined")
         return self.loss_out
 
     def early_update(self, lo, hi, lr=0.01, decay=1e-6, momentum=0.9):
@@ -916,6 +980,7 @@ class LisecNet:
                                       self._iter_dev)
         else:
             ops.sgd_nesterov_step_dev(self.params.theta, self.grad, self.velocity, lr, decay, momentum, self._iter_dev)
+        self._mark("step:updated")
         self._iterations += 1
         self.params_version += 1
         if self._train_ready and self.early_pack:

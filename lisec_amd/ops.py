@@ -134,8 +134,14 @@ class BnSink:
         self.ref = ctypes.pointer(d)
 
 
+def _fold_fields(fold):
+    if fold is None:
+        return None, None, None, 0
+    return _lib.ptr(fold[0]), _lib.ptr(fold[1]), _lib.ptr(fold[2]), 1 if fold[3] else 0
+
+
 def conv_forward(g, x, wp, out, bias=None, in_bn=None, flags=0, stats=None, splitk=True, rows=None, out_mask=None,
-                 bwd=None, sink=None, ws_tag="main", queue=None, tail=None):
+                 bwd=None, sink=None, ws_tag="main", queue=None, tail=None, fold=None):
     """rows: optional (row_coords int32 (cap,3), row_count int32 device scalar, capacity) row list.
     out_mask: optional tensor laid out like `out`; values are stored as 0 where out_mask <= 0.
     bwd: optional (y, bnstate, relu): `out` is a gradient about to cross that BatchNormalization(+ReLU) backwards and
@@ -144,13 +150,16 @@ def conv_forward(g, x, wp, out, bias=None, in_bn=None, flags=0, stats=None, spli
     queue: optional int32[2] device tensor, zero before its first use: lets a big row list run as resident workgroups
     that draw their tiles from a counter (lisec_conv_extras.queue).
     tail: optional (packed 64 x 64 kernel, out2): out2 = out (as stored) @ kernel rides on the tile; bwd / sink then describe
-    out2 (lisec_conv_extras.tail_w)."""
+    out2 (lisec_conv_extras.tail_w).
+    fold: optional (y, bnstate, coef, relu): x is a gradient about to cross that BatchNormalization(+ReLU) backwards and the
+    apply pass runs on load (lisec_conv_extras.in_y)."""
     rc, rn, cap = rows if rows is not None else (None, None, 0)
     ws = conv_workspace(g, out.device, cap, ws_tag) if splitk else None
     ex = _lib.ConvExtras(_lib.ptr(out_mask), _lib.ptr(bwd[0]) if bwd is not None else None,
                          _lib.ptr(bwd[1]) if bwd is not None else None, 1 if (bwd is not None and bwd[2]) else 0,
                          sink.ref if sink is not None else None, _lib.ptr(queue),
-                         _lib.ptr(tail[0]) if tail is not None else None, _lib.ptr(tail[1]) if tail is not None else None)
+                         _lib.ptr(tail[0]) if tail is not None else None, _lib.ptr(tail[1]) if tail is not None else None,
+                         *_fold_fields(fold))
     _lib.check(_lib.load().lisec_conv_forward_ex(ctypes.byref(g), _lib.ptr(x), _lib.ptr(wp), _lib.ptr(bias),
                                                  _lib.ptr(in_bn), flags, _lib.ptr(out), ctypes.byref(ex),
                                                  _lib.ptr(stats), _lib.ptr(ws),
@@ -160,7 +169,7 @@ def conv_forward(g, x, wp, out, bias=None, in_bn=None, flags=0, stats=None, spli
 
 
 def conv_plan(g, in_bn=False, flags=0, stats=False, splitk=True, rows_capacity=0, out_mask=None, bwd=None, sink=None,
-              queue=None, tail=None):
+              queue=None, tail=None, fold=None):
     """The launch plan conv_forward(...) with the same arguments runs (lisec_conv_plan_query), as a dict."""
     lib = _lib.load()
     ws_bytes = 0
@@ -170,7 +179,8 @@ def conv_plan(g, in_bn=False, flags=0, stats=False, splitk=True, rows_capacity=0
     ex = _lib.ConvExtras(_lib.ptr(out_mask), _lib.ptr(bwd[0]) if bwd is not None else None,
                          _lib.ptr(bwd[1]) if bwd is not None else None, 1 if (bwd is not None and bwd[2]) else 0,
                          sink.ref if sink is not None else None, _lib.ptr(queue),
-                         _lib.ptr(tail[0]) if tail is not None else None, _lib.ptr(tail[1]) if tail is not None else None)
+                         _lib.ptr(tail[0]) if tail is not None else None, _lib.ptr(tail[1]) if tail is not None else None,
+                         *_fold_fields(fold))
     plan = _lib.ConvPlan()
     _lib.check(lib.lisec_conv_plan_query(ctypes.byref(g), 1 if in_bn else 0, flags, ctypes.byref(ex), 1 if stats else 0,
                                          ws_bytes, 1 if rows_capacity > 0 else 0, rows_capacity, ctypes.byref(plan)))

@@ -191,6 +191,45 @@ def test_data_gradient(case):
         assert np.abs(coef[:cout] - db / M).max() <= tol_s / M and np.abs(coef[cout:] - dg / M).max() <= 3 * tol_s / M, name
 
 
+@pytest.mark.parametrize("case", [c for c in DGRAD if c[0].startswith("rpn") and "[" not in c[0]],
+                         ids=[c[0] for c in DGRAD if c[0].startswith("rpn") and "[" not in c[0]])
+def test_data_gradient_with_bn_backward_on_load(case):
+    """lisec_conv_extras.in_y: the gradient the contraction gathers is w.r.t. the OUTPUT of the layer's BatchNormalization +
+    ReLU (model_training.py:204-206); the apply pass of that backward -- scale (gate(y) g - mean(dz) - yhat mean(dz yhat)) --
+    runs on load, with the constants a backward sink finalised.  Against apply-then-contract in fp64, every RPN geometry."""
+    from lisec_amd import _lib, ops
+    from oracle import conv_ref
+    name, mode, ind, outd, k, s, p, cin, cout, kind, expect = case
+    _lib.set_tuning(wide_tile=0)
+    dev = torch.device("cuda")
+    rng = np.random.default_rng(seed_of("fold" + name))
+    ntaps = k[0] * k[1] * k[2]
+    gq = rng.normal(0, 1, (*ind, cin)).astype(np.float32)              # gradient w.r.t. relu(bn(y))
+    y = rng.normal(0, 1, (*ind, cin)).astype(np.float32)               # raw output of the layer the gradient belongs to
+    st_dev, (scale, shift) = make_bn(rng, cin, dev)
+    st = st_dev.cpu().numpy().astype(np.float64)
+    mean, invstd = st[2 * cin:3 * cin], st[3 * cin:]
+    y64, g64 = y.astype(np.float64), gq.astype(np.float64)
+    dz = np.where(y64 * scale + shift > 0, g64, 0.0)
+    yhat = (y64 - mean) * invstd
+    m1, m2 = dz.reshape(-1, cin).mean(0), (dz * yhat).reshape(-1, cin).mean(0)
+    coef = torch.from_numpy(np.concatenate([m1, m2]).astype(np.float32)).to(dev)
+    c32 = coef.cpu().numpy().astype(np.float64)
+    dy = scale * (dz - c32[:cin] - yhat * c32[cin:])                   # what lisec_bn_backward_apply_coef writes
+    Wt = (rng.normal(0, 1, (ntaps, cin, cout)) / np.sqrt(ntaps * cin)).astype(np.float32)
+    geo = ops.geom(mode, ind, outd, k, s, p, cin, cout)
+    wp = ops.pack_weights(torch.from_numpy(Wt).to(dev), ntaps, cin, cout, cin * cout, cout, 1)
+    out = torch.full((*outd, cout), float("nan"), device=dev)
+    fold = (torch.from_numpy(y).to(dev), st_dev, coef, True)
+    plan = ops.conv_plan(geo, fold=fold)
+    check_plan(plan, {k_: v for k_, v in expect.items() if k_ in ("kernel", "cols", "k_slices", "parity_classes", "double_buffered")})
+    ops.conv_forward(geo, torch.from_numpy(gq).to(dev), wp, out, fold=fold)
+    torch.cuda.synchronize()
+    ref = conv_ref.conv_forward(dy, Wt, outd, k, s, p, mode=mode)
+    e = rel_l2(out.cpu().numpy(), ref, note="data gradient, BatchNormalization backward on load " + name)
+    assert e <= TOL, f"{name}: relative L2 {e:.2e}"
+
+
 @pytest.mark.parametrize("case", [c for c in DGRAD if c[0] in ("mid2", "mid3")], ids=["mid2", "mid3"])
 def test_data_gradient_with_dense_tail(case):
     """The Dense(64, relu) data gradient of the block below riding on the tile (lisec_conv_extras.tail_w,

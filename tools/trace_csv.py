@@ -13,7 +13,10 @@ rows.sort(key=lambda r: r["s"])
 step = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].isdigit() else 8
 # a step ends with the optimizer update (the voxeliser is no step boundary any more: PipelinedStep runs the NEXT sweep's
 # voxelisation on the second stream in the middle of the backward pass)
-idx = [i + 1 for i, r in enumerate(rows) if "k_sgd_nesterov" in r["Kernel_Name"]]
+# (two optimizer launches per step since round 4: the RPN + head variables early, the rest -- the SMALLER grid -- at the end)
+sgd = [r for r in rows if "k_sgd_nesterov" in r["Kernel_Name"]]
+gmin = min(int(r["Grid_Size_X"]) for r in sgd)
+idx = [i + 1 for i, r in enumerate(rows) if "k_sgd_nesterov" in r["Kernel_Name"] and int(r["Grid_Size_X"]) == gmin]
 a, b = idx[step], idx[step + 1]
 t0 = rows[a - 1]["e"]
 agg = defaultdict(lambda: [0, 0.0])
