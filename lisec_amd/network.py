@@ -185,6 +185,7 @@ class LisecNet:
         self.fold_bn_bwd = _lib.knob("fold_bn_bwd", 0)
         self.early_sgd = _lib.knob("early_sgd", True)           # RPN + head variables updated under the rest of the backward pass
         self._early_from = None
+        self.dense_wgrad_late = _lib.knob("dense_wgrad_late", True)   # Dense weight gradient behind the block's ring weight gradient
         self.mid_wgrad_first = _lib.knob("mid_wgrad_first", True)   # ring weight gradient enqueued before the block's data gradient
         self.fuse_dense_bwd = _lib.knob("fuse_dense_bwd", True)   # Dense(64) data gradients ride on the tile of the block above
         self.chain_first = _lib.knob("chain_first", True)      # head phase: the chain's contraction is enqueued before the leaves
@@ -897,8 +898,14 @@ class LisecNet:
                                    mask=a[self.fold_src])
             else:   # mid layer: conv3d -> BN -> Dense(relu)
                 n, dn = L["name"], L["dense"]
-                on_side(lambda n=n, dn=dn: ops.conv_wgrad(dn.g, a[n + ".y"], d[n + ".u"], p.grad_view(G, dn.wname),
-                                                          self.wgrad_ws, in_bn=self.bnstate[dn.in_bn]))
+                dense_wg = lambda n=n, dn=dn: ops.conv_wgrad(dn.g, a[n + ".y"], d[n + ".u"], p.grad_view(G, dn.wname),
+                                                             self.wgrad_ws, in_bn=self.bnstate[dn.in_bn])
+                # the Dense weight gradient (HBM-bound, 52 granules of LDS) finds no room beside three data-gradient
+                # workgroups per CU and waited 474 us in the queue IN FRONT of the block's ring weight gradient: behind it
+                # (dense_wgrad_late) the ring kernel starts as soon as its gradient exists
+                late_dense = self.dense_wgrad_late and self.mid_wgrad_first and L["src"] != "grid"
+                if not late_dense:
+                    on_side(dense_wg)
                 # Dense data gradient; its store also reduces the statistics of the BatchNormalization under it
                 if n in fused_dense:
                     msink = fused_dense.pop(n)         # done inside the data gradient of the block above (dgrad_into)
@@ -938,6 +945,9 @@ class LisecNet:
                                                               self.wgrad_ws)
                     if self.mid_wgrad_first:
                         on_side(wg)
+                        if late_dense:
+                            pending.append((dense_wg, False))
+                            flush_side()
                         dgrad_into(c, d[n + ".z"], L["src"])
                     else:
                         dgrad_into(c, d[n + ".z"], L["src"])
