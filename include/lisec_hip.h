@@ -352,6 +352,30 @@ int lisec_conv_forward(const lisec_conv_geom* g, const float* in, const float* p
                        void* workspace, size_t workspace_bytes, const int32_t* row_coords,
                        const int32_t* row_count, int row_capacity, lisec_stream_t stream);
 
+/* Winograd F(2x2, 3x3) form of lisec_conv_forward_ex (csrc/wino.hip) for contractions with 3 x 3 (h, w) taps, stride 1 and
+ * padding 1 along h and w, any depth taps / depth stride, both gather modes: the Conv3D middle blocks
+ * (model_training.py:193, 237-238), the stride-1 Conv2Ds of the RPN (:210-214) and the data gradients of both.  Same
+ * arithmetic contract as lisec_conv_forward_ex -- fp32 operands, fp32 accumulation, in_bnstate / LISEC_CONV_IN_RELU applied
+ * on load with exact zero padding, bias, LISEC_CONV_ACCUMULATE / LISEC_CONV_OUT_RELU, extras.out_mask, extras.bwd_y +
+ * a LISEC_SINK_BACKWARD sink, or a LISEC_SINK_FORWARD sink -- with 4 / 9 of the multiplications: a 2 x 2 block of outputs is
+ * A^T [ sum_c (G g G^T) . (B^T d B) ] A.  Results differ from lisec_conv_forward_ex by fp32 rounding only (the transforms add
+ * and halve exactly representable values; tests/test_gpu_winograd.py holds both against the fp64 oracle).
+ *   lisec_conv_pack_weights_winograd: G g G^T of every (depth tap, k, n) kernel slice, in the LDS image order of the kernel.
+ *       src element (tap, k, n), tap = (kd * 3 + kh) * 3 + kw, is read at src[tap*tap_stride + k*k_stride + n*n_stride];
+ *       flip_hw != 0 mirrors the (kh, kw) taps -- the data gradient of a stride-1 correlation is the correlation with the
+ *       mirrored kernel and K / N swapped (k_stride / n_stride), so g->mode == 1 calls take a kernel packed with flip_hw = 1.
+ *       dst: lisec_conv_winograd_packed_floats(KD, K, N) floats, 16-byte aligned.
+ *   lisec_conv_winograd_supported: 1 when lisec_conv_forward_winograd serves these arguments (extras: only the fields named
+ *       above; statistics only through a sink; Cin % 8 == 0), else 0 -- nothing is launched.
+ *   lisec_conv_forward_winograd: no workspace (never K-sliced); LISEC_EINVAL for arguments it does not serve. */
+size_t lisec_conv_winograd_packed_floats(int KD, int K, int N);
+int lisec_conv_pack_weights_winograd(const float* src, int KD, int K, int N, long long tap_stride, long long k_stride,
+                                     long long n_stride, int flip_hw, float* dst, lisec_stream_t stream);
+int lisec_conv_winograd_supported(const lisec_conv_geom* g, int has_in_bnstate, int flags, const lisec_conv_extras* extras);
+int lisec_conv_forward_winograd(const lisec_conv_geom* g, const float* in, const float* wino_w, const float* bias,
+                                const float* in_bnstate, int flags, float* out, const lisec_conv_extras* extras,
+                                lisec_stream_t stream);
+
 /* Weight gradient of the contraction described by `g` (the geometry of the FORWARD layer):
  *   dW[tap][c][n] = sum_m f(in[src(m,tap), c]) * dy[m, n]      dy: float32, g->out_stride floats per row
  * Written in the Keras kernel layout (taps, Cin, Cout); transpose_out != 0 writes (taps, Cout, Cin),
@@ -721,6 +745,7 @@ int lisec_debug_igemm_stamps(unsigned long long* buf);
 int lisec_debug_wgrad_stamps(unsigned long long* buf);
 int lisec_debug_vfe_stamps(unsigned long long* buf);
 int lisec_debug_field_stamps(unsigned long long* buf);
+int lisec_debug_wino_stamps(unsigned long long* buf);
 
 #ifdef __cplusplus
 }

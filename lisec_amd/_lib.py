@@ -165,6 +165,14 @@ def _declare(lib):
     lib.lisec_conv_forward_ex.restype = c_int
     lib.lisec_conv_forward_ex.argtypes = [POINTER(ConvGeom), P, P, P, P, c_int, P, POINTER(ConvExtras), P, P, c_size_t, P, P,
                                           c_int, P]
+    lib.lisec_conv_winograd_packed_floats.restype = c_size_t
+    lib.lisec_conv_winograd_packed_floats.argtypes = [c_int, c_int, c_int]
+    lib.lisec_conv_pack_weights_winograd.restype = c_int
+    lib.lisec_conv_pack_weights_winograd.argtypes = [P, c_int, c_int, c_int, LL, LL, LL, c_int, P, P]
+    lib.lisec_conv_winograd_supported.restype = c_int
+    lib.lisec_conv_winograd_supported.argtypes = [POINTER(ConvGeom), c_int, c_int, POINTER(ConvExtras)]
+    lib.lisec_conv_forward_winograd.restype = c_int
+    lib.lisec_conv_forward_winograd.argtypes = [POINTER(ConvGeom), P, P, P, P, c_int, P, POINTER(ConvExtras), P]
     lib.lisec_conv_num_mblocks_bwd.restype = c_int
     lib.lisec_conv_num_mblocks_bwd.argtypes = [POINTER(ConvGeom)]
     lib.lisec_bn_backward_apply.restype = c_int
@@ -254,7 +262,8 @@ def _declare(lib):
     lib.lisec_tuning_get.argtypes = [POINTER(Tuning)]
     lib.lisec_tuning_set.restype = c_int
     lib.lisec_tuning_set.argtypes = [POINTER(Tuning)]
-    for name in ("lisec_debug_igemm_stamps", "lisec_debug_wgrad_stamps", "lisec_debug_vfe_stamps", "lisec_debug_field_stamps"):
+    for name in ("lisec_debug_igemm_stamps", "lisec_debug_wgrad_stamps", "lisec_debug_vfe_stamps", "lisec_debug_field_stamps",
+                 "lisec_debug_wino_stamps"):
         getattr(lib, name).restype = c_int
         getattr(lib, name).argtypes = [P]
     lib.lisec_bn_finalize.restype = c_int

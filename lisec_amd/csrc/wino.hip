@@ -1,0 +1,502 @@
+// Winograd F(2x2, 3x3) form of the stride-1 3x3 (h, w) contractions on the fp32 matrix cores of gfx950.
+//
+// The middle Conv3D blocks (model_training.py:193, 237-238), the stride-1 Conv2Ds of the first RPN block (:210-214) and their
+// data gradients run at the POWER ceiling of v_mfma_f32_32x32x2_f32 (~122 TFLOP/s executed): what is
+// left is fewer MFMAs per output.  For a 3x3 stride-1 pad-1 correlation a 2x2 block of outputs is
+//     Y = A^T [ sum_c (G g_c G^T) . (B^T d_c B) ] A          (Lavin & Gray; d: 4x4 input patch, g: 3x3 kernel)
+// 16 products per channel pair instead of 36: the layer becomes 16 independent contractions (one per transform point)
+//     M_pt[tile, n] = sum_{kd} sum_c V_pt[tile, (kd, c)] * U_pt[(kd, c), n]
+// over tiles x (depth taps x Cin) x Cout -- 4 / 9 of the MFMAs of the direct form.  fp32 in / fp32 accumulate throughout;
+// B^T and A^T hold only 0 and +-1 (exact adds), G holds +-1/2 (exact scalings): the result differs from the fmaf chain of the
+// direct kernels by summation order and by the transforms' own roundings (measured in tests/test_gpu_winograd.py against
+// the fp64 oracle, same bound as the direct kernels).
+//
+// One 256-thread workgroup (one wave per SIMD, one workgroup per CU: 256 accumulator registers per lane) owns 8 x 8
+// Winograd tiles (16 x 16 outputs) of one output plane x 64 output channels; wave (wm, wn) owns 32 tiles x 32 channels x
+// ALL 16 points, so the output transform is lane-local (accumulator register r of every point is the same (tile, channel)).
+// K runs in chunks of 8 input channels of one depth tap; per chunk
+//   V[pt][tile][8]  -- each thread loads the 4 x 4 patch of one (tile, channel pair) straight from global memory (two
+//                      channels = 8 bytes per position; the BatchNormalization(+ReLU) of the producing layer is applied
+//                      here, padding stays exactly zero), transforms it (32 adds per channel) and stores 16 x 8 bytes
+//   U[pt][n][8]     -- linear 32 KB copy of the pre-transformed kernel (lisec_conv_pack_weights_winograd writes the LDS
+//                      image, swizzle included)
+//   64 MFMAs per wave: per point one ds_read_b128 of V and one of U (four K steps each).
+// Two LDS stages (128 KB): the image of chunk c + 1 is built while the MFMAs of chunk c read the other one; one barrier
+// per chunk.  Rows of V / U are 32 bytes; the 16-byte half a lane reads is swizzled by bit 3 of the row so that every
+// 16-lane group of a ds_read_b128 covers all 64 banks.
+#include "conv.h"
+
+namespace lisec {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kWinoThreads = 256;
+constexpr int WT = 64;                      // Winograd tiles per workgroup (8 x 8)
+constexpr int WN = 64;                      // output channels per workgroup
+constexpr int WK = 8;                       // input channels per K chunk
+constexpr int V_FLOATS = 16 * WT * WK;      // 8192
+constexpr int U_FLOATS = 16 * WN * WK;      // 8192
+constexpr int STAGE_FLOATS = V_FLOATS + U_FLOATS;
+constexpr size_t kWinoLds = 2 * STAGE_FLOATS * sizeof(float);      // 131072
+
+// float index of element k (0..7) of row `row` (0..63) inside one point's [64][8] plane
+__host__ __device__ __forceinline__ int wino_swz(int row, int k) {
+    return row * 8 + ((((k >> 2) ^ ((row >> 3) & 1))) << 2) + (k & 3);
+}
+
+// diagnostic (tools/wino_stamps.py): per workgroup, thread 0: [0] start, [1] first image in LDS, [2] after the K loop, [3] end
+// (100 MHz s_memrealtime), [4] / [5] s_memtime (shader cycles) at [1] / [2], [6] chunks; nullptr (the default) = no stamp executes
+__device__ unsigned long long* g_wino_stamps = nullptr;
+#define WINO_STAMP(K_, V_)                                                                       \
+    do {                                                                                         \
+        if (stamps && threadIdx.x == 0 && stamp_wg < 8192) stamps[(size_t)stamp_wg * 8 + (K_)] = (V_); \
+    } while (0)
+
+template <bool XF>
+__global__ void __launch_bounds__(kWinoThreads) __attribute__((amdgpu_waves_per_eu(1, 1)))
+k_wino(ConvGeom g, int mode, const float* __restrict__ in, const float* __restrict__ U,
+       const float* __restrict__ bias, const float* __restrict__ in_bn, int flags, float* __restrict__ out,
+       int BH, int BW) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int H = g.Ho, W = g.Wo;
+    unsigned long long* stamps = g_wino_stamps;
+    const unsigned stamp_wg = blockIdx.y * gridDim.x + blockIdx.x;
+    WINO_STAMP(0, __builtin_amdgcn_s_memrealtime());
+    // ---- which block ------------------------------------------------------------------------------------------
+    const int blk = xcd_remap(blockIdx.x, gridDim.x);
+    const int per_plane = BH * BW;
+    const int dplane = blk / per_plane;
+    const int brem = blk - dplane * per_plane;
+    const int by = brem / BW, bx = brem - by * BW;
+    const int nb = blockIdx.y;
+    // ---- depth taps of this output plane (wave-uniform): bit kd of dmask = tap kd reads a plane inside the tensor -------------
+    int dmask = 0, npairs = 0;
+#pragma unroll
+    for (int kd = 0; kd < 4; ++kd) {
+        bool ok = kd < g.KD;
+        src_coord(dplane, kd, g.ls_d, g.pd, g.Di, mode, ok);
+        dmask |= ok ? (1 << kd) : 0;
+        npairs += ok ? 1 : 0;
+    }
+    const int ncc = g.Cin / WK;
+    const int nchunks = (flags & 0x4000) ? 0 : npairs * ncc;
+    // ---- the (tile, channel pair) this thread stages ---------------------------------------------------------------
+    const int tl = tid >> 2, cp = tid & 3;
+    const int y0 = 2 * (by * 8 + (tl >> 3)) - 1, x0 = 2 * (bx * 8 + (tl & 7)) - 1;
+    unsigned pmask = 0;                              // bit 4 i + j: patch position (i, j) lies inside the map
+    int poff[16];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool ok = (unsigned)(y0 + i) < (unsigned)H && (unsigned)(x0 + j) < (unsigned)W;
+            pmask |= ok ? (1u << (4 * i + j)) : 0u;
+            poff[4 * i + j] = (ok && !(flags & 0x1000)) ? ((y0 + i) * W + (x0 + j)) * g.in_stride + cp * 2 : 0;
+        }
+    const int vdst = tl * 8 + (((cp >> 1) ^ ((tl >> 3) & 1)) << 2) + (cp & 1) * 2;      // + pt * 512
+    const size_t plane_floats = (size_t)H * W * g.in_stride;
+    const int u_chunk = (flags & 0x2000) ? 0 : 16 * WN * WK;   // floats of one (depth tap, channel chunk, column block) image
+    const int nnb = gridDim.y;
+    const float relu_lo = (flags & LISEC_CONV_IN_RELU) ? 0.f : -INFINITY;
+
+    float2 raw[16];
+    float2 tsc = make_float2(1.f, 1.f), tsh = make_float2(0.f, 0.f);
+    // two walks over the chunk list (depth tap, channel chunk): the patch loads run two chunks ahead of the MFMAs, the U image
+    // one; past the last chunk a walk stays there (the loop body is branch-free so that the compiler can interleave it with
+    // the MFMAs: the surplus image is never read)
+    int r_kd = __builtin_ctz(dmask | 16), r_cc = 0, r_left = nchunks - 1;
+    int u_kd = r_kd, u_cc = 0, u_left = nchunks - 1;
+    auto advance = [&](int& kd, int& cc, int& left) {          // (selects, no branch: the loop body stays one basic block)
+        const bool more = left > 0;
+        const bool wrap = cc + 1 == ncc;
+        const int kd_next = __builtin_ctz((dmask >> (kd + 1)) | 16) + kd + 1;
+        left -= more ? 1 : 0;
+        kd = (more && wrap) ? kd_next : kd;
+        cc = more ? (wrap ? 0 : cc + 1) : cc;
+    };
+    auto issue_raw = [&]() {
+        bool dok = true;
+        const int sd = src_coord(dplane, r_kd, g.ls_d, g.pd, g.Di, mode, dok);
+        const float* src = in + (size_t)sd * plane_floats + r_cc * WK;
+#pragma unroll
+        for (int p = 0; p < 16; ++p) raw[p] = *reinterpret_cast<const float2*>(src + poff[p]);
+        if (XF) {
+            tsc = *reinterpret_cast<const float2*>(in_bn + r_cc * WK + cp * 2);
+            tsh = *reinterpret_cast<const float2*>(in_bn + g.Cin + r_cc * WK + cp * 2);
+        }
+        advance(r_kd, r_cc, r_left);
+    };
+    // U image of one chunk: a linear 32 KB copy through registers (an LDS-DMA piece costs the issuing wave 100-185 cycles
+    // beside MFMAs and LDS reads -- eight of them per chunk were a quarter of the loop -- and makes every barrier wait for
+    // vmcnt(0); a global_load_dwordx4 + ds_write_b128 pair costs ~25 and plain loads stay in flight across the barrier)
+    float4 ub[8];
+    auto issue_u = [&]() {
+        const float* us = U + ((size_t)(u_kd * ncc + u_cc) * nnb + nb) * u_chunk + tid * 4;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) ub[q] = *reinterpret_cast<const float4*>(us + q * 1024);
+        advance(u_kd, u_cc, u_left);
+    };
+    auto store_u = [&](float* stage) {
+        float* up = stage + V_FLOATS + tid * 4;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) *reinterpret_cast<float4*>(up + q * 1024) = ub[q];
+    };
+    auto store_v = [&](float* stage) {
+        // B^T d B on both channels of the pair; padding (and tiles beyond the map) contribute exact zeros
+        float2 d[16];
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+            const bool ok = (pmask >> p) & 1;
+            float2 v = raw[p];
+            if (XF) {
+                v.x = fmaxf(fmaf(v.x, tsc.x, tsh.x), relu_lo);
+                v.y = fmaxf(fmaf(v.y, tsc.y, tsh.y), relu_lo);
+            }
+            d[p].x = ok ? v.x : 0.f;
+            d[p].y = ok ? v.y : 0.f;
+        }
+        float2 t[16];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            t[0 + j].x = d[0 + j].x - d[8 + j].x;   t[0 + j].y = d[0 + j].y - d[8 + j].y;
+            t[4 + j].x = d[4 + j].x + d[8 + j].x;   t[4 + j].y = d[4 + j].y + d[8 + j].y;
+            t[8 + j].x = d[8 + j].x - d[4 + j].x;   t[8 + j].y = d[8 + j].y - d[4 + j].y;
+            t[12 + j].x = d[4 + j].x - d[12 + j].x; t[12 + j].y = d[4 + j].y - d[12 + j].y;
+        }
+        float* vp = stage + vdst;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float2 v0, v1, v2, v3;
+            v0.x = t[4 * i + 0].x - t[4 * i + 2].x; v0.y = t[4 * i + 0].y - t[4 * i + 2].y;
+            v1.x = t[4 * i + 1].x + t[4 * i + 2].x; v1.y = t[4 * i + 1].y + t[4 * i + 2].y;
+            v2.x = t[4 * i + 2].x - t[4 * i + 1].x; v2.y = t[4 * i + 2].y - t[4 * i + 1].y;
+            v3.x = t[4 * i + 1].x - t[4 * i + 3].x; v3.y = t[4 * i + 1].y - t[4 * i + 3].y;
+            *reinterpret_cast<float2*>(vp + (4 * i + 0) * (WT * WK)) = v0;
+            *reinterpret_cast<float2*>(vp + (4 * i + 1) * (WT * WK)) = v1;
+            *reinterpret_cast<float2*>(vp + (4 * i + 2) * (WT * WK)) = v2;
+            *reinterpret_cast<float2*>(vp + (4 * i + 3) * (WT * WK)) = v3;
+        }
+    };
+
+    f32x16 acc[16];
+#pragma unroll
+    for (int p = 0; p < 16; ++p) acc[p] = (f32x16){0};
+
+    const int arow = wm * 32 + (lane & 31), brow = wn * 32 + (lane & 31);
+    const int aoff = arow * 8 + (((lane >> 5) ^ ((arow >> 3) & 1)) << 2);
+    const int boff = V_FLOATS + brow * 8 + (((lane >> 5) ^ ((brow >> 3) & 1)) << 2);
+
+    if (nchunks > 0) {
+        issue_raw();
+        issue_u();
+        store_v(smem);
+        store_u(smem);
+        issue_raw();
+        issue_u();
+    }
+    __syncthreads();
+    WINO_STAMP(1, __builtin_amdgcn_s_memrealtime());
+    WINO_STAMP(4, __builtin_amdgcn_s_memtime());
+    // One wave per SIMD: whatever is not an MFMA has to issue in the shadow of one (64 cycles each, ~13 issue slots), and the
+    // compiler left alone puts the whole transform in front of the MFMAs and the loads behind them, next to the barrier that
+    // waits for them.  The chunk is therefore cut by hand into 16 groups (one per transform point: two fragment reads, four
+    // MFMAs) and every group carries one slice of the side work, pinned by sched_barrier:
+    //   groups 0-3   gate (+ BatchNormalization, ReLU) of patch row i of chunk c + 1; two 16-byte stores of its U image
+    //   groups 4-7   B^T d (column j) -- and the patch loads of chunk c + 2, four per group, into the registers just freed
+    //   groups 8-11  (B^T d) B (row i) and its four 8-byte stores into the other stage
+    //   groups 12-15 the U image of chunk c + 2, two loads per group (in flight across the barrier)
+    float2 d[16], t[16];
+    for (int c = 0; c < nchunks; ++c) {
+        const float* st = smem + (c & 1) * STAGE_FLOATS;
+        float* nx = smem + ((c + 1) & 1) * STAGE_FLOATS;
+        const float* ap = st + aoff;
+        const float* bp = st + boff;
+        float4 a = *reinterpret_cast<const float4*>(ap);
+        float4 b = *reinterpret_cast<const float4*>(bp);
+        typedef __attribute__((address_space(1))) const void* gptr;
+        typedef __attribute__((address_space(3))) void* lptr;
+        const float* us = U + ((size_t)(u_kd * ncc + u_cc) * nnb + nb) * u_chunk + wave * 256 + lane * 4;
+        float* ud = nx + V_FLOATS + wave * 256;
+        bool dok = true;
+        const int sd = src_coord(dplane, r_kd, g.ls_d, g.pd, g.Di, mode, dok);
+        const float* src = in + (size_t)sd * plane_floats + r_cc * WK;
+        const float2 sc = tsc, sh = tsh;             // (chunk c + 1's; the loads below replace them with chunk c + 2's)
+        float* vp = nx + vdst;
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+            float4 an = a, bn = b;
+            if (p + 1 < 16) {
+                an = *reinterpret_cast<const float4*>(ap + (p + 1) * (WT * WK));
+                bn = *reinterpret_cast<const float4*>(bp + (p + 1) * (WN * WK));
+            }
+            if (p < 2) {
+#pragma unroll
+                for (int q = 4 * p; q < 4 * p + 4; ++q)
+                    __builtin_amdgcn_global_load_lds((gptr)(us + q * 1024), (lptr)(ud + q * 1024), 16, 0, 0);
+            }
+            if (p < 4) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int e = 4 * p + j;
+                    const bool ok = (pmask >> e) & 1;
+                    float2 v = raw[e];
+                    if (XF) {
+                        v.x = fmaxf(fmaf(v.x, sc.x, sh.x), relu_lo);
+                        v.y = fmaxf(fmaf(v.y, sc.y, sh.y), relu_lo);
+                    }
+                    d[e].x = ok ? v.x : 0.f;
+                    d[e].y = ok ? v.y : 0.f;
+                }
+            } else if (p < 8) {
+                const int j = p - 4;
+                t[0 + j].x = d[0 + j].x - d[8 + j].x;   t[0 + j].y = d[0 + j].y - d[8 + j].y;
+                t[4 + j].x = d[4 + j].x + d[8 + j].x;   t[4 + j].y = d[4 + j].y + d[8 + j].y;
+                t[8 + j].x = d[8 + j].x - d[4 + j].x;   t[8 + j].y = d[8 + j].y - d[4 + j].y;
+                t[12 + j].x = d[4 + j].x - d[12 + j].x; t[12 + j].y = d[4 + j].y - d[12 + j].y;
+#pragma unroll
+                for (int e = 4 * j; e < 4 * j + 4; ++e) raw[e] = *reinterpret_cast<const float2*>(src + poff[e]);
+                if (XF && p == 4) {
+                    tsc = *reinterpret_cast<const float2*>(in_bn + r_cc * WK + cp * 2);
+                    tsh = *reinterpret_cast<const float2*>(in_bn + g.Cin + r_cc * WK + cp * 2);
+                }
+            } else if (p < 12) {
+                const int i = p - 8;
+                float2 v0, v1, v2, v3;
+                v0.x = t[4 * i + 0].x - t[4 * i + 2].x; v0.y = t[4 * i + 0].y - t[4 * i + 2].y;
+                v1.x = t[4 * i + 1].x + t[4 * i + 2].x; v1.y = t[4 * i + 1].y + t[4 * i + 2].y;
+                v2.x = t[4 * i + 2].x - t[4 * i + 1].x; v2.y = t[4 * i + 2].y - t[4 * i + 1].y;
+                v3.x = t[4 * i + 1].x - t[4 * i + 3].x; v3.y = t[4 * i + 1].y - t[4 * i + 3].y;
+                *reinterpret_cast<float2*>(vp + (4 * i + 0) * (WT * WK)) = v0;
+                *reinterpret_cast<float2*>(vp + (4 * i + 1) * (WT * WK)) = v1;
+                *reinterpret_cast<float2*>(vp + (4 * i + 2) * (WT * WK)) = v2;
+                *reinterpret_cast<float2*>(vp + (4 * i + 3) * (WT * WK)) = v3;
+            }
+            acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[p], 0, 0, 0);
+            acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[p], 0, 0, 0);
+            acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[p], 0, 0, 0);
+            acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[p], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);      // VALU
+                __builtin_amdgcn_sched_group_barrier(0x080, 1, 0);      // LDS read / write
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // global load
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            a = an; b = bn;
+        }
+        advance(u_kd, u_cc, u_left);
+        advance(r_kd, r_cc, r_left);
+        __syncthreads();
+    }
+
+    WINO_STAMP(2, __builtin_amdgcn_s_memrealtime());
+    WINO_STAMP(5, __builtin_amdgcn_s_memtime());
+    WINO_STAMP(6, (unsigned long long)nchunks);
+    if (flags & 0x8000) { if (acc[3][5] == 123.f) out[0] = 1.f; return; }
+    // ---- output transform A^T M A (lane-local) + the epilogue of the direct kernels ---------------------------------------
+    const int col = lane & 31;
+    const int n = nb * WN + wn * 32 + col;
+    const bool nok = n < g.Cout;
+    const float bv = (bias && nok) ? bias[n] : 0.f;
+    const bool orelu = (flags & LISEC_CONV_OUT_RELU) != 0, accum = (flags & LISEC_CONV_ACCUMULATE) != 0;
+    float ys = 1.f, yh = 0.f, ym = 0.f, yi = 0.f;
+    if (g.bwd_y && nok) { ys = g.bwd_bn[n]; yh = g.bwd_bn[g.Cout + n]; ym = g.bwd_bn[2 * g.Cout + n]; yi = g.bwd_bn[3 * g.Cout + n]; }
+    float sum = 0.f, sq = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int gty = by * 8 + wm * 4 + (row >> 3), gtx = bx * 8 + (row & 7);
+        float s[2][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            s[0][j] = acc[0 + j][r] + acc[4 + j][r] + acc[8 + j][r];
+            s[1][j] = acc[4 + j][r] - acc[8 + j][r] - acc[12 + j][r];
+        }
+#pragma unroll
+        for (int a2 = 0; a2 < 2; ++a2) {
+            const float o0 = s[a2][0] + s[a2][1] + s[a2][2];
+            const float o1 = s[a2][1] - s[a2][2] - s[a2][3];
+#pragma unroll
+            for (int b2 = 0; b2 < 2; ++b2) {
+                const int y = 2 * gty + a2, x = 2 * gtx + b2;
+                if (y < H && x < W && nok) {
+                    const size_t orow = ((size_t)dplane * H + y) * W + x;
+                    float* o = out + orow * g.out_stride + n;
+                    float v = (b2 ? o1 : o0) + bv;
+                    if (accum) v += *o;
+                    if (g.out_mask && !(g.out_mask[orow * g.out_stride + n] > 0.f)) v = 0.f;
+                    if (orelu) v = fmaxf(v, 0.f);
+                    *o = v;
+                    if (g.bwd_y) {
+                        const float yv = g.bwd_y[orow * g.Cout + n];
+                        const float dv = (g.bwd_relu && !(fmaf(yv, ys, yh) > 0.f)) ? 0.f : v;
+                        sum += dv; sq = fmaf(dv, (yv - ym) * yi, sq);
+                    } else {
+                        sum += v; sq = fmaf(v, v, sq);
+                    }
+                }
+            }
+        }
+    }
+    WINO_STAMP(3, __builtin_amdgcn_s_memrealtime());
+    if (g.sink.acc) {
+        __syncthreads();                             // (the stages are dead: the scratch below reuses them)
+        float* red = smem;                           // [4 waves][2][32]
+        sum += __shfl_xor(sum, 32, 64); sq += __shfl_xor(sq, 32, 64);
+        if (lane < 32) { red[(wave * 2 + 0) * 32 + lane] = sum; red[(wave * 2 + 1) * 32 + lane] = sq; }
+        __syncthreads();
+        if (tid < 128) {
+            const int which = (tid >> 5) & 1, hn = tid >> 6, c = tid & 31;
+            const double v = (double)red[((0 * 2 + hn) * 2 + which) * 32 + c] + (double)red[((1 * 2 + hn) * 2 + which) * 32 + c];
+            const int ch = nb * WN + hn * 32 + c;
+            if (ch < g.Cout) sink_add(g.sink, which, ch, v);
+        }
+        sink_finish(g.sink);
+    }
+}
+
+// U image of one (depth tap, 8-channel chunk, 64-column block): [pt][n][8 k] with the kernel's swizzle; element (tap, k, n) of
+// the source is read at src[tap * tap_stride + k * k_stride + n * n_stride], tap = (kd * 3 + kh) * 3 + kw.  flip: the (kh, kw)
+// taps are mirrored (the data gradient of a stride-1 pad-1 correlation is the correlation with the mirrored kernel).
+__global__ void k_wino_pack(const float* __restrict__ src, int KD, int K, int N, long long tap_stride, long long k_stride,
+                            long long n_stride, int flip, int ncc, int nnb, float* __restrict__ dst) {
+    const long long total = (long long)KD * ncc * 8 * nnb * 64;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int nn = (int)(i % 64);
+        long long t = i / 64;
+        const int kk = (int)(t % 8); t /= 8;
+        const int b = (int)(t % nnb); t /= nnb;
+        const int cc = (int)(t % ncc);
+        const int kd = (int)(t / ncc);
+        const int k = cc * 8 + kk, n = b * 64 + nn;
+        float gk[3][3];
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int sh = flip ? 2 - kh : kh, sw = flip ? 2 - kw : kw;
+                gk[kh][kw] = (k < K && n < N) ? src[((kd * 3 + sh) * 3 + sw) * tap_stride + k * k_stride + n * n_stride] : 0.f;
+            }
+        float tmp[4][3];
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            tmp[0][kw] = gk[0][kw];
+            tmp[1][kw] = 0.5f * (gk[0][kw] + gk[1][kw] + gk[2][kw]);
+            tmp[2][kw] = 0.5f * (gk[0][kw] - gk[1][kw] + gk[2][kw]);
+            tmp[3][kw] = gk[2][kw];
+        }
+        float* d = dst + ((size_t)(kd * ncc + cc) * nnb + b) * (16 * WN * WK) + wino_swz(nn, kk);
+#pragma unroll
+        for (int i4 = 0; i4 < 4; ++i4) {
+            d[(4 * i4 + 0) * (WN * WK)] = tmp[i4][0];
+            d[(4 * i4 + 1) * (WN * WK)] = 0.5f * (tmp[i4][0] + tmp[i4][1] + tmp[i4][2]);
+            d[(4 * i4 + 2) * (WN * WK)] = 0.5f * (tmp[i4][0] - tmp[i4][1] + tmp[i4][2]);
+            d[(4 * i4 + 3) * (WN * WK)] = tmp[i4][2];
+        }
+    }
+}
+
+// geometry + extras the Winograd kernel serves; msg: why not (for lisec_last_error)
+bool wino_ok(const lisec_conv_geom* c, const ConvGeom& g, bool has_in_bn, int flags, const lisec_conv_extras* ex,
+             const char** msg) {
+#define LISEC_WINO_NEED(cond, text) do { if (!(cond)) { *msg = text; return false; } } while (0)
+    LISEC_WINO_NEED(c->KH == 3 && c->KW == 3 && c->sh == 1 && c->sw == 1 && c->ph == 1 && c->pw == 1, "3x3 (h, w) taps, stride 1, pad 1");
+    LISEC_WINO_NEED(c->Hi == c->Ho && c->Wi == c->Wo && c->Ho >= 2 && c->Wo >= 2, "equal input and output maps of at least 2 x 2");
+    LISEC_WINO_NEED(!c->ps, "no pixel-shuffle store");
+    LISEC_WINO_NEED(c->Cin % 8 == 0 && c->in_stride % 2 == 0, "Cin % 8 == 0 and an even in_stride");
+    LISEC_WINO_NEED(has_in_bn || !(flags & LISEC_CONV_IN_RELU), "LISEC_CONV_IN_RELU needs in_bnstate");
+    LISEC_WINO_NEED(!(flags & LISEC_CONV_TAG_ROOFLINE), "no roofline tag");
+    if (ex) {
+        LISEC_WINO_NEED(!ex->tail_w && !ex->in_y && !ex->queue, "no tail contraction, no backward on load, no row queue");
+        LISEC_WINO_NEED(!ex->bwd_y || (ex->bwd_bnstate && ex->sink && ex->sink->kind == LISEC_SINK_BACKWARD),
+                        "backward statistics go through a backward sink");
+        LISEC_WINO_NEED(!ex->sink || ex->sink->kind == LISEC_SINK_BACKWARD || !ex->bwd_y, "a forward sink excludes bwd_y");
+    }
+#undef LISEC_WINO_NEED
+    (void)g;
+    return true;
+}
+
+}  // namespace
+}  // namespace lisec
+
+using namespace lisec;
+
+extern "C" size_t lisec_conv_winograd_packed_floats(int KD, int K, int N) {
+    if (KD <= 0 || K <= 0 || N <= 0) return 0;
+    return (size_t)KD * (align_up(K, 8) / 8) * (align_up(N, 64) / 64) * (16 * WN * WK);
+}
+
+extern "C" int lisec_conv_pack_weights_winograd(const float* src, int KD, int K, int N, long long tap_stride,
+                                                long long k_stride, long long n_stride, int flip_hw, float* dst,
+                                                lisec_stream_t stream_) {
+    LISEC_CHECK_ARG(src && dst && KD > 0 && KD <= 4 && K > 0 && N > 0, "bad Winograd pack arguments");
+    LISEC_CHECK_ARG(((uintptr_t)dst & 15) == 0, "dst must be 16-byte aligned");
+    const int ncc = (int)(align_up(K, 8) / 8), nnb = (int)(align_up(N, 64) / 64);
+    const long long total = (long long)KD * ncc * 8 * nnb * 64;
+    int gb = cdiv(total, 256);
+    if (gb > 8192) gb = 8192;
+    LISEC_LAUNCH(k_wino_pack, dim3(gb), dim3(256), 0, static_cast<hipStream_t>(stream_), src, KD, K, N, tap_stride, k_stride,
+                 n_stride, flip_hw ? 1 : 0, ncc, nnb, dst);
+    LISEC_LAUNCH_CHECK();
+    return LISEC_OK;
+}
+
+extern "C" int lisec_conv_winograd_supported(const lisec_conv_geom* c, int has_in_bnstate, int flags,
+                                             const lisec_conv_extras* extras) {
+    ConvGeom g;
+    if (conv_geom_check(c, &g)) return 0;
+    const char* msg = "";
+    return wino_ok(c, g, has_in_bnstate != 0, flags, extras, &msg) ? 1 : 0;
+}
+
+extern "C" int lisec_conv_forward_winograd(const lisec_conv_geom* c, const float* in, const float* wino_w, const float* bias,
+                                           const float* in_bnstate, int flags, float* out, const lisec_conv_extras* extras,
+                                           lisec_stream_t stream_) {
+    ConvGeom g;
+    if (int rc = conv_geom_check(c, &g)) return rc;
+    const char* msg = "";
+    LISEC_CHECK_ARG(wino_ok(c, g, in_bnstate != nullptr, flags, extras, &msg), "Winograd form needs: %s", msg);
+    LISEC_CHECK_ARG(in && wino_w && out, "NULL tensor pointer");
+    LISEC_CHECK_ARG(((uintptr_t)in & 7) == 0 && ((uintptr_t)wino_w & 15) == 0 && (!in_bnstate || ((uintptr_t)in_bnstate & 7) == 0),
+                    "in: 8-byte aligned; Winograd kernel: 16-byte aligned");
+    const int TH = (g.Ho + 1) / 2, TW = (g.Wo + 1) / 2;
+    const int BH = cdiv(TH, 8), BW = cdiv(TW, 8);
+    const int nnb = (int)(align_up(g.Cout, WN) / WN);
+    if (extras) {
+        g.out_mask = extras->out_mask;
+        if (extras->bwd_y) { g.bwd_y = extras->bwd_y; g.bwd_bn = extras->bwd_bnstate; g.bwd_relu = extras->bwd_relu ? 1 : 0; }
+        if (const lisec_bn_sink* sk = extras->sink) {
+            LISEC_CHECK_ARG(sk->acc && sk->n_rows > 0, "bn sink: accumulators and a row count");
+            LISEC_CHECK_ARG((sk->kind == LISEC_SINK_FORWARD && !extras->bwd_y && sk->gamma && sk->beta && sk->bnstate &&
+                             (sk->moving_mean == nullptr) == (sk->moving_var == nullptr)) ||
+                            (sk->kind == LISEC_SINK_BACKWARD && extras->bwd_y && sk->dgamma && sk->dbeta && sk->coef),
+                            "bn sink: kind 1 needs gamma/beta/bnstate and no bwd_y, kind 2 needs bwd_y and dgamma/dbeta/coef");
+            g.sink.acc = static_cast<long long*>(sk->acc);
+            g.sink.kind = sk->kind; g.sink.C = g.Cout; g.sink.unbiased = sk->unbiased_moving;
+            g.sink.total = (unsigned)(g.Do * BH * BW) * (unsigned)nnb;
+            g.sink.N = sk->n_rows;
+            g.sink.gamma = sk->gamma; g.sink.beta = sk->beta; g.sink.mmean = sk->moving_mean; g.sink.mvar = sk->moving_var;
+            g.sink.bnstate = sk->bnstate; g.sink.dgamma = sk->dgamma; g.sink.dbeta = sk->dbeta; g.sink.coef = sk->coef;
+        }
+    }
+    dim3 grid(g.Do * BH * BW, nnb, 1);
+    hipStream_t st = static_cast<hipStream_t>(stream_);
+    if (in_bnstate)
+        LISEC_LAUNCH((k_wino<true>), grid, dim3(kWinoThreads), kWinoLds, st, g, c->mode, in, wino_w, bias, in_bnstate, flags, out, BH, BW);
+    else
+        LISEC_LAUNCH((k_wino<false>), grid, dim3(kWinoThreads), kWinoLds, st, g, c->mode, in, wino_w, bias, in_bnstate, flags, out, BH, BW);
+    LISEC_LAUNCH_CHECK();
+    return LISEC_OK;
+}
+
+// Diagnostic: points k_wino's stamp buffer at `buf` (device, 8192*8 uint64) or NULL.
+extern "C" int lisec_debug_wino_stamps(unsigned long long* buf) {
+    LISEC_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_wino_stamps), &buf, sizeof(buf)));
+    return LISEC_OK;
+}

@@ -168,6 +168,42 @@ def conv_forward(g, x, wp, out, bias=None, in_bn=None, flags=0, stats=None, spli
     return out
 
 
+def winograd_packed_floats(KD, K, N):
+    return _lib.load().lisec_conv_winograd_packed_floats(KD, K, N)
+
+
+def pack_weights_winograd(src, KD, K, N, tap_stride, k_stride, n_stride, flip=False, out=None):
+    """G g G^T of a (KD, 3, 3, ...) kernel in the Winograd kernel's LDS image order (lisec_conv_pack_weights_winograd);
+    flip mirrors the (kh, kw) taps: the kernel a data gradient (mode 1) takes."""
+    n = winograd_packed_floats(KD, K, N)
+    if out is None:
+        out = torch.empty(n, dtype=torch.float32, device=src.device)
+    assert out.numel() >= n
+    _lib.check(_lib.load().lisec_conv_pack_weights_winograd(_lib.ptr(src), KD, K, N, tap_stride, k_stride, n_stride,
+                                                            1 if flip else 0, _lib.ptr(out), _lib.current_stream()))
+    return out
+
+
+def _wino_extras(out_mask, bwd, sink):
+    return _lib.ConvExtras(_lib.ptr(out_mask), _lib.ptr(bwd[0]) if bwd is not None else None,
+                           _lib.ptr(bwd[1]) if bwd is not None else None, 1 if (bwd is not None and bwd[2]) else 0,
+                           sink.ref if sink is not None else None, None, None, None, None, None, None, 0)
+
+
+def winograd_supported(g, in_bn=False, flags=0, out_mask=None, bwd=None, sink=None):
+    ex = _wino_extras(out_mask, bwd, sink)
+    return bool(_lib.load().lisec_conv_winograd_supported(ctypes.byref(g), 1 if in_bn else 0, flags, ctypes.byref(ex)))
+
+
+def conv_forward_winograd(g, x, wu, out, bias=None, in_bn=None, flags=0, out_mask=None, bwd=None, sink=None):
+    """conv_forward(...) in the Winograd F(2x2, 3x3) form (lisec_conv_forward_winograd); wu from pack_weights_winograd."""
+    ex = _wino_extras(out_mask, bwd, sink)
+    _lib.check(_lib.load().lisec_conv_forward_winograd(ctypes.byref(g), _lib.ptr(x), _lib.ptr(wu), _lib.ptr(bias),
+                                                       _lib.ptr(in_bn), flags, _lib.ptr(out), ctypes.byref(ex),
+                                                       _lib.current_stream()))
+    return out
+
+
 def conv_plan(g, in_bn=False, flags=0, stats=False, splitk=True, rows_capacity=0, out_mask=None, bwd=None, sink=None,
               queue=None, tail=None, fold=None):
     """The launch plan conv_forward(...) with the same arguments runs (lisec_conv_plan_query), as a dict."""
