@@ -24,6 +24,8 @@
 // Two LDS stages (128 KB): the image of chunk c + 1 is built while the MFMAs of chunk c read the other one; one barrier
 // per chunk.  Rows of V / U are 32 bytes; the 16-byte half a lane reads is swizzled by bit 3 of the row so that every
 // 16-lane group of a ds_read_b128 covers all 64 banks.
+#include <type_traits>
+
 #include "conv.h"
 
 namespace lisec {
@@ -38,7 +40,10 @@ constexpr int WK = 8;                       // input channels per K chunk
 constexpr int V_FLOATS = 16 * WT * WK;      // 8192
 constexpr int U_FLOATS = 16 * WN * WK;      // 8192
 constexpr int STAGE_FLOATS = V_FLOATS + U_FLOATS;
-constexpr size_t kWinoLds = 2 * STAGE_FLOATS * sizeof(float);      // 131072
+constexpr int R_POS = 18 * 18;                // positions of the raw window under 8 x 8 tiles
+constexpr int R_STRIDE = 20;                  // floats per position in LDS: 16 channels + 4 pad
+constexpr int R_ITEMS = 6;                    // 16-byte pieces per thread: 324 x 4 = 1296 <= 6 x 256
+constexpr size_t kWinoLds = (2 * STAGE_FLOATS + R_POS * R_STRIDE) * sizeof(float);      // 156 992
 
 // float index of element k (0..7) of row `row` (0..63) inside one point's [64][8] plane
 __host__ __device__ __forceinline__ int wino_swz(int row, int k) {
@@ -53,7 +58,9 @@ __device__ unsigned long long* g_wino_stamps = nullptr;
         if (stamps && threadIdx.x == 0 && stamp_wg < 8192) stamps[(size_t)stamp_wg * 8 + (K_)] = (V_); \
     } while (0)
 
-template <bool XF>
+// EXP: timing-only variants (wrong results; tools/wino_stamps.py): 1 = no side work in the K loop, 2 = no global loads in it,
+// 3 = no LDS stores in it
+template <bool XF, int EXP = 0>
 __global__ void __launch_bounds__(kWinoThreads) __attribute__((amdgpu_waves_per_eu(1, 1)))
 k_wino(ConvGeom g, int mode, const float* __restrict__ in, const float* __restrict__ U,
        const float* __restrict__ bias, const float* __restrict__ in_bn, int flags, float* __restrict__ out,
@@ -84,102 +91,90 @@ k_wino(ConvGeom g, int mode, const float* __restrict__ in, const float* __restri
     }
     const int ncc = g.Cin / WK;
     const int nchunks = (flags & 0x4000) ? 0 : npairs * ncc;
-    // ---- the (tile, channel pair) this thread stages ---------------------------------------------------------------
+    // ---- the (tile, channel pair) this thread transforms -------------------------------------------------------------
     const int tl = tid >> 2, cp = tid & 3;
-    const int y0 = 2 * (by * 8 + (tl >> 3)) - 1, x0 = 2 * (bx * 8 + (tl & 7)) - 1;
+    const int ty = tl >> 3, tx = tl & 7;
+    const int y0 = 2 * (by * 8 + ty) - 1, x0 = 2 * (bx * 8 + tx) - 1;
     unsigned pmask = 0;                              // bit 4 i + j: patch position (i, j) lies inside the map
-    int poff[16];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const bool ok = (unsigned)(y0 + i) < (unsigned)H && (unsigned)(x0 + j) < (unsigned)W;
-            pmask |= ok ? (1u << (4 * i + j)) : 0u;
-            poff[4 * i + j] = (ok && !(flags & 0x1000)) ? ((y0 + i) * W + (x0 + j)) * g.in_stride + cp * 2 : 0;
-        }
+        for (int j = 0; j < 4; ++j)
+            pmask |= ((unsigned)(y0 + i) < (unsigned)H && (unsigned)(x0 + j) < (unsigned)W) ? (1u << (4 * i + j)) : 0u;
     const int vdst = tl * 8 + (((cp >> 1) ^ ((tl >> 3) & 1)) << 2) + (cp & 1) * 2;      // + pt * 512
+    // ---- the raw window: the 18 x 18 positions under the block's 8 x 8 tiles, 16 channels of one depth plane at a time ----
+    // Every position is fetched ONCE, as 64 contiguous bytes (four lanes x 16 B), and parked in LDS ([position][16 + 4 pad]
+    // floats: the 8-byte patch reads of 8 tiles x 4 channel pairs then cover all 64 banks); the transform reads its 4 x 4
+    // patches from there.  (First version: every thread loaded its own patch from global memory, 8 bytes per position -- 16
+    // cache lines per wave instruction, every position fetched by up to four tiles: the loop was bound by the address unit,
+    // ~1500 of 6200 cycles per chunk.)
+    float* sR = smem + 2 * STAGE_FLOATS;
+    int rg_off[R_ITEMS], rl_off[R_ITEMS];
+#pragma unroll
+    for (int r = 0; r < R_ITEMS; ++r) {
+        int item = tid + 256 * r;
+        item = item < R_POS * 4 ? item : R_POS * 4 - 1;          // (the surplus threads repeat the last item: same bytes)
+        const int pos = item >> 2, quad = item & 3;
+        const int py = pos / 18, px = pos - py * 18;
+        int y = 16 * by - 1 + py, x = 16 * bx - 1 + px;
+        y = y < 0 ? 0 : (y > H - 1 ? H - 1 : y);                 // positions outside the map read a valid address: the
+        x = x < 0 ? 0 : (x > W - 1 ? W - 1 : x);                 // transform gates them to zero (pmask)
+        rg_off[r] = (flags & 0x1000) ? 0 : (y * W + x) * g.in_stride + quad * 4;
+        rl_off[r] = pos * R_STRIDE + quad * 4;
+    }
+    const int rsrc = ((2 * ty) * 18 + 2 * tx) * R_STRIDE + cp * 2;      // patch (0, 0) of this thread's tile in the window
     const size_t plane_floats = (size_t)H * W * g.in_stride;
     const int u_chunk = (flags & 0x2000) ? 0 : 16 * WN * WK;   // floats of one (depth tap, channel chunk, column block) image
     const int nnb = gridDim.y;
     const float relu_lo = (flags & LISEC_CONV_IN_RELU) ? 0.f : -INFINITY;
 
-    float2 raw[16];
-    float2 tsc = make_float2(1.f, 1.f), tsh = make_float2(0.f, 0.f);
-    // two walks over the chunk list (depth tap, channel chunk): the patch loads run two chunks ahead of the MFMAs, the U image
-    // one; past the last chunk a walk stays there (the loop body is branch-free so that the compiler can interleave it with
-    // the MFMAs: the surplus image is never read)
-    int r_kd = __builtin_ctz(dmask | 16), r_cc = 0, r_left = nchunks - 1;
-    int u_kd = r_kd, u_cc = 0, u_left = nchunks - 1;
-    auto advance = [&](int& kd, int& cc, int& left) {          // (selects, no branch: the loop body stays one basic block)
+    // Walks over the chunk list (depth tap, channel chunk), each a fixed distance ahead of the MFMAs; past the last chunk a
+    // walk stays there (the loop body is branch-free so that it can be interleaved with the MFMAs: the surplus images are
+    // never read).  u_: the U image (two chunks ahead), x_: the on-load constants (two ahead), w_: the raw window (by
+    // 16-channel groups = two chunks).
+    const int kd0 = __builtin_ctz(dmask | 16);
+    int u_kd = kd0, u_cc = 0, u_left = nchunks - 1;
+    int x_kd = kd0, x_cc = 0, x_left = nchunks - 1;
+    int w_kd = kd0, w_cc = 0, w_left = nchunks / 2 - 1;
+    auto advance = [&](int& kd, int& cc, int& left, int step) {          // (selects, no branch)
         const bool more = left > 0;
-        const bool wrap = cc + 1 == ncc;
+        const bool wrap = cc + step == ncc;
         const int kd_next = __builtin_ctz((dmask >> (kd + 1)) | 16) + kd + 1;
         left -= more ? 1 : 0;
         kd = (more && wrap) ? kd_next : kd;
-        cc = more ? (wrap ? 0 : cc + 1) : cc;
+        cc = more ? (wrap ? 0 : cc + step) : cc;
     };
-    auto issue_raw = [&]() {
+    float4 rw0, rw1, rw2, rw3, rw4, rw5;             // the window's next 16 channels on their way to LDS
+    float4 ub0, ub1, ub2, ub3, ub4, ub5, ub6, ub7;   // the next U image on its way to LDS (named: an array stayed in scratch)
+    float2 tsc = make_float2(1.f, 1.f), tsh = make_float2(0.f, 0.f);
+    auto window_src = [&]() -> const float* {
         bool dok = true;
-        const int sd = src_coord(dplane, r_kd, g.ls_d, g.pd, g.Di, mode, dok);
-        const float* src = in + (size_t)sd * plane_floats + r_cc * WK;
-#pragma unroll
-        for (int p = 0; p < 16; ++p) raw[p] = *reinterpret_cast<const float2*>(src + poff[p]);
-        if (XF) {
-            tsc = *reinterpret_cast<const float2*>(in_bn + r_cc * WK + cp * 2);
-            tsh = *reinterpret_cast<const float2*>(in_bn + g.Cin + r_cc * WK + cp * 2);
-        }
-        advance(r_kd, r_cc, r_left);
+        const int sd = src_coord(dplane, w_kd, g.ls_d, g.pd, g.Di, mode, dok);
+        return in + (size_t)sd * plane_floats + w_cc * WK;
     };
-    // U image of one chunk: a linear 32 KB copy through registers (an LDS-DMA piece costs the issuing wave 100-185 cycles
-    // beside MFMAs and LDS reads -- eight of them per chunk were a quarter of the loop -- and makes every barrier wait for
-    // vmcnt(0); a global_load_dwordx4 + ds_write_b128 pair costs ~25 and plain loads stay in flight across the barrier)
-    float4 ub[8];
+#define WINO_R_LD(R_, I_) R_ = *reinterpret_cast<const float4*>(wsrc + rg_off[I_])
+#define WINO_R_ST(R_, I_) *reinterpret_cast<float4*>(sR + rl_off[I_]) = R_
     auto issue_u = [&]() {
         const float* us = U + ((size_t)(u_kd * ncc + u_cc) * nnb + nb) * u_chunk + tid * 4;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) ub[q] = *reinterpret_cast<const float4*>(us + q * 1024);
-        advance(u_kd, u_cc, u_left);
+        ub0 = *reinterpret_cast<const float4*>(us + 0 * 1024); ub1 = *reinterpret_cast<const float4*>(us + 1 * 1024);
+        ub2 = *reinterpret_cast<const float4*>(us + 2 * 1024); ub3 = *reinterpret_cast<const float4*>(us + 3 * 1024);
+        ub4 = *reinterpret_cast<const float4*>(us + 4 * 1024); ub5 = *reinterpret_cast<const float4*>(us + 5 * 1024);
+        ub6 = *reinterpret_cast<const float4*>(us + 6 * 1024); ub7 = *reinterpret_cast<const float4*>(us + 7 * 1024);
+        advance(u_kd, u_cc, u_left, 1);
     };
     auto store_u = [&](float* stage) {
         float* up = stage + V_FLOATS + tid * 4;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) *reinterpret_cast<float4*>(up + q * 1024) = ub[q];
+        *reinterpret_cast<float4*>(up + 0 * 1024) = ub0; *reinterpret_cast<float4*>(up + 1 * 1024) = ub1;
+        *reinterpret_cast<float4*>(up + 2 * 1024) = ub2; *reinterpret_cast<float4*>(up + 3 * 1024) = ub3;
+        *reinterpret_cast<float4*>(up + 4 * 1024) = ub4; *reinterpret_cast<float4*>(up + 5 * 1024) = ub5;
+        *reinterpret_cast<float4*>(up + 6 * 1024) = ub6; *reinterpret_cast<float4*>(up + 7 * 1024) = ub7;
     };
-    auto store_v = [&](float* stage) {
-        // B^T d B on both channels of the pair; padding (and tiles beyond the map) contribute exact zeros
-        float2 d[16];
-#pragma unroll
-        for (int p = 0; p < 16; ++p) {
-            const bool ok = (pmask >> p) & 1;
-            float2 v = raw[p];
-            if (XF) {
-                v.x = fmaxf(fmaf(v.x, tsc.x, tsh.x), relu_lo);
-                v.y = fmaxf(fmaf(v.y, tsc.y, tsh.y), relu_lo);
-            }
-            d[p].x = ok ? v.x : 0.f;
-            d[p].y = ok ? v.y : 0.f;
+    auto issue_x = [&]() {
+        if (XF) {
+            tsc = *reinterpret_cast<const float2*>(in_bn + x_cc * WK + cp * 2);
+            tsh = *reinterpret_cast<const float2*>(in_bn + g.Cin + x_cc * WK + cp * 2);
         }
-        float2 t[16];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            t[0 + j].x = d[0 + j].x - d[8 + j].x;   t[0 + j].y = d[0 + j].y - d[8 + j].y;
-            t[4 + j].x = d[4 + j].x + d[8 + j].x;   t[4 + j].y = d[4 + j].y + d[8 + j].y;
-            t[8 + j].x = d[8 + j].x - d[4 + j].x;   t[8 + j].y = d[8 + j].y - d[4 + j].y;
-            t[12 + j].x = d[4 + j].x - d[12 + j].x; t[12 + j].y = d[4 + j].y - d[12 + j].y;
-        }
-        float* vp = stage + vdst;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float2 v0, v1, v2, v3;
-            v0.x = t[4 * i + 0].x - t[4 * i + 2].x; v0.y = t[4 * i + 0].y - t[4 * i + 2].y;
-            v1.x = t[4 * i + 1].x + t[4 * i + 2].x; v1.y = t[4 * i + 1].y + t[4 * i + 2].y;
-            v2.x = t[4 * i + 2].x - t[4 * i + 1].x; v2.y = t[4 * i + 2].y - t[4 * i + 1].y;
-            v3.x = t[4 * i + 1].x - t[4 * i + 3].x; v3.y = t[4 * i + 1].y - t[4 * i + 3].y;
-            *reinterpret_cast<float2*>(vp + (4 * i + 0) * (WT * WK)) = v0;
-            *reinterpret_cast<float2*>(vp + (4 * i + 1) * (WT * WK)) = v1;
-            *reinterpret_cast<float2*>(vp + (4 * i + 2) * (WT * WK)) = v2;
-            *reinterpret_cast<float2*>(vp + (4 * i + 3) * (WT * WK)) = v3;
-        }
+        advance(x_kd, x_cc, x_left, 1);
     };
 
     f32x16 acc[16];
@@ -190,127 +185,191 @@ k_wino(ConvGeom g, int mode, const float* __restrict__ in, const float* __restri
     const int aoff = arow * 8 + (((lane >> 5) ^ ((arow >> 3) & 1)) << 2);
     const int boff = V_FLOATS + brow * 8 + (((lane >> 5) ^ ((brow >> 3) & 1)) << 2);
 
+    float2 d[16], t[16];
+    // gate (+ BatchNormalization, ReLU) of patch row i of the window's channel half `half`: d[4 i .. 4 i + 3]
+    auto gate_row = [&](int i, int half, const float2& sc, const float2& sh) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int e = 4 * i + j;
+            const bool ok = (pmask >> e) & 1;
+            float2 v = *reinterpret_cast<const float2*>(sR + rsrc + (i * 18 + j) * R_STRIDE + half * WK);
+            if (XF) {
+                v.x = fmaxf(fmaf(v.x, sc.x, sh.x), relu_lo);
+                v.y = fmaxf(fmaf(v.y, sc.y, sh.y), relu_lo);
+            }
+            d[e].x = ok ? v.x : 0.f;
+            d[e].y = ok ? v.y : 0.f;
+        }
+    };
+    auto bt_col = [&](int j) {                       // B^T d, column j
+        t[0 + j].x = d[0 + j].x - d[8 + j].x;   t[0 + j].y = d[0 + j].y - d[8 + j].y;
+        t[4 + j].x = d[4 + j].x + d[8 + j].x;   t[4 + j].y = d[4 + j].y + d[8 + j].y;
+        t[8 + j].x = d[8 + j].x - d[4 + j].x;   t[8 + j].y = d[8 + j].y - d[4 + j].y;
+        t[12 + j].x = d[4 + j].x - d[12 + j].x; t[12 + j].y = d[4 + j].y - d[12 + j].y;
+    };
+    auto b_row = [&](int i, float* vp, bool store) { // (B^T d) B, row i, and its four 8-byte stores
+        float2 v0, v1, v2, v3;
+        v0.x = t[4 * i + 0].x - t[4 * i + 2].x; v0.y = t[4 * i + 0].y - t[4 * i + 2].y;
+        v1.x = t[4 * i + 1].x + t[4 * i + 2].x; v1.y = t[4 * i + 1].y + t[4 * i + 2].y;
+        v2.x = t[4 * i + 2].x - t[4 * i + 1].x; v2.y = t[4 * i + 2].y - t[4 * i + 1].y;
+        v3.x = t[4 * i + 1].x - t[4 * i + 3].x; v3.y = t[4 * i + 1].y - t[4 * i + 3].y;
+        if (store) {
+            *reinterpret_cast<float2*>(vp + (4 * i + 0) * (WT * WK)) = v0;
+            *reinterpret_cast<float2*>(vp + (4 * i + 1) * (WT * WK)) = v1;
+            *reinterpret_cast<float2*>(vp + (4 * i + 2) * (WT * WK)) = v2;
+            *reinterpret_cast<float2*>(vp + (4 * i + 3) * (WT * WK)) = v3;
+        } else {                                     // (timing variant: keeps the transform alive without the stores)
+            asm volatile("" :: "v"(v0.x), "v"(v0.y), "v"(v1.x), "v"(v1.y), "v"(v2.x), "v"(v2.y), "v"(v3.x), "v"(v3.y));
+        }
+    };
+
     if (nchunks > 0) {
-        issue_raw();
+        // window of group 0 -> LDS; the registers then take group 1's; image of chunk 0 -> stage 0; U / constants of chunk 1
+        {
+            const float* wsrc = window_src();
+            WINO_R_LD(rw0, 0); WINO_R_LD(rw1, 1); WINO_R_LD(rw2, 2); WINO_R_LD(rw3, 3); WINO_R_LD(rw4, 4); WINO_R_LD(rw5, 5);
+            advance(w_kd, w_cc, w_left, 2);
+        }
         issue_u();
-        store_v(smem);
+        issue_x();
+        WINO_R_ST(rw0, 0); WINO_R_ST(rw1, 1); WINO_R_ST(rw2, 2); WINO_R_ST(rw3, 3); WINO_R_ST(rw4, 4); WINO_R_ST(rw5, 5);
+        __syncthreads();
+        {
+            const float* wsrc = window_src();
+            WINO_R_LD(rw0, 0); WINO_R_LD(rw1, 1); WINO_R_LD(rw2, 2); WINO_R_LD(rw3, 3); WINO_R_LD(rw4, 4); WINO_R_LD(rw5, 5);
+            advance(w_kd, w_cc, w_left, 2);
+        }
+        const float2 sc = tsc, sh = tsh;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) gate_row(i, 0, sc, sh);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bt_col(j);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) b_row(i, smem + vdst, true);
         store_u(smem);
-        issue_raw();
         issue_u();
+        issue_x();
     }
     __syncthreads();
     WINO_STAMP(1, __builtin_amdgcn_s_memrealtime());
     WINO_STAMP(4, __builtin_amdgcn_s_memtime());
     // One wave per SIMD: whatever is not an MFMA has to issue in the shadow of one (64 cycles each, ~13 issue slots), and the
-    // compiler left alone puts the whole transform in front of the MFMAs and the loads behind them, next to the barrier that
-    // waits for them.  The chunk is therefore cut by hand into 16 groups (one per transform point: two fragment reads, four
-    // MFMAs) and every group carries one slice of the side work, pinned by sched_barrier:
-    //   groups 0-3   gate (+ BatchNormalization, ReLU) of patch row i of chunk c + 1; two 16-byte stores of its U image
-    //   groups 4-7   B^T d (column j) -- and the patch loads of chunk c + 2, four per group, into the registers just freed
-    //   groups 8-11  (B^T d) B (row i) and its four 8-byte stores into the other stage
-    //   groups 12-15 the U image of chunk c + 2, two loads per group (in flight across the barrier)
-    float2 d[16], t[16];
-    for (int c = 0; c < nchunks; ++c) {
-        const float* st = smem + (c & 1) * STAGE_FLOATS;
-        float* nx = smem + ((c + 1) & 1) * STAGE_FLOATS;
+    // compiler left alone puts the whole transform in front of the MFMAs and the loads behind them.  A chunk is therefore cut
+    // by hand into 8 groups of two transform points (four fragment reads, eight MFMAs alternating between two accumulators)
+    // and every group carries two slices p of the side work for chunk c + 1, pinned by sched_barrier:
+    //   p 0-3    patch row i: four 8-byte reads from the window, gate (+ BatchNormalization, ReLU); two 16-byte stores of the
+    //            U image of chunk c + 1
+    //   p 4-7    B^T d (column j); ODD chunks: two 16-byte loads of the window's next 16 channels (p 4-6)
+    //   p 8-11   (B^T d) B (row i) and its four 8-byte stores into the other stage; two loads of the U image of chunk c + 2
+    //   p 12-14  EVEN chunks: the window's next 16 channels -> LDS (two 16-byte stores each).  The window is single: an even
+    //            chunk reads its second half (p 0-3), ALL waves meet at a barrier after group 2, and only then is it
+    //            overwritten; the odd chunk that follows reads the new window after the barrier that ends the even one.
+    // (the compiler waits for vmcnt(0) at the top of a chunk -- a wait count cannot be carried round the loop edge -- so the
+    // last load of a chunk goes out ~1000 MFMA cycles before its end)
+    auto chunk = [&](auto par_tag) {
+        constexpr int PAR = decltype(par_tag)::value;
+        const float* st = smem + PAR * STAGE_FLOATS;
+        float* nx = smem + (PAR ^ 1) * STAGE_FLOATS;
         const float* ap = st + aoff;
         const float* bp = st + boff;
-        float4 a = *reinterpret_cast<const float4*>(ap);
-        float4 b = *reinterpret_cast<const float4*>(bp);
-        typedef __attribute__((address_space(1))) const void* gptr;
-        typedef __attribute__((address_space(3))) void* lptr;
-        const float* us = U + ((size_t)(u_kd * ncc + u_cc) * nnb + nb) * u_chunk + wave * 256 + lane * 4;
-        float* ud = nx + V_FLOATS + wave * 256;
-        bool dok = true;
-        const int sd = src_coord(dplane, r_kd, g.ls_d, g.pd, g.Di, mode, dok);
-        const float* src = in + (size_t)sd * plane_floats + r_cc * WK;
-        const float2 sc = tsc, sh = tsh;             // (chunk c + 1's; the loads below replace them with chunk c + 2's)
+        float4 a0 = *reinterpret_cast<const float4*>(ap), a1 = *reinterpret_cast<const float4*>(ap + WT * WK);
+        float4 b0 = *reinterpret_cast<const float4*>(bp), b1 = *reinterpret_cast<const float4*>(bp + WN * WK);
+        const float* us = U + ((size_t)(u_kd * ncc + u_cc) * nnb + nb) * u_chunk + tid * 4;
+        float* up = nx + V_FLOATS + tid * 4;
+        const float* wsrc = window_src();
+        const float2 sc = tsc, sh = tsh;             // (chunk c + 1's; issue_x below replaces them with chunk c + 2's)
         float* vp = nx + vdst;
 #pragma unroll
-        for (int p = 0; p < 16; ++p) {
-            float4 an = a, bn = b;
-            if (p + 1 < 16) {
-                an = *reinterpret_cast<const float4*>(ap + (p + 1) * (WT * WK));
-                bn = *reinterpret_cast<const float4*>(bp + (p + 1) * (WN * WK));
+        for (int pp = 0; pp < 8; ++pp) {
+            float4 a0n = a0, a1n = a1, b0n = b0, b1n = b1;
+            if (pp + 1 < 8) {
+                a0n = *reinterpret_cast<const float4*>(ap + (2 * pp + 2) * (WT * WK));
+                b0n = *reinterpret_cast<const float4*>(bp + (2 * pp + 2) * (WN * WK));
+                a1n = *reinterpret_cast<const float4*>(ap + (2 * pp + 3) * (WT * WK));
+                b1n = *reinterpret_cast<const float4*>(bp + (2 * pp + 3) * (WN * WK));
             }
-            if (p < 2) {
+#define WINO_U_ST(A_, B_, Q_) if (EXP != 1 && EXP != 3) { *reinterpret_cast<float4*>(up + (Q_) * 1024) = A_; *reinterpret_cast<float4*>(up + ((Q_) + 1) * 1024) = B_; }
+#define WINO_U_LD(A_, B_, Q_) if (EXP != 1 && EXP != 2) { A_ = *reinterpret_cast<const float4*>(us + (Q_) * 1024); B_ = *reinterpret_cast<const float4*>(us + ((Q_) + 1) * 1024); }
 #pragma unroll
-                for (int q = 4 * p; q < 4 * p + 4; ++q)
-                    __builtin_amdgcn_global_load_lds((gptr)(us + q * 1024), (lptr)(ud + q * 1024), 16, 0, 0);
-            }
-            if (p < 4) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int e = 4 * p + j;
-                    const bool ok = (pmask >> e) & 1;
-                    float2 v = raw[e];
-                    if (XF) {
-                        v.x = fmaxf(fmaf(v.x, sc.x, sh.x), relu_lo);
-                        v.y = fmaxf(fmaf(v.y, sc.y, sh.y), relu_lo);
-                    }
-                    d[e].x = ok ? v.x : 0.f;
-                    d[e].y = ok ? v.y : 0.f;
+            for (int p = 2 * pp; p < 2 * pp + 2; ++p) {
+                if (EXP == 1) continue;
+                if (p == 0) WINO_U_ST(ub0, ub1, 0)
+                if (p == 1) WINO_U_ST(ub2, ub3, 2)
+                if (p == 2) WINO_U_ST(ub4, ub5, 4)
+                if (p == 3) WINO_U_ST(ub6, ub7, 6)
+                if (p == 8) WINO_U_LD(ub0, ub1, 0)
+                if (p == 9) WINO_U_LD(ub2, ub3, 2)
+                if (p == 10) WINO_U_LD(ub4, ub5, 4)
+                if (p == 11) WINO_U_LD(ub6, ub7, 6)
+                if (p < 4) gate_row(p, PAR ^ 1, sc, sh);         // chunk c + 1 is the OTHER half of the window's 16 channels
+                else if (p < 8) bt_col(p - 4);
+                else if (p < 12) b_row(p - 8, vp, EXP != 3);
+                if (PAR == 1 && EXP != 2) {
+                    if (p == 4) { WINO_R_LD(rw0, 0); WINO_R_LD(rw1, 1); }
+                    if (p == 5) { WINO_R_LD(rw2, 2); WINO_R_LD(rw3, 3); }
+                    if (p == 6) { WINO_R_LD(rw4, 4); WINO_R_LD(rw5, 5); }
                 }
-            } else if (p < 8) {
-                const int j = p - 4;
-                t[0 + j].x = d[0 + j].x - d[8 + j].x;   t[0 + j].y = d[0 + j].y - d[8 + j].y;
-                t[4 + j].x = d[4 + j].x + d[8 + j].x;   t[4 + j].y = d[4 + j].y + d[8 + j].y;
-                t[8 + j].x = d[8 + j].x - d[4 + j].x;   t[8 + j].y = d[8 + j].y - d[4 + j].y;
-                t[12 + j].x = d[4 + j].x - d[12 + j].x; t[12 + j].y = d[4 + j].y - d[12 + j].y;
-#pragma unroll
-                for (int e = 4 * j; e < 4 * j + 4; ++e) raw[e] = *reinterpret_cast<const float2*>(src + poff[e]);
-                if (XF && p == 4) {
-                    tsc = *reinterpret_cast<const float2*>(in_bn + r_cc * WK + cp * 2);
-                    tsh = *reinterpret_cast<const float2*>(in_bn + g.Cin + r_cc * WK + cp * 2);
+                if (PAR == 0 && EXP != 3) {
+                    if (p == 12) { WINO_R_ST(rw0, 0); WINO_R_ST(rw1, 1); }
+                    if (p == 13) { WINO_R_ST(rw2, 2); WINO_R_ST(rw3, 3); }
+                    if (p == 14) { WINO_R_ST(rw4, 4); WINO_R_ST(rw5, 5); }
                 }
-            } else if (p < 12) {
-                const int i = p - 8;
-                float2 v0, v1, v2, v3;
-                v0.x = t[4 * i + 0].x - t[4 * i + 2].x; v0.y = t[4 * i + 0].y - t[4 * i + 2].y;
-                v1.x = t[4 * i + 1].x + t[4 * i + 2].x; v1.y = t[4 * i + 1].y + t[4 * i + 2].y;
-                v2.x = t[4 * i + 2].x - t[4 * i + 1].x; v2.y = t[4 * i + 2].y - t[4 * i + 1].y;
-                v3.x = t[4 * i + 1].x - t[4 * i + 3].x; v3.y = t[4 * i + 1].y - t[4 * i + 3].y;
-                *reinterpret_cast<float2*>(vp + (4 * i + 0) * (WT * WK)) = v0;
-                *reinterpret_cast<float2*>(vp + (4 * i + 1) * (WT * WK)) = v1;
-                *reinterpret_cast<float2*>(vp + (4 * i + 2) * (WT * WK)) = v2;
-                *reinterpret_cast<float2*>(vp + (4 * i + 3) * (WT * WK)) = v3;
             }
-            acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[p], 0, 0, 0);
-            acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[p], 0, 0, 0);
-            acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[p], 0, 0, 0);
-            acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[p], 0, 0, 0);
+#undef WINO_U_ST
+#undef WINO_U_LD
+            acc[2 * pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b0.x, acc[2 * pp], 0, 0, 0);
+            acc[2 * pp + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b1.x, acc[2 * pp + 1], 0, 0, 0);
+            acc[2 * pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b0.y, acc[2 * pp], 0, 0, 0);
+            acc[2 * pp + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b1.y, acc[2 * pp + 1], 0, 0, 0);
+            acc[2 * pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b0.z, acc[2 * pp], 0, 0, 0);
+            acc[2 * pp + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b1.z, acc[2 * pp + 1], 0, 0, 0);
+            acc[2 * pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b0.w, acc[2 * pp], 0, 0, 0);
+            acc[2 * pp + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b1.w, acc[2 * pp + 1], 0, 0, 0);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < 8; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // MFMA
                 __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);      // VALU
                 __builtin_amdgcn_sched_group_barrier(0x080, 1, 0);      // LDS read / write
                 __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // global load
             }
             __builtin_amdgcn_sched_barrier(0);
-            a = an; b = bn;
+            if (PAR == 0 && pp == 2 && EXP != 1) __syncthreads();      // every wave has read the window's second half
+            a0 = a0n; a1 = a1n; b0 = b0n; b1 = b1n;
         }
-        advance(u_kd, u_cc, u_left);
-        advance(r_kd, r_cc, r_left);
+        advance(u_kd, u_cc, u_left, 1);
+        if (PAR == 1) advance(w_kd, w_cc, w_left, 2);
+        issue_x();
         __syncthreads();
+    };
+    for (int c = 0; c < nchunks; c += 2) {
+        chunk(std::integral_constant<int, 0>{});
+        chunk(std::integral_constant<int, 1>{});
     }
+#undef WINO_R_LD
+#undef WINO_R_ST
 
     WINO_STAMP(2, __builtin_amdgcn_s_memrealtime());
     WINO_STAMP(5, __builtin_amdgcn_s_memtime());
     WINO_STAMP(6, (unsigned long long)nchunks);
     if (flags & 0x8000) { if (acc[3][5] == 123.f) out[0] = 1.f; return; }
     // ---- output transform A^T M A (lane-local) + the epilogue of the direct kernels ---------------------------------------
-    const int col = lane & 31;
+    // accumulator register r of a lane: tile row (r >> 2) of the wave's four, tile column (r & 3) + 4 (lane >> 5), channel
+    // lane & 31 -- the output line is wave-uniform (scalar row pointers), the position inside it one 32-bit lane offset
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));                 // (keeps the epilogue's per-lane values out of the K loop's registers)
+    const int col = lane_e & 31, hi = lane_e >> 5;
     const int n = nb * WN + wn * 32 + col;
     const bool nok = n < g.Cout;
     const float bv = (bias && nok) ? bias[n] : 0.f;
     const bool orelu = (flags & LISEC_CONV_OUT_RELU) != 0, accum = (flags & LISEC_CONV_ACCUMULATE) != 0;
     float ys = 1.f, yh = 0.f, ym = 0.f, yi = 0.f;
     if (g.bwd_y && nok) { ys = g.bwd_bn[n]; yh = g.bwd_bn[g.Cout + n]; ym = g.bwd_bn[2 * g.Cout + n]; yi = g.bwd_bn[3 * g.Cout + n]; }
+    const int xt = 2 * (bx * 8 + 4 * hi);            // first output column of the lane's tile column 0
+    const unsigned xo = (unsigned)(xt * g.out_stride + n), xy = (unsigned)(xt * g.Cout + n);
     float sum = 0.f, sq = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        const int gty = by * 8 + wm * 4 + (row >> 3), gtx = bx * 8 + (row & 7);
+        const int gty = by * 8 + wm * 4 + (r >> 2);
         float s[2][4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -321,19 +380,23 @@ k_wino(ConvGeom g, int mode, const float* __restrict__ in, const float* __restri
         for (int a2 = 0; a2 < 2; ++a2) {
             const float o0 = s[a2][0] + s[a2][1] + s[a2][2];
             const float o1 = s[a2][1] - s[a2][2] - s[a2][3];
+            const int y = 2 * gty + a2;
+            const size_t line = ((size_t)dplane * H + y) * W;
+            float* oline = out + line * g.out_stride;
+            const float* mline = g.out_mask ? g.out_mask + line * g.out_stride : nullptr;
+            const float* yline = g.bwd_y ? g.bwd_y + line * g.Cout : nullptr;
 #pragma unroll
             for (int b2 = 0; b2 < 2; ++b2) {
-                const int y = 2 * gty + a2, x = 2 * gtx + b2;
-                if (y < H && x < W && nok) {
-                    const size_t orow = ((size_t)dplane * H + y) * W + x;
-                    float* o = out + orow * g.out_stride + n;
+                const int dx = 2 * (r & 3) + b2;
+                if (y < H && xt + dx < W && nok) {
+                    const unsigned off = xo + (unsigned)(dx * g.out_stride);
                     float v = (b2 ? o1 : o0) + bv;
-                    if (accum) v += *o;
-                    if (g.out_mask && !(g.out_mask[orow * g.out_stride + n] > 0.f)) v = 0.f;
+                    if (accum) v += oline[off];
+                    if (mline && !(mline[off] > 0.f)) v = 0.f;
                     if (orelu) v = fmaxf(v, 0.f);
-                    *o = v;
-                    if (g.bwd_y) {
-                        const float yv = g.bwd_y[orow * g.Cout + n];
+                    oline[off] = v;
+                    if (yline) {
+                        const float yv = yline[xy + (unsigned)(dx * g.Cout)];
                         const float dv = (g.bwd_relu && !(fmaf(yv, ys, yh) > 0.f)) ? 0.f : v;
                         sum += dv; sq = fmaf(dv, (yv - ym) * yi, sq);
                     } else {
@@ -408,7 +471,7 @@ bool wino_ok(const lisec_conv_geom* c, const ConvGeom& g, bool has_in_bn, int fl
     LISEC_WINO_NEED(c->KH == 3 && c->KW == 3 && c->sh == 1 && c->sw == 1 && c->ph == 1 && c->pw == 1, "3x3 (h, w) taps, stride 1, pad 1");
     LISEC_WINO_NEED(c->Hi == c->Ho && c->Wi == c->Wo && c->Ho >= 2 && c->Wo >= 2, "equal input and output maps of at least 2 x 2");
     LISEC_WINO_NEED(!c->ps, "no pixel-shuffle store");
-    LISEC_WINO_NEED(c->Cin % 8 == 0 && c->in_stride % 2 == 0, "Cin % 8 == 0 and an even in_stride");
+    LISEC_WINO_NEED(c->Cin % 16 == 0 && c->in_stride % 4 == 0, "Cin % 16 == 0 and in_stride % 4 == 0");
     LISEC_WINO_NEED(has_in_bn || !(flags & LISEC_CONV_IN_RELU), "LISEC_CONV_IN_RELU needs in_bnstate");
     LISEC_WINO_NEED(!(flags & LISEC_CONV_TAG_ROOFLINE), "no roofline tag");
     if (ex) {
@@ -463,8 +526,8 @@ extern "C" int lisec_conv_forward_winograd(const lisec_conv_geom* c, const float
     const char* msg = "";
     LISEC_CHECK_ARG(wino_ok(c, g, in_bnstate != nullptr, flags, extras, &msg), "Winograd form needs: %s", msg);
     LISEC_CHECK_ARG(in && wino_w && out, "NULL tensor pointer");
-    LISEC_CHECK_ARG(((uintptr_t)in & 7) == 0 && ((uintptr_t)wino_w & 15) == 0 && (!in_bnstate || ((uintptr_t)in_bnstate & 7) == 0),
-                    "in: 8-byte aligned; Winograd kernel: 16-byte aligned");
+    LISEC_CHECK_ARG(((uintptr_t)in & 15) == 0 && ((uintptr_t)wino_w & 15) == 0 && (!in_bnstate || ((uintptr_t)in_bnstate & 7) == 0),
+                    "in and the Winograd kernel: 16-byte aligned");
     const int TH = (g.Ho + 1) / 2, TW = (g.Wo + 1) / 2;
     const int BH = cdiv(TH, 8), BW = cdiv(TW, 8);
     const int nnb = (int)(align_up(g.Cout, WN) / WN);
@@ -487,10 +550,15 @@ extern "C" int lisec_conv_forward_winograd(const lisec_conv_geom* c, const float
     }
     dim3 grid(g.Do * BH * BW, nnb, 1);
     hipStream_t st = static_cast<hipStream_t>(stream_);
-    if (in_bnstate)
-        LISEC_LAUNCH((k_wino<true>), grid, dim3(kWinoThreads), kWinoLds, st, g, c->mode, in, wino_w, bias, in_bnstate, flags, out, BH, BW);
-    else
-        LISEC_LAUNCH((k_wino<false>), grid, dim3(kWinoThreads), kWinoLds, st, g, c->mode, in, wino_w, bias, in_bnstate, flags, out, BH, BW);
+#define LISEC_WINO_GO(X_, E_) LISEC_LAUNCH((k_wino<X_, E_>), grid, dim3(kWinoThreads), kWinoLds, st, g, c->mode, in, wino_w, bias, \
+        in_bnstate, flags, out, BH, BW)
+    const int exp = (flags >> 16) & 3;               // timing-only variants (tools/wino_stamps.py), 0 in every real call
+    if (exp == 1) LISEC_WINO_GO(false, 1);
+    else if (exp == 2) LISEC_WINO_GO(false, 2);
+    else if (exp == 3) LISEC_WINO_GO(false, 3);
+    else if (in_bnstate) LISEC_WINO_GO(true, 0);
+    else LISEC_WINO_GO(false, 0);
+#undef LISEC_WINO_GO
     LISEC_LAUNCH_CHECK();
     return LISEC_OK;
 }

@@ -30,16 +30,16 @@ def make_bn(rng, c, dev):
 
 # name, mode, in dims, out dims, KD, depth stride, depth pad, cin, cout, BN+ReLU on load
 SMALL = [
-    ("2d 16x16", 0, (1, 16, 16), (1, 16, 16), 1, 1, 0, 8, 64, False),
+    ("2d 16x16", 0, (1, 16, 16), (1, 16, 16), 1, 1, 0, 16, 64, False),
     ("2d odd map 25x50, 2 column blocks, bn", 0, (1, 25, 50), (1, 25, 50), 1, 1, 0, 16, 128, True),
-    ("2d 18x34 (partial tile blocks), cout 40", 0, (1, 18, 34), (1, 18, 34), 1, 1, 0, 24, 40, True),
+    ("2d 18x34 (partial tile blocks), cout 40", 0, (1, 18, 34), (1, 18, 34), 1, 1, 0, 48, 40, True),
     ("3d valid depth (mid2 shape)", 0, (4, 12, 20), (2, 12, 20), 3, 1, 0, 16, 64, False),
     ("3d depth stride 2 pad 1 (mid3 shape)", 0, (2, 10, 18), (1, 10, 18), 3, 2, 1, 16, 64, False),
-    ("3d depth stride 2 pad 1, 8 planes", 0, (8, 6, 10), (4, 6, 10), 3, 2, 1, 8, 64, True),
+    ("3d depth stride 2 pad 1, 8 planes", 0, (8, 6, 10), (4, 6, 10), 3, 2, 1, 32, 64, True),
     ("transposed 2d", 1, (1, 14, 22), (1, 14, 22), 1, 1, 0, 16, 64, False),
     ("transposed 3d valid depth", 1, (2, 12, 20), (4, 12, 20), 3, 1, 0, 16, 64, False),
     ("transposed 3d depth stride 2 pad 1", 1, (1, 10, 18), (2, 10, 18), 3, 2, 1, 16, 64, False),
-    ("transposed 3d depth stride 2 pad 1, 4 planes", 1, (4, 6, 10), (8, 6, 10), 3, 2, 1, 8, 72, False),
+    ("transposed 3d depth stride 2 pad 1, 4 planes", 1, (4, 6, 10), (8, 6, 10), 3, 2, 1, 16, 72, False),
 ]
 
 
@@ -107,11 +107,11 @@ def test_unsupported_arguments_are_refused():
     dev = torch.device("cuda")
     g = ops.geom(0, (1, 16, 16), (1, 8, 8), (1, 3, 3), (1, 2, 2), (0, 1, 1), 16, 64)          # stride 2
     assert not ops.winograd_supported(g)
-    g = ops.geom(0, (1, 16, 16), (1, 16, 16), (1, 3, 3), (1, 1, 1), (0, 1, 1), 12, 64)        # Cin % 8
+    g = ops.geom(0, (1, 16, 16), (1, 16, 16), (1, 3, 3), (1, 1, 1), (0, 1, 1), 24, 64)        # Cin % 16
     assert not ops.winograd_supported(g)
-    x = torch.zeros(1, 16, 16, 12, device=dev)
+    x = torch.zeros(1, 16, 16, 24, device=dev)
     with pytest.raises(_lib.LisecError):
-        ops.conv_forward_winograd(g, x, torch.zeros(16 * 64 * 8 * 2, device=dev), torch.zeros(1, 16, 16, 64, device=dev))
+        ops.conv_forward_winograd(g, x, torch.zeros(16 * 64 * 8 * 3, device=dev), torch.zeros(1, 16, 16, 64, device=dev))
 
 
 # the layers the training step runs in this form, at the Lyft grid: name, mode, in dims, out dims, KD, sd, pd, cin, cout, kind
