@@ -33,7 +33,7 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int kWinoThreads = 256;
+constexpr int kWinoThreads = 512;
 constexpr int WT = 64;                      // Winograd tiles per workgroup (8 x 8)
 constexpr int WN = 64;                      // output channels per workgroup
 constexpr int WK = 8;                       // input channels per K chunk
@@ -59,16 +59,19 @@ __device__ unsigned long long* g_wino_stamps = nullptr;
     } while (0)
 
 // EXP: timing-only variants (wrong results; tools/wino_stamps.py): 1 = no side work in the K loop, 2 = no global loads in it,
-// 3 = no LDS stores in it
+// 3 = no LDS stores in it, 4 = no MFMAs in the helper waves, 5 = no MFMAs in the staging waves
 template <bool XF, int EXP = 0>
-__global__ void __launch_bounds__(kWinoThreads) __attribute__((amdgpu_waves_per_eu(1, 1)))
+__global__ void __launch_bounds__(kWinoThreads) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_wino(ConvGeom g, int mode, const float* __restrict__ in, const float* __restrict__ U,
        const float* __restrict__ bias, const float* __restrict__ in_bn, int flags, float* __restrict__ out,
        int BH, int BW) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // waves 0-3 (half 0) stage AND multiply, waves 4-7 (half 1) only multiply: wave w and wave w + 4 sit on one SIMD and own
+    // the same 32 tiles x 32 channels, points 0-7 and 8-15
+    const int half = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
+    const int tid = threadIdx.x & 255;               // staging identity (half 0 only)
     const int H = g.Ho, W = g.Wo;
     unsigned long long* stamps = g_wino_stamps;
     const unsigned stamp_wg = blockIdx.y * gridDim.x + blockIdx.x;
@@ -109,7 +112,7 @@ k_wino(ConvGeom g, int mode, const float* __restrict__ in, const float* __restri
     // cache lines per wave instruction, every position fetched by up to four tiles: the loop was bound by the address unit,
     // ~1500 of 6200 cycles per chunk.)
     float* sR = smem + 2 * STAGE_FLOATS;
-    int rg_off[R_ITEMS], rl_off[R_ITEMS];
+    int rg_off[R_ITEMS];
 #pragma unroll
     for (int r = 0; r < R_ITEMS; ++r) {
         int item = tid + 256 * r;
@@ -120,8 +123,10 @@ k_wino(ConvGeom g, int mode, const float* __restrict__ in, const float* __restri
         y = y < 0 ? 0 : (y > H - 1 ? H - 1 : y);                 // positions outside the map read a valid address: the
         x = x < 0 ? 0 : (x > W - 1 ? W - 1 : x);                 // transform gates them to zero (pmask)
         rg_off[r] = (flags & 0x1000) ? 0 : (y * W + x) * g.in_stride + quad * 4;
-        rl_off[r] = pos * R_STRIDE + quad * 4;
     }
+    // LDS offset of item tid + 256 r: (position) * R_STRIDE + quad * 4 = rl0 + 64 R_STRIDE r; the last round is partial
+    const int rl0 = (tid >> 2) * R_STRIDE + (tid & 3) * 4;
+    const int rl5 = tid + 256 * 5 < R_POS * 4 ? rl0 + 5 * 64 * R_STRIDE : (R_POS - 1) * R_STRIDE + 12;
     const int rsrc = ((2 * ty) * 18 + 2 * tx) * R_STRIDE + cp * 2;      // patch (0, 0) of this thread's tile in the window
     const size_t plane_floats = (size_t)H * W * g.in_stride;
     const int u_chunk = (flags & 0x2000) ? 0 : 16 * WN * WK;   // floats of one (depth tap, channel chunk, column block) image
@@ -134,7 +139,6 @@ k_wino(ConvGeom g, int mode, const float* __restrict__ in, const float* __restri
     // 16-channel groups = two chunks).
     const int kd0 = __builtin_ctz(dmask | 16);
     int u_kd = kd0, u_cc = 0, u_left = nchunks - 1;
-    int x_kd = kd0, x_cc = 0, x_left = nchunks - 1;
     int w_kd = kd0, w_cc = 0, w_left = nchunks / 2 - 1;
     auto advance = [&](int& kd, int& cc, int& left, int step) {          // (selects, no branch)
         const bool more = left > 0;
@@ -144,8 +148,11 @@ k_wino(ConvGeom g, int mode, const float* __restrict__ in, const float* __restri
         kd = (more && wrap) ? kd_next : kd;
         cc = more ? (wrap ? 0 : cc + step) : cc;
     };
-    float4 rw0, rw1, rw2, rw3, rw4, rw5;             // the window's next 16 channels on their way to LDS
-    float4 ub0, ub1, ub2, ub3, ub4, ub5, ub6, ub7;   // the next U image on its way to LDS (named: an array stayed in scratch)
+    // Everything that goes through registers on its way to LDS is loaded AND stored inside one chunk (no load is in flight at
+    // a chunk boundary: the compiler waits for vmcnt(0) at the top of the loop body -- a wait count cannot be carried round the
+    // loop edge -- and a load issued just before it would be waited for in full):
+    float4 rw0, rw1, rw2;                            // half of the window's next 16 channels at a time (even chunks)
+    float4 ub0, ub1, ub2, ub3;                       // half of the next U image at a time (named: an array stayed in scratch)
     float2 tsc = make_float2(1.f, 1.f), tsh = make_float2(0.f, 0.f);
     auto window_src = [&]() -> const float* {
         bool dok = true;
@@ -153,46 +160,41 @@ k_wino(ConvGeom g, int mode, const float* __restrict__ in, const float* __restri
         return in + (size_t)sd * plane_floats + w_cc * WK;
     };
 #define WINO_R_LD(R_, I_) R_ = *reinterpret_cast<const float4*>(wsrc + rg_off[I_])
-#define WINO_R_ST(R_, I_) *reinterpret_cast<float4*>(sR + rl_off[I_]) = R_
-    auto issue_u = [&]() {
-        const float* us = U + ((size_t)(u_kd * ncc + u_cc) * nnb + nb) * u_chunk + tid * 4;
-        ub0 = *reinterpret_cast<const float4*>(us + 0 * 1024); ub1 = *reinterpret_cast<const float4*>(us + 1 * 1024);
-        ub2 = *reinterpret_cast<const float4*>(us + 2 * 1024); ub3 = *reinterpret_cast<const float4*>(us + 3 * 1024);
-        ub4 = *reinterpret_cast<const float4*>(us + 4 * 1024); ub5 = *reinterpret_cast<const float4*>(us + 5 * 1024);
-        ub6 = *reinterpret_cast<const float4*>(us + 6 * 1024); ub7 = *reinterpret_cast<const float4*>(us + 7 * 1024);
-        advance(u_kd, u_cc, u_left, 1);
-    };
-    auto store_u = [&](float* stage) {
-        float* up = stage + V_FLOATS + tid * 4;
-        *reinterpret_cast<float4*>(up + 0 * 1024) = ub0; *reinterpret_cast<float4*>(up + 1 * 1024) = ub1;
-        *reinterpret_cast<float4*>(up + 2 * 1024) = ub2; *reinterpret_cast<float4*>(up + 3 * 1024) = ub3;
-        *reinterpret_cast<float4*>(up + 4 * 1024) = ub4; *reinterpret_cast<float4*>(up + 5 * 1024) = ub5;
-        *reinterpret_cast<float4*>(up + 6 * 1024) = ub6; *reinterpret_cast<float4*>(up + 7 * 1024) = ub7;
-    };
-    auto issue_x = [&]() {
+#define WINO_R_ST(R_, I_) *reinterpret_cast<float4*>(sR + ((I_) < 5 ? rl0 + (I_) * 64 * R_STRIDE : rl5)) = R_
+#define WINO_U_LD4(Q_) { ub0 = *reinterpret_cast<const float4*>(us + ((Q_) + 0) * 1024); ub1 = *reinterpret_cast<const float4*>(us + ((Q_) + 1) * 1024); \
+                         ub2 = *reinterpret_cast<const float4*>(us + ((Q_) + 2) * 1024); ub3 = *reinterpret_cast<const float4*>(us + ((Q_) + 3) * 1024); }
+#define WINO_U_ST2(A_, B_, Q_) { *reinterpret_cast<float4*>(up + (Q_) * 1024) = A_; *reinterpret_cast<float4*>(up + ((Q_) + 1) * 1024) = B_; }
+    auto load_x = [&](float2& sc, float2& sh, int xc) {      // on-load constants of channel chunk xc
         if (XF) {
-            tsc = *reinterpret_cast<const float2*>(in_bn + x_cc * WK + cp * 2);
-            tsh = *reinterpret_cast<const float2*>(in_bn + g.Cin + x_cc * WK + cp * 2);
+            sc = *reinterpret_cast<const float2*>(in_bn + xc * WK + cp * 2);
+            sh = *reinterpret_cast<const float2*>(in_bn + g.Cin + xc * WK + cp * 2);
         }
-        advance(x_kd, x_cc, x_left, 1);
     };
 
-    f32x16 acc[16];
+    f32x16 acc[8];
 #pragma unroll
-    for (int p = 0; p < 16; ++p) acc[p] = (f32x16){0};
+    for (int p = 0; p < 8; ++p) acc[p] = (f32x16){0};
 
     const int arow = wm * 32 + (lane & 31), brow = wn * 32 + (lane & 31);
-    const int aoff = arow * 8 + (((lane >> 5) ^ ((arow >> 3) & 1)) << 2);
-    const int boff = V_FLOATS + brow * 8 + (((lane >> 5) ^ ((brow >> 3) & 1)) << 2);
+    const int aoff = half * 8 * (WT * WK) + arow * 8 + (((lane >> 5) ^ ((arow >> 3) & 1)) << 2);
+    const int boff = V_FLOATS + half * 8 * (WN * WK) + brow * 8 + (((lane >> 5) ^ ((brow >> 3) & 1)) << 2);
 
     float2 d[16], t[16];
-    // gate (+ BatchNormalization, ReLU) of patch row i of the window's channel half `half`: d[4 i .. 4 i + 3]
-    auto gate_row = [&](int i, int half, const float2& sc, const float2& sh) {
+    // rows i0, i0 + 1 of the thread's 4 x 4 patch of the window's channel half `ch_half` -> d (raw; gated two slices later)
+    auto read_rows = [&](int i0, int ch_half) {
+#pragma unroll
+        for (int i = i0; i < i0 + 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                d[4 * i + j] = *reinterpret_cast<const float2*>(sR + rsrc + (i * 18 + j) * R_STRIDE + ch_half * WK);
+    };
+    // gate (+ BatchNormalization, ReLU) of patch row i, in place
+    auto gate_row = [&](int i, const float2& sc, const float2& sh) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int e = 4 * i + j;
             const bool ok = (pmask >> e) & 1;
-            float2 v = *reinterpret_cast<const float2*>(sR + rsrc + (i * 18 + j) * R_STRIDE + half * WK);
+            float2 v = d[e];
             if (XF) {
                 v.x = fmaxf(fmaf(v.x, sc.x, sh.x), relu_lo);
                 v.y = fmaxf(fmaf(v.y, sc.y, sh.y), relu_lo);
@@ -224,137 +226,156 @@ k_wino(ConvGeom g, int mode, const float* __restrict__ in, const float* __restri
     };
 
     if (nchunks > 0) {
-        // window of group 0 -> LDS; the registers then take group 1's; image of chunk 0 -> stage 0; U / constants of chunk 1
-        {
+        // window of group 0 -> LDS, image of chunk 0 -> stage 0 (the loop then prepares chunk c + 1 inside chunk c)
+        if (half == 0) {
             const float* wsrc = window_src();
-            WINO_R_LD(rw0, 0); WINO_R_LD(rw1, 1); WINO_R_LD(rw2, 2); WINO_R_LD(rw3, 3); WINO_R_LD(rw4, 4); WINO_R_LD(rw5, 5);
+            WINO_R_LD(rw0, 0); WINO_R_LD(rw1, 1); WINO_R_LD(rw2, 2);
+            WINO_R_ST(rw0, 0); WINO_R_ST(rw1, 1); WINO_R_ST(rw2, 2);
+            WINO_R_LD(rw0, 3); WINO_R_LD(rw1, 4); WINO_R_LD(rw2, 5);
+            WINO_R_ST(rw0, 3); WINO_R_ST(rw1, 4); WINO_R_ST(rw2, 5);
             advance(w_kd, w_cc, w_left, 2);
+            load_x(tsc, tsh, 0);
         }
-        issue_u();
-        issue_x();
-        WINO_R_ST(rw0, 0); WINO_R_ST(rw1, 1); WINO_R_ST(rw2, 2); WINO_R_ST(rw3, 3); WINO_R_ST(rw4, 4); WINO_R_ST(rw5, 5);
         __syncthreads();
-        {
-            const float* wsrc = window_src();
-            WINO_R_LD(rw0, 0); WINO_R_LD(rw1, 1); WINO_R_LD(rw2, 2); WINO_R_LD(rw3, 3); WINO_R_LD(rw4, 4); WINO_R_LD(rw5, 5);
-            advance(w_kd, w_cc, w_left, 2);
+        if (half == 0) {
+            const float* us = U + ((size_t)(u_kd * ncc + u_cc) * nnb + nb) * u_chunk + tid * 4;
+            float* up = smem + V_FLOATS + tid * 4;
+            WINO_U_LD4(0)
+            read_rows(0, 0);
+            read_rows(2, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) gate_row(i, tsc, tsh);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bt_col(j);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) b_row(i, smem + vdst, true);
+            WINO_U_ST2(ub0, ub1, 0) WINO_U_ST2(ub2, ub3, 2)
+            WINO_U_LD4(4)
+            WINO_U_ST2(ub0, ub1, 4) WINO_U_ST2(ub2, ub3, 6)
+            advance(u_kd, u_cc, u_left, 1);
+            load_x(tsc, tsh, u_cc);                  // chunk 1's
         }
-        const float2 sc = tsc, sh = tsh;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) gate_row(i, 0, sc, sh);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) bt_col(j);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) b_row(i, smem + vdst, true);
-        store_u(smem);
-        issue_u();
-        issue_x();
     }
     __syncthreads();
     WINO_STAMP(1, __builtin_amdgcn_s_memrealtime());
     WINO_STAMP(4, __builtin_amdgcn_s_memtime());
-    // One wave per SIMD: whatever is not an MFMA has to issue in the shadow of one (64 cycles each, ~13 issue slots), and the
-    // compiler left alone puts the whole transform in front of the MFMAs and the loads behind them.  A chunk is therefore cut
-    // by hand into 8 groups of two transform points (four fragment reads, eight MFMAs alternating between two accumulators)
-    // and every group carries two slices p of the side work for chunk c + 1, pinned by sched_barrier:
-    //   p 0-3    patch row i: four 8-byte reads from the window, gate (+ BatchNormalization, ReLU); two 16-byte stores of the
-    //            U image of chunk c + 1
-    //   p 4-7    B^T d (column j); ODD chunks: two 16-byte loads of the window's next 16 channels (p 4-6)
-    //   p 8-11   (B^T d) B (row i) and its four 8-byte stores into the other stage; two loads of the U image of chunk c + 2
-    //   p 12-14  EVEN chunks: the window's next 16 channels -> LDS (two 16-byte stores each).  The window is single: an even
-    //            chunk reads its second half (p 0-3), ALL waves meet at a barrier after group 2, and only then is it
-    //            overwritten; the odd chunk that follows reads the new window after the barrier that ends the even one.
-    // (the compiler waits for vmcnt(0) at the top of a chunk -- a wait count cannot be carried round the loop edge -- so the
-    // last load of a chunk goes out ~1000 MFMA cycles before its end)
-    auto chunk = [&](auto par_tag) {
+    // A wave's fp32 MFMA holds its issue slot for the whole 64 cycles: measured on the one-wave-per-SIMD form of this kernel,
+    // the issue time of EVERY other instruction of the wave simply added to the MFMA time (4293 cycles per chunk with nothing
+    // but MFMAs and fragment reads, 6039 with the staging: profiles/r04_winograd.txt) -- nothing hides in a lone wave.  So a
+    // SIMD holds TWO waves: wave w (half 0) runs 32 MFMAs per chunk and ALL of the staging, wave w + 4 (half 1) runs the other
+    // 32 MFMAs and nothing else; while the one stages, the other's MFMAs keep the pipe busy.  The compiler left alone puts the
+    // whole transform in front of the MFMAs and the loads behind them, so the stager's chunk is cut by hand into 8 groups of
+    // one transform point (two fragment reads, four MFMAs), each carrying two
+    // slices p of the side work for chunk c + 1, pinned by sched_barrier:
+    //   p 0-1    the thread's 4 x 4 patch: two rows (eight 8-byte reads from the window) per slice, gated two slices later --
+    //            the side work alone is LATENCY-bound (4400 cycles per chunk with read-then-use slices and no MFMA at all)
+    //   p 0, 8   four 16-byte loads of one half of the U image of chunk c + 1;  p 6-7, 14-15  their stores, two per slice
+    //   p 1-2    EVEN chunks: three 16-byte loads each of the window's next 16 channels;  p 12-13  their stores.  The window
+    //            is single: an even chunk reads its second half (p 0-1), ALL waves meet at a barrier after group 3 (p 7), and
+    //            only then is it overwritten; the odd chunk that follows reads the new window after the barrier that ends
+    //            the even one
+    //   p 2-5    gate (+ BatchNormalization, ReLU) of patch row i;  p 3  the on-load constants of chunk c + 2
+    //   p 6-9    B^T d (column j)
+    //   p 10-13  (B^T d) B (row i) and its four 8-byte stores into the other stage
+#define WINO_MFMA4(P_)                                                                                   \
+    acc[P_] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b0.x, acc[P_], 0, 0, 0);                            \
+    acc[P_] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b0.y, acc[P_], 0, 0, 0);                            \
+    acc[P_] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b0.z, acc[P_], 0, 0, 0);                            \
+    acc[P_] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b0.w, acc[P_], 0, 0, 0);
+    auto chunk = [&](auto par_tag, auto stager_tag) {
         constexpr int PAR = decltype(par_tag)::value;
+        constexpr bool STAGER = decltype(stager_tag)::value != 0;
         const float* st = smem + PAR * STAGE_FLOATS;
         float* nx = smem + (PAR ^ 1) * STAGE_FLOATS;
         const float* ap = st + aoff;
         const float* bp = st + boff;
-        float4 a0 = *reinterpret_cast<const float4*>(ap), a1 = *reinterpret_cast<const float4*>(ap + WT * WK);
-        float4 b0 = *reinterpret_cast<const float4*>(bp), b1 = *reinterpret_cast<const float4*>(bp + WN * WK);
+        float4 a0 = *reinterpret_cast<const float4*>(ap);
+        float4 b0 = *reinterpret_cast<const float4*>(bp);
         const float* us = U + ((size_t)(u_kd * ncc + u_cc) * nnb + nb) * u_chunk + tid * 4;
         float* up = nx + V_FLOATS + tid * 4;
-        const float* wsrc = window_src();
-        const float2 sc = tsc, sh = tsh;             // (chunk c + 1's; issue_x below replaces them with chunk c + 2's)
+        const float* wsrc = STAGER ? window_src() : in;
+        const float2 sc = tsc, sh = tsh;             // chunk c + 1's
+        float2 scn = sc, shn = sh;
+        const int x_next = (u_left > 0) ? (u_cc + 1 == ncc ? 0 : u_cc + 1) : u_cc;      // channel chunk of chunk c + 2
         float* vp = nx + vdst;
 #pragma unroll
         for (int pp = 0; pp < 8; ++pp) {
-            float4 a0n = a0, a1n = a1, b0n = b0, b1n = b1;
+            float4 a0n = a0, b0n = b0;
             if (pp + 1 < 8) {
-                a0n = *reinterpret_cast<const float4*>(ap + (2 * pp + 2) * (WT * WK));
-                b0n = *reinterpret_cast<const float4*>(bp + (2 * pp + 2) * (WN * WK));
-                a1n = *reinterpret_cast<const float4*>(ap + (2 * pp + 3) * (WT * WK));
-                b1n = *reinterpret_cast<const float4*>(bp + (2 * pp + 3) * (WN * WK));
+                a0n = *reinterpret_cast<const float4*>(ap + (pp + 1) * (WT * WK));
+                b0n = *reinterpret_cast<const float4*>(bp + (pp + 1) * (WN * WK));
             }
-#define WINO_U_ST(A_, B_, Q_) if (EXP != 1 && EXP != 3) { *reinterpret_cast<float4*>(up + (Q_) * 1024) = A_; *reinterpret_cast<float4*>(up + ((Q_) + 1) * 1024) = B_; }
-#define WINO_U_LD(A_, B_, Q_) if (EXP != 1 && EXP != 2) { A_ = *reinterpret_cast<const float4*>(us + (Q_) * 1024); B_ = *reinterpret_cast<const float4*>(us + ((Q_) + 1) * 1024); }
+            if (STAGER && EXP != 1) {
 #pragma unroll
-            for (int p = 2 * pp; p < 2 * pp + 2; ++p) {
-                if (EXP == 1) continue;
-                if (p == 0) WINO_U_ST(ub0, ub1, 0)
-                if (p == 1) WINO_U_ST(ub2, ub3, 2)
-                if (p == 2) WINO_U_ST(ub4, ub5, 4)
-                if (p == 3) WINO_U_ST(ub6, ub7, 6)
-                if (p == 8) WINO_U_LD(ub0, ub1, 0)
-                if (p == 9) WINO_U_LD(ub2, ub3, 2)
-                if (p == 10) WINO_U_LD(ub4, ub5, 4)
-                if (p == 11) WINO_U_LD(ub6, ub7, 6)
-                if (p < 4) gate_row(p, PAR ^ 1, sc, sh);         // chunk c + 1 is the OTHER half of the window's 16 channels
-                else if (p < 8) bt_col(p - 4);
-                else if (p < 12) b_row(p - 8, vp, EXP != 3);
-                if (PAR == 1 && EXP != 2) {
-                    if (p == 4) { WINO_R_LD(rw0, 0); WINO_R_LD(rw1, 1); }
-                    if (p == 5) { WINO_R_LD(rw2, 2); WINO_R_LD(rw3, 3); }
-                    if (p == 6) { WINO_R_LD(rw4, 4); WINO_R_LD(rw5, 5); }
-                }
-                if (PAR == 0 && EXP != 3) {
-                    if (p == 12) { WINO_R_ST(rw0, 0); WINO_R_ST(rw1, 1); }
-                    if (p == 13) { WINO_R_ST(rw2, 2); WINO_R_ST(rw3, 3); }
-                    if (p == 14) { WINO_R_ST(rw4, 4); WINO_R_ST(rw5, 5); }
+                for (int p = 2 * pp; p < 2 * pp + 2; ++p) {
+                    if (p == 0) WINO_U_LD4(0)
+                    if (p == 0) read_rows(0, PAR ^ 1);           // chunk c + 1 is the OTHER half of the window's 16 channels
+                    if (p == 1) read_rows(2, PAR ^ 1);
+                    if (PAR == 0) {
+                        if (p == 1) { WINO_R_LD(rw0, 0); WINO_R_LD(rw1, 1); WINO_R_LD(rw2, 2); }
+                        if (p == 8) { WINO_R_ST(rw0, 0); WINO_R_ST(rw1, 1); WINO_R_ST(rw2, 2); }      // (behind the barrier)
+                        if (p == 9) { WINO_R_LD(rw0, 3); WINO_R_LD(rw1, 4); WINO_R_LD(rw2, 5); }
+                        if (p == 15) { WINO_R_ST(rw0, 3); WINO_R_ST(rw1, 4); WINO_R_ST(rw2, 5); }
+                    }
+                    if (p >= 2 && p < 6) gate_row(p - 2, sc, sh);
+                    if (p == 3) load_x(scn, shn, x_next);
+                    if (p >= 6 && p < 10) bt_col(p - 6);
+                    if (p >= 10 && p < 14) b_row(p - 10, vp, true);
+                    if (p == 6) WINO_U_ST2(ub0, ub1, 0)
+                    if (p == 7) WINO_U_ST2(ub2, ub3, 2)
+                    if (p == 8) WINO_U_LD4(4)
+                    if (p == 14) WINO_U_ST2(ub0, ub1, 4)
+                    if (p == 15) WINO_U_ST2(ub2, ub3, 6)
                 }
             }
-#undef WINO_U_ST
-#undef WINO_U_LD
-            acc[2 * pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b0.x, acc[2 * pp], 0, 0, 0);
-            acc[2 * pp + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b1.x, acc[2 * pp + 1], 0, 0, 0);
-            acc[2 * pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b0.y, acc[2 * pp], 0, 0, 0);
-            acc[2 * pp + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b1.y, acc[2 * pp + 1], 0, 0, 0);
-            acc[2 * pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b0.z, acc[2 * pp], 0, 0, 0);
-            acc[2 * pp + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b1.z, acc[2 * pp + 1], 0, 0, 0);
-            acc[2 * pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b0.w, acc[2 * pp], 0, 0, 0);
-            acc[2 * pp + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b1.w, acc[2 * pp + 1], 0, 0, 0);
+            if (!((EXP == 4 && !STAGER) || (EXP == 5 && STAGER))) { WINO_MFMA4(pp) }
+            if (STAGER) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // MFMA
-                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);      // VALU
-                __builtin_amdgcn_sched_group_barrier(0x080, 1, 0);      // LDS read / write
-                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // global load
+                for (int i = 0; i < 4; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);      // VALU
+                    __builtin_amdgcn_sched_group_barrier(0x080, 2, 0);      // LDS read / write
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // global load
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (PAR == 0 && pp == 2 && EXP != 1) __syncthreads();      // every wave has read the window's second half
-            a0 = a0n; a1 = a1n; b0 = b0n; b1 = b1n;
+            if (PAR == 0 && pp == 3 && EXP != 1) __syncthreads();      // every wave has read the window's second half
+            a0 = a0n; b0 = b0n;
         }
-        advance(u_kd, u_cc, u_left, 1);
-        if (PAR == 1) advance(w_kd, w_cc, w_left, 2);
-        issue_x();
+        if (STAGER) {
+            advance(u_kd, u_cc, u_left, 1);
+            if (PAR == 0) advance(w_kd, w_cc, w_left, 2);
+            tsc = scn; tsh = shn;
+        }
         __syncthreads();
     };
-    for (int c = 0; c < nchunks; c += 2) {
-        chunk(std::integral_constant<int, 0>{});
-        chunk(std::integral_constant<int, 1>{});
+    if (half == 0) {
+        for (int c = 0; c < nchunks; c += 2) {
+            chunk(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+            chunk(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+        }
+    } else {
+        for (int c = 0; c < nchunks; c += 2) {
+            chunk(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+            chunk(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
+        }
     }
+#undef WINO_MFMA4
 #undef WINO_R_LD
 #undef WINO_R_ST
+#undef WINO_U_LD4
+#undef WINO_U_ST2
 
     WINO_STAMP(2, __builtin_amdgcn_s_memrealtime());
     WINO_STAMP(5, __builtin_amdgcn_s_memtime());
     WINO_STAMP(6, (unsigned long long)nchunks);
     if (flags & 0x8000) { if (acc[3][5] == 123.f) out[0] = 1.f; return; }
-    // ---- output transform A^T M A (lane-local) + the epilogue of the direct kernels ---------------------------------------
+    // ---- output transform A^T M A + the epilogue of the direct kernels --------------------------------------------------
     // accumulator register r of a lane: tile row (r >> 2) of the wave's four, tile column (r & 3) + 4 (lane >> 5), channel
-    // lane & 31 -- the output line is wave-uniform (scalar row pointers), the position inside it one 32-bit lane offset
+    // lane & 31 -- the output line is wave-uniform (scalar row pointers), the position inside it one 32-bit lane offset.
+    // A half holds two of the four rows i of M: it forms its share of both output lines a (the transform is linear), keeps
+    // line a = half, hands line a = half ^ 1 to the wave it shares the tile with through LDS (the stages are dead), adds what
+    // it is handed and stores its line.
     int lane_e = lane;
     asm volatile("" : "+v"(lane_e));                 // (keeps the epilogue's per-lane values out of the K loop's registers)
     const int col = lane_e & 31, hi = lane_e >> 5;
@@ -366,31 +387,49 @@ k_wino(ConvGeom g, int mode, const float* __restrict__ in, const float* __restri
     if (g.bwd_y && nok) { ys = g.bwd_bn[n]; yh = g.bwd_bn[g.Cout + n]; ym = g.bwd_bn[2 * g.Cout + n]; yi = g.bwd_bn[3 * g.Cout + n]; }
     const int xt = 2 * (bx * 8 + 4 * hi);            // first output column of the lane's tile column 0
     const unsigned xo = (unsigned)(xt * g.out_stride + n), xy = (unsigned)(xt * g.Cout + n);
-    float sum = 0.f, sq = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int gty = by * 8 + wm * 4 + (r >> 2);
-        float s[2][4];
+    // this half's share of output line a, columns b = 0, 1, from accumulator register r (A^T M A is linear in the rows of M)
+    auto share = [&](int r, int a, float& ob0, float& ob1) {
+        float s[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            s[0][j] = acc[0 + j][r] + acc[4 + j][r] + acc[8 + j][r];
-            s[1][j] = acc[4 + j][r] - acc[8 + j][r] - acc[12 + j][r];
+            const float m_lo = acc[j][r], m_hi = acc[4 + j][r];          // rows i = 2 half, 2 half + 1 of M
+            s[j] = half == 0 ? (a == 0 ? m_lo + m_hi : m_hi) : (a == 0 ? m_lo : -m_lo - m_hi);
         }
+        ob0 = s[0] + s[1] + s[2];
+        ob1 = s[1] - s[2] - s[3];
+    };
+    {
+        float* give = smem + (half ^ 1) * 8192 + ((wave & 3) * 32) * 64 + lane_e;      // [receiving half][tile wave][2 r + b][lane]
 #pragma unroll
-        for (int a2 = 0; a2 < 2; ++a2) {
-            const float o0 = s[a2][0] + s[a2][1] + s[a2][2];
-            const float o1 = s[a2][1] - s[a2][2] - s[a2][3];
+        for (int r = 0; r < 16; ++r) {
+            float g0, g1;
+            share(r, half ^ 1, g0, g1);
+            give[(2 * r) * 64] = g0;
+            give[(2 * r + 1) * 64] = g1;
+        }
+    }
+    __syncthreads();
+    float sum = 0.f, sq = 0.f;
+    {
+        const float* take = smem + half * 8192 + ((wave & 3) * 32) * 64 + lane_e;
+        const int a2 = half;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int gty = by * 8 + wm * 4 + (r >> 2);
             const int y = 2 * gty + a2;
             const size_t line = ((size_t)dplane * H + y) * W;
             float* oline = out + line * g.out_stride;
             const float* mline = g.out_mask ? g.out_mask + line * g.out_stride : nullptr;
             const float* yline = g.bwd_y ? g.bwd_y + line * g.Cout : nullptr;
+            float k0, k1;
+            share(r, a2, k0, k1);
 #pragma unroll
             for (int b2 = 0; b2 < 2; ++b2) {
                 const int dx = 2 * (r & 3) + b2;
+                const float part = take[(2 * r + b2) * 64], mine = b2 ? k1 : k0;
                 if (y < H && xt + dx < W && nok) {
                     const unsigned off = xo + (unsigned)(dx * g.out_stride);
-                    float v = (b2 ? o1 : o0) + bv;
+                    float v = (half == 0 ? mine + part : part + mine) + bv;       // (rows 0-1 of M first: one order)
                     if (accum) v += oline[off];
                     if (mline && !(mline[off] > 0.f)) v = 0.f;
                     if (orelu) v = fmaxf(v, 0.f);
@@ -408,14 +447,17 @@ k_wino(ConvGeom g, int mode, const float* __restrict__ in, const float* __restri
     }
     WINO_STAMP(3, __builtin_amdgcn_s_memrealtime());
     if (g.sink.acc) {
-        __syncthreads();                             // (the stages are dead: the scratch below reuses them)
-        float* red = smem;                           // [4 waves][2][32]
+        __syncthreads();                             // (the exchange is over: the scratch below reuses its space)
+        float* red = smem;                           // [8 waves][2][32]
         sum += __shfl_xor(sum, 32, 64); sq += __shfl_xor(sq, 32, 64);
         if (lane < 32) { red[(wave * 2 + 0) * 32 + lane] = sum; red[(wave * 2 + 1) * 32 + lane] = sq; }
         __syncthreads();
-        if (tid < 128) {
-            const int which = (tid >> 5) & 1, hn = tid >> 6, c = tid & 31;
-            const double v = (double)red[((0 * 2 + hn) * 2 + which) * 32 + c] + (double)red[((1 * 2 + hn) * 2 + which) * 32 + c];
+        if (threadIdx.x < 128) {
+            const int which = (threadIdx.x >> 5) & 1, hn = threadIdx.x >> 6, c = threadIdx.x & 31;
+            double v = 0.0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w)              // the four waves that hold column half hn: (half, wm) = (w >> 1, w & 1)
+                v += (double)red[((((w >> 1) * 4 + (w & 1) * 2 + hn) * 2) + which) * 32 + c];
             const int ch = nb * WN + hn * 32 + c;
             if (ch < g.Cout) sink_add(g.sink, which, ch, v);
         }
@@ -552,10 +594,12 @@ extern "C" int lisec_conv_forward_winograd(const lisec_conv_geom* c, const float
     hipStream_t st = static_cast<hipStream_t>(stream_);
 #define LISEC_WINO_GO(X_, E_) LISEC_LAUNCH((k_wino<X_, E_>), grid, dim3(kWinoThreads), kWinoLds, st, g, c->mode, in, wino_w, bias, \
         in_bnstate, flags, out, BH, BW)
-    const int exp = (flags >> 16) & 3;               // timing-only variants (tools/wino_stamps.py), 0 in every real call
+    const int exp = (flags >> 16) & 7;               // timing-only variants (tools/wino_stamps.py), 0 in every real call
     if (exp == 1) LISEC_WINO_GO(false, 1);
     else if (exp == 2) LISEC_WINO_GO(false, 2);
     else if (exp == 3) LISEC_WINO_GO(false, 3);
+    else if (exp == 4) LISEC_WINO_GO(false, 4);
+    else if (exp == 5) LISEC_WINO_GO(false, 5);
     else if (in_bnstate) LISEC_WINO_GO(true, 0);
     else LISEC_WINO_GO(false, 0);
 #undef LISEC_WINO_GO

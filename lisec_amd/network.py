@@ -156,6 +156,25 @@ class LisecNet:
                         self.bnstate[c.bn] = torch.zeros(4 * c.g.Cout, dtype=f32, device=dev)
                         max_parts = max(max_parts, c.nmb * 2 * c.g.Cout)
         self.packed["head"] = torch.empty(ops.packed_floats(1, 768, 16), dtype=f32, device=dev)
+        # Winograd F(2x2, 3x3) form (csrc/wino.hip) of the stride-1 3x3 contractions that fill the chip in it (>= 128 blocks of
+        # 8 x 8 tiles x 64 channels: the Conv3D blocks behind the first and the stride-1 Conv2Ds of RPN block 1): 4 / 9 of the
+        # multiplications.  LISEC_TUNING winograd: bit 0 = forward calls, bit 1 = data gradients (0 keeps the direct kernels)
+        self.winograd = _lib.knob("winograd", 3)
+        self.packed_wu, self.packed_wu_t = {}, {}
+        for L in self.layers:
+            c = L["conv"]
+            g = c.g
+            if L["kind"] == "deconv" or L["src"] == "grid" or not self.winograd:
+                continue
+            blocks = g.Do * ((g.Ho + 15) // 16) * ((g.Wo + 15) // 16) * ((g.Cout + 63) // 64)
+            if blocks >= 128 and ops.winograd_supported(g, in_bn=c.in_bn is not None, flags=ops.IN_RELU if c.in_relu else 0):
+                if self.winograd & 1:
+                    self.packed_wu[c.name] = torch.empty(ops.winograd_packed_floats(g.KD, g.Cin, g.Cout), dtype=f32, device=dev)
+                # data gradient: kept on the direct kernel where the Dense(64) gradient of the block below rides on its tile
+                # (lisec_conv_extras.tail_w: the middle blocks) -- measured equal there, and the tail would cost a launch
+                if self.winograd & 2 and L["kind"] == "conv":
+                    self.packed_wu_t[c.name] = torch.empty(ops.winograd_packed_floats(g.KD, g.Cout, g.Cin), dtype=f32,
+                                                           device=dev)
         self.head_w = torch.empty(768, 16, dtype=f32, device=dev)
         self.head_b = torch.empty(16, dtype=f32, device=dev)
         self.fused_bias = torch.empty(16, dtype=f32, device=dev)     # b' = head bias + the branch biases through H
@@ -238,6 +257,12 @@ class LisecNet:
         # (after_main records that point when the repack runs early on the second stream); the composite kernels of the
         # collapsed heads -- three compose launches in front of their pack -- are not read before the first branch
         self._pack_table.run()
+        for L in self.layers:
+            c = L["conv"]
+            if c.name in self.packed_wu:
+                g = c.g
+                ops.pack_weights_winograd(p.view(c.wname), g.KD, g.Cin, g.Cout, g.Cin * g.Cout, g.Cout, 1,
+                                          out=self.packed_wu[c.name])
         if after_main is not None:
             after_main()
         if self.compose_head:
@@ -287,8 +312,12 @@ class LisecNet:
         p = self.params
         flags = (ops.IN_RELU if c.in_relu else 0) | (ops.OUT_RELU if c.out_relu else 0)
         sink = self._fwd_sink(c) if (c.bn and training) else None
-        ops.conv_forward(c.g, x, self.packed[c.name], out, bias=p.view(c.bias) if c.bias else None,
-                         in_bn=self.bnstate[c.in_bn] if c.in_bn else None, flags=flags, sink=sink, ws_tag=ws_tag)
+        if c.name in self.packed_wu:
+            ops.conv_forward_winograd(c.g, x, self.packed_wu[c.name], out, bias=p.view(c.bias) if c.bias else None,
+                                      in_bn=self.bnstate[c.in_bn] if c.in_bn else None, flags=flags, sink=sink)
+        else:
+            ops.conv_forward(c.g, x, self.packed[c.name], out, bias=p.view(c.bias) if c.bias else None,
+                             in_bn=self.bnstate[c.in_bn] if c.in_bn else None, flags=flags, sink=sink, ws_tag=ws_tag)
         if c.bn:
             self._bn_after(c, training)
 
@@ -581,6 +610,12 @@ class LisecNet:
                 entries.append((self.head_w, self.packed_t["head"][0], 1, 16, 768, 0, 1, 16))
             self._pack_table_t = ops.PackTable(entries, self.device)
         self._pack_table_t.run()
+        for L in self.layers:
+            c = L["conv"]
+            if c.name in self.packed_wu_t:
+                g = c.g                          # K = forward Cout, N = forward Cin, taps mirrored
+                ops.pack_weights_winograd(p.view(c.wname), g.KD, g.Cout, g.Cin, g.Cin * g.Cout, 1, g.Cout, flip=True,
+                                          out=self.packed_wu_t[c.name])
         self._packed_t_version = (self.params_version, self.params.version)
 
     def backward(self, y_cls, y_reg, loss="mse", grad_scale=1.0, rpn_grads_ready=None, side_filler=None):
@@ -779,8 +814,12 @@ class LisecNet:
                 bwd = (a[n + ".y"], self.bnstate[cn.bn], False)
                 tail = (self.packed_t[dn.name][0], d[n + ".z"])
                 fused_dense[n] = sink
-            ops.conv_forward(self.dgeom[c.name], dy, self.packed_t[c.name][0], d[dst_name], flags=flags, out_mask=mask,
-                             bwd=bwd, sink=sink, ws_tag=ws_tag, tail=tail, fold=fold)
+            if c.name in self.packed_wu_t and tail is None and fold is None:
+                ops.conv_forward_winograd(self.dgeom[c.name], dy, self.packed_wu_t[c.name], d[dst_name], flags=flags,
+                                          out_mask=mask, bwd=bwd, sink=sink)
+            else:
+                ops.conv_forward(self.dgeom[c.name], dy, self.packed_t[c.name][0], d[dst_name], flags=flags, out_mask=mask,
+                                 bwd=bwd, sink=sink, ws_tag=ws_tag, tail=tail, fold=fold)
             first_write.add(dst_name)
 
         def branch_dy(L):
