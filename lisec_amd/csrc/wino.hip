@@ -64,7 +64,7 @@ template <bool XF, int EXP = 0>
 __global__ void __launch_bounds__(kWinoThreads) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_wino(ConvGeom g, int mode, const float* __restrict__ in, const float* __restrict__ U,
        const float* __restrict__ bias, const float* __restrict__ in_bn, int flags, float* __restrict__ out,
-       int BH, int BW) {
+       int BH, int BW, unsigned plane_list) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -79,8 +79,13 @@ k_wino(ConvGeom g, int mode, const float* __restrict__ in, const float* __restri
     // ---- which block ------------------------------------------------------------------------------------------
     const int blk = xcd_remap(blockIdx.x, gridDim.x);
     const int per_plane = BH * BW;
-    const int dplane = blk / per_plane;
-    const int brem = blk - dplane * per_plane;
+    // plane_list: the output planes this launch covers, one nibble each.  The planes of a strided / transposed Conv3D run
+    // different numbers of depth taps (the data gradient of the second middle block: 1, 2, 2, 1) and the dispatcher waits for
+    // a slot on the CU whose turn it is: in one launch the unequal workgroups left a third of the chip idle (mean 175 of 256
+    // workgroups alive), so the host issues one launch per tap count.
+    const int dslot = blk / per_plane;
+    const int dplane = (plane_list >> (4 * dslot)) & 15;
+    const int brem = blk - dslot * per_plane;
     const int by = brem / BW, bx = brem - by * BW;
     const int nb = blockIdx.y;
     // ---- depth taps of this output plane (wave-uniform): bit kd of dmask = tap kd reads a plane inside the tensor -------------
@@ -590,18 +595,35 @@ extern "C" int lisec_conv_forward_winograd(const lisec_conv_geom* c, const float
             g.sink.bnstate = sk->bnstate; g.sink.dgamma = sk->dgamma; g.sink.dbeta = sk->dbeta; g.sink.coef = sk->coef;
         }
     }
-    dim3 grid(g.Do * BH * BW, nnb, 1);
+    // one launch per number of live depth taps (see k_wino: plane_list), most taps first
+    LISEC_CHECK_ARG(g.Do <= 8, "Winograd form: at most 8 output planes");
+    int live[8];
+    for (int d = 0; d < g.Do; ++d) {
+        live[d] = 0;
+        for (int kd = 0; kd < g.KD; ++kd) {
+            if (c->mode == 0) { const int sd = (d << g.ls_d) - g.pd + kd; live[d] += sd >= 0 && sd < g.Di; }
+            else { const int t = d + g.pd - kd; live[d] += t >= 0 && (t & ((1 << g.ls_d) - 1)) == 0 && (t >> g.ls_d) < g.Di; }
+        }
+    }
     hipStream_t st = static_cast<hipStream_t>(stream_);
-#define LISEC_WINO_GO(X_, E_) LISEC_LAUNCH((k_wino<X_, E_>), grid, dim3(kWinoThreads), kWinoLds, st, g, c->mode, in, wino_w, bias, \
-        in_bnstate, flags, out, BH, BW)
     const int exp = (flags >> 16) & 7;               // timing-only variants (tools/wino_stamps.py), 0 in every real call
-    if (exp == 1) LISEC_WINO_GO(false, 1);
-    else if (exp == 2) LISEC_WINO_GO(false, 2);
-    else if (exp == 3) LISEC_WINO_GO(false, 3);
-    else if (exp == 4) LISEC_WINO_GO(false, 4);
-    else if (exp == 5) LISEC_WINO_GO(false, 5);
-    else if (in_bnstate) LISEC_WINO_GO(true, 0);
-    else LISEC_WINO_GO(false, 0);
+#define LISEC_WINO_GO(X_, E_) LISEC_LAUNCH((k_wino<X_, E_>), grid, dim3(kWinoThreads), kWinoLds, st, g, c->mode, in, wino_w, bias, \
+        in_bnstate, flags, out, BH, BW, plane_list)
+    for (int taps = g.KD; taps >= 0; --taps) {
+        unsigned plane_list = 0;
+        int nslots = 0;
+        for (int d = 0; d < g.Do; ++d)
+            if (live[d] == taps) plane_list |= (unsigned)d << (4 * nslots++);
+        if (!nslots) continue;
+        dim3 grid(nslots * BH * BW, nnb, 1);
+        if (exp == 1) LISEC_WINO_GO(false, 1);
+        else if (exp == 2) LISEC_WINO_GO(false, 2);
+        else if (exp == 3) LISEC_WINO_GO(false, 3);
+        else if (exp == 4) LISEC_WINO_GO(false, 4);
+        else if (exp == 5) LISEC_WINO_GO(false, 5);
+        else if (in_bnstate) LISEC_WINO_GO(true, 0);
+        else LISEC_WINO_GO(false, 0);
+    }
 #undef LISEC_WINO_GO
     LISEC_LAUNCH_CHECK();
     return LISEC_OK;

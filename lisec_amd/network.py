@@ -158,8 +158,9 @@ class LisecNet:
         self.packed["head"] = torch.empty(ops.packed_floats(1, 768, 16), dtype=f32, device=dev)
         # Winograd F(2x2, 3x3) form (csrc/wino.hip) of the stride-1 3x3 contractions that fill the chip in it (>= 128 blocks of
         # 8 x 8 tiles x 64 channels: the Conv3D blocks behind the first and the stride-1 Conv2Ds of RPN block 1): 4 / 9 of the
-        # multiplications.  LISEC_TUNING winograd: bit 0 = forward calls, bit 1 = data gradients (0 keeps the direct kernels)
-        self.winograd = _lib.knob("winograd", 3)
+        # multiplications.  LISEC_TUNING winograd: bit 0 = forward calls, bit 1 = data gradients of the Conv2Ds, bit 2 = data gradients of the Conv3D
+        # blocks (their Dense(64) gradient then runs as a launch of its own); 0 keeps the direct kernels
+        self.winograd = _lib.knob("winograd", 7)
         self.packed_wu, self.packed_wu_t = {}, {}
         for L in self.layers:
             c = L["conv"]
@@ -172,7 +173,7 @@ class LisecNet:
                     self.packed_wu[c.name] = torch.empty(ops.winograd_packed_floats(g.KD, g.Cin, g.Cout), dtype=f32, device=dev)
                 # data gradient: kept on the direct kernel where the Dense(64) gradient of the block below rides on its tile
                 # (lisec_conv_extras.tail_w: the middle blocks) -- measured equal there, and the tail would cost a launch
-                if self.winograd & 2 and L["kind"] == "conv":
+                if (self.winograd & 2 and L["kind"] == "conv") or (self.winograd & 4 and L["kind"] == "mid"):
                     self.packed_wu_t[c.name] = torch.empty(ops.winograd_packed_floats(g.KD, g.Cout, g.Cin), dtype=f32,
                                                            device=dev)
         self.head_w = torch.empty(768, 16, dtype=f32, device=dev)
@@ -803,7 +804,8 @@ class LisecNet:
                 bn_name, C = self.bn_of[dst_name]
                 bwd, sink = (a[dst_name], self.bnstate[bn_name], True), self._bwd_sink(bn_name, C, a[dst_name].numel() // C)
                 bwd_ready[dst_name] = sink
-            if mask is not None and self.fuse_dense_bwd and self._tail_supported(c, dst_name):
+            use_w = c.name in self.packed_wu_t and fold is None
+            if mask is not None and self.fuse_dense_bwd and not use_w and self._tail_supported(c, dst_name):
                 # the Dense(64, relu) of the block BELOW (model_training.py:195) rides on this tile: its data gradient
                 # dz = (gated gradient) @ Wd^T and the statistics of the BatchNormalization under it come out of the same
                 # launch (lisec_conv_extras.tail_w); the separate Dense data-gradient launch is skipped further down
@@ -814,7 +816,7 @@ class LisecNet:
                 bwd = (a[n + ".y"], self.bnstate[cn.bn], False)
                 tail = (self.packed_t[dn.name][0], d[n + ".z"])
                 fused_dense[n] = sink
-            if c.name in self.packed_wu_t and tail is None and fold is None:
+            if use_w:
                 ops.conv_forward_winograd(self.dgeom[c.name], dy, self.packed_wu_t[c.name], d[dst_name], flags=flags,
                                           out_mask=mask, bwd=bwd, sink=sink)
             else:
