@@ -12,7 +12,7 @@ MSE+MSE loss (the reference's compile(), model_training.py:296) -> full backward
 all-reduce of the 6.49 M fp32 gradients) -> SGD-Nesterov update.  Weak scaling: one sample per GPU.
 
 Prints ONE JSON line (rank 0) with the contract fields plus
-  roofline      dominant kernel = the data gradient of the second middle Conv3D (k_igemm_halo, fp32 MFMA bound), timed
+  roofline      dominant kernel = the second middle Conv3D in its Winograd form (k_wino, fp32 MFMA bound; forward launch), timed
                 live with HIP events on the launch stream; clock and HBM traffic of that kernel come from the PMC passes
                 summarised in profiles/r03_pmc_dominant.json (tools/pmc_summary.py writes it; null when absent)
   roofline_vfe  the VFE grid writer (HBM bound)
@@ -376,36 +376,50 @@ def main():
     result = None
     if rank == 0:
         # ---- roofline of the dominant kernel, timed live on the launch stream ----------------------
-        # Since the first Conv3D runs over the VFE's compact output (csrc/field_conv.hip, ~1 GFLOP), the largest launches
-        # of the step are the second middle block's: its data gradient is the longest one on the main chain.
+        # Since the first Conv3D runs over the VFE's compact output (csrc/field_conv.hip, ~1 GFLOP), the largest contraction
+        # of the step is the second middle block's (2 * 160 000 positions * 27 taps * 64 * 64 = 35.4 GFLOP forward, the same
+        # again for each gradient).  Its forward and data gradient run in the Winograd F(2x2, 3x3) form (csrc/wino.hip, 4/9 of
+        # the multiplications); k_wino is the symbol with the most time in the step and the forward its longest launch.
         mid2 = next(L for L in net.layers if L["name"] == "mid2")
         c2, dg2 = mid2["conv"], net.dgeom[mid2["conv"].name]
         dz2, du1 = net.dact["mid2.z"], net.dact["mid1.u"]
+        flops = 2.0 * c2.M * 27 * 64 * 64
+        pmc = pmc_dominant()
+        pmc_src = "PMC passes of this file: " + pmc.get("source", "profiles/r*_pmc_dominant.json absent")
 
-        def run_mid2_dgrad():
+        def run_mid2_dgrad_direct():
             # TAG_ROOFLINE: one un-sliced launch under its own symbol (k_igemm_halo<1,false,1,2,64,false>), so the row of that
             # symbol in the rocprofv3 --stats summary of this command is this layer alone
             ops.conv_forward(dg2, dz2, net.packed_t[c2.name][0], du1, flags=ops.TAG_ROOFLINE)
-        ms = event_time_ms(run_mid2_dgrad, 20)
-        pmc = pmc_dominant()
-        pmc_src = "PMC passes of this file: " + pmc.get("source", "profiles/r*_pmc_dominant.json absent")
-        # algorithmic FLOPs: 2 * output positions of the layer * 27 taps * 64 * 64 -- every (position, tap)
-        # pair of the forward contraction is one pair of its transpose; the kernel runs exactly those (depth taps that
-        # fall outside are skipped per tile), so executed == algorithmic here
-        flops = 2.0 * c2.M * 27 * 64 * 64
-        tf = flops / (ms * 1e-3) / 1e12
-        roofline = dict(bound="mfma", kernel="k_igemm_halo<1,false,1,2,64,false> mid2 Conv3D 64->64 k3 s1 data gradient", achieved=tf,
-                        peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s", frac=tf / PEAK_F32_MFMA_TFLOPS,
-                        frac_executed=tf / PEAK_F32_MFMA_TFLOPS, executed_share=1.0,
-                        clock_ghz=pmc.get("clock_ghz"), clock_note="GRBM_GUI_ACTIVE/8/duration, " + pmc_src,
-                        traffic=pmc.get("traffic_bytes"), traffic_unit="bytes/launch, " + pmc_src,
-                        mfma_busy=pmc.get("mfma_busy"),
-                        us_per_launch=ms * 1e3, flops_per_launch=flops,
-                        # the same launch INSIDE the step, beside the weight gradients of the second stream (kernel trace of
-                        # this command, tools/profile_round.sh): what the step pays, next to what the kernel takes alone
-                        in_step_us=pmc.get("in_step_us"),
-                        in_step_frac=(flops / (pmc["in_step_us"] * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS
-                                      if pmc.get("in_step_us") else None))
+        ms_direct = event_time_ms(run_mid2_dgrad_direct, 20)
+        if c2.name in net.packed_wu:
+            def run_mid2_forward_winograd():
+                # TAG_ROOFLINE: the same kernel under the symbol k_wino<false,0,1>
+                ops.conv_forward_winograd(c2.g, net.act["mid1.u"], net.packed_wu[c2.name], net.act["mid2.y"],
+                                          bias=net.params.view(c2.bias), flags=ops.TAG_ROOFLINE)
+            ms = event_time_ms(run_mid2_forward_winograd, 20)
+            tf = flops / (ms * 1e-3) / 1e12
+            # algorithmic FLOPs = the contraction's own (every (position, tap, channel pair) once); the Winograd
+            # form EXECUTES 16 / 36 of them as MFMA work on 650 blocks of 64 tiles (40 000 tiles padded to 41 600)
+            share = (16.0 / 36.0) * (650.0 * 64.0 / (c2.M / 4.0))
+            roofline = dict(bound="mfma", kernel="k_wino<false,0,1> mid2 Conv3D 64->64 k3 s1 forward, Winograd F(2x2,3x3) form",
+                            achieved=tf, peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s", frac=tf / PEAK_F32_MFMA_TFLOPS,
+                            frac_executed=tf * share / PEAK_F32_MFMA_TFLOPS, executed_share=share,
+                            note="achieved = algorithmic FLOPs of the contraction / time; the kernel executes executed_share of "
+                                 "them on the matrix cores (frac_executed = that work against the same peak)",
+                            clock_ghz=pmc.get("clock_ghz"), clock_note="GRBM_GUI_ACTIVE/8/duration, " + pmc_src,
+                            traffic=pmc.get("traffic_bytes"), traffic_unit="bytes/launch, " + pmc_src,
+                            mfma_busy=pmc.get("mfma_busy"),
+                            us_per_launch=ms * 1e3, flops_per_launch=flops,
+                            in_step_us=pmc.get("in_step_us"),
+                            in_step_frac=(flops / (pmc["in_step_us"] * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS
+                                          if pmc.get("in_step_us") else None))
+        else:                                        # LISEC_TUNING=winograd=0: the direct data gradient is the dominant launch
+            tf = flops / (ms_direct * 1e-3) / 1e12
+            roofline = dict(bound="mfma", kernel="k_igemm_halo<1,false,1,2,64,false> mid2 Conv3D 64->64 k3 s1 data gradient", achieved=tf,
+                            peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s", frac=tf / PEAK_F32_MFMA_TFLOPS,
+                            frac_executed=tf / PEAK_F32_MFMA_TFLOPS, executed_share=1.0,
+                            clock_ghz=None, traffic=None, us_per_launch=ms_direct * 1e3, flops_per_launch=flops)
         # the other large contractions, same clock: mid2 forward, and the dense form of the first Conv3D (the dominant
         # kernel of rounds 1-2; sweeps beyond LISEC_FIELD_MAX_VOXELS still take it)
         grid = net.dense_grid()
@@ -421,8 +435,13 @@ def main():
                                                                 bias=net.params.view(c1.bias)), 20)
         f1 = 2.0 * c1.M * 27 * 64 * 64
         roofline["others"] = {
-            "mid2_forward": dict(us_per_launch=ms_f2 * 1e3, achieved=flops / (ms_f2 * 1e-3) / 1e12,
-                                 frac=flops / (ms_f2 * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, flops_per_launch=flops),
+            "mid2_data_gradient_direct": dict(kernel="k_igemm_halo<1,false,1,2,64,false>", us_per_launch=ms_direct * 1e3,
+                                              achieved=flops / (ms_direct * 1e-3) / 1e12,
+                                              frac=flops / (ms_direct * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, flops_per_launch=flops,
+                                              note="the direct (implicit-GEMM) form of the same contraction's data gradient: the "
+                                                   "dominant launch of rounds 3-4a, executed == algorithmic"),
+            "mid2_forward_direct": dict(us_per_launch=ms_f2 * 1e3, achieved=flops / (ms_f2 * 1e-3) / 1e12,
+                                        frac=flops / (ms_f2 * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, flops_per_launch=flops),
             "mid1_dense_form": dict(us_per_launch=ms_f1 * 1e3, achieved=f1 / (ms_f1 * 1e-3) / 1e12,
                                     frac=f1 / (ms_f1 * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, flops_per_launch=f1),
             "mid1_field_form": dict(us_per_call=ms_field * 1e3, launches=2,

@@ -197,8 +197,9 @@ typedef struct {
 #define LISEC_CONV_IN_RELU 1     /* apply ReLU to the gathered input (after the optional affine)        */
 #define LISEC_CONV_OUT_RELU 2    /* apply ReLU before the store (Dense(..., 'relu'), :195)              */
 #define LISEC_CONV_ACCUMULATE 4  /* out += result (gradient fan-in)                                     */
-#define LISEC_CONV_TAG_ROOFLINE 32 /* measurement aid: one un-sliced launch under the symbol k_igemm<0,false,1>,
-                                     so a rocprofv3 --stats row shows this layer alone (bench.py roofline)       */
+#define LISEC_CONV_TAG_ROOFLINE 32 /* measurement aid: one un-sliced launch under the symbol k_igemm<0,false,1>
+                                     (lisec_conv_forward_winograd: k_wino<false,0,1>), so a rocprofv3 --stats row
+                                     shows this layer alone (bench.py roofline)                                    */
 #define LISEC_CONV_DY_RELU 8     /* wgrad only: ReLU on the (optionally affine-transformed) dy operand     */
 
 /* Packed weight layout the kernels read: [tap][K/4][N][4] fp32, K and N zero padded to 64.

@@ -60,7 +60,9 @@ __device__ unsigned long long* g_wino_stamps = nullptr;
 
 // EXP: timing-only variants (wrong results; tools/wino_stamps.py): 1 = no side work in the K loop, 2 = no global loads in it,
 // 3 = no LDS stores in it, 4 = no MFMAs in the helper waves, 5 = no MFMAs in the staging waves
-template <bool XF, int EXP = 0>
+// TAG only changes the symbol name: bench.py launches the second middle block's forward through k_wino<false, 0, 1> so that
+// its row in a rocprofv3 --stats summary is that layer alone (same code as TAG 0).
+template <bool XF, int EXP = 0, int TAG = 0>
 __global__ void __launch_bounds__(kWinoThreads) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_wino(ConvGeom g, int mode, const float* __restrict__ in, const float* __restrict__ U,
        const float* __restrict__ bias, const float* __restrict__ in_bn, int flags, float* __restrict__ out,
@@ -520,7 +522,7 @@ bool wino_ok(const lisec_conv_geom* c, const ConvGeom& g, bool has_in_bn, int fl
     LISEC_WINO_NEED(!c->ps, "no pixel-shuffle store");
     LISEC_WINO_NEED(c->Cin % 16 == 0 && c->in_stride % 4 == 0, "Cin % 16 == 0 and in_stride % 4 == 0");
     LISEC_WINO_NEED(has_in_bn || !(flags & LISEC_CONV_IN_RELU), "LISEC_CONV_IN_RELU needs in_bnstate");
-    LISEC_WINO_NEED(!(flags & LISEC_CONV_TAG_ROOFLINE), "no roofline tag");
+    LISEC_WINO_NEED(!(flags & LISEC_CONV_TAG_ROOFLINE) || !has_in_bn, "the roofline tag only without in_bnstate");
     if (ex) {
         LISEC_WINO_NEED(!ex->tail_w && !ex->in_y && !ex->queue, "no tail contraction, no backward on load, no row queue");
         LISEC_WINO_NEED(!ex->bwd_y || (ex->bwd_bnstate && ex->sink && ex->sink->kind == LISEC_SINK_BACKWARD),
@@ -621,6 +623,8 @@ extern "C" int lisec_conv_forward_winograd(const lisec_conv_geom* c, const float
         else if (exp == 3) LISEC_WINO_GO(false, 3);
         else if (exp == 4) LISEC_WINO_GO(false, 4);
         else if (exp == 5) LISEC_WINO_GO(false, 5);
+        else if (flags & LISEC_CONV_TAG_ROOFLINE)
+            LISEC_LAUNCH((k_wino<false, 0, 1>), grid, dim3(kWinoThreads), kWinoLds, st, g, c->mode, in, wino_w, bias, in_bnstate, flags, out, BH, BW, plane_list);
         else if (in_bnstate) LISEC_WINO_GO(true, 0);
         else LISEC_WINO_GO(false, 0);
     }

@@ -2,8 +2,8 @@
 mean counter value and duration over its last launches.
 usage: python tools/pmc_summary.py <dir> [<dir> ...]
        python tools/pmc_summary.py --dominant profiles/r03_pmc_dominant.json <dir> [<dir> ...]
-The second form also writes what bench.py quotes in its `roofline` object for the dominant kernel (the mid2 data gradient
-on its own symbol): traffic_bytes = FETCH_SIZE x 2 (the gfx950 correction for wide coalesced reads, MI355X guide) +
+The second form also writes what bench.py quotes in its `roofline` object for the dominant kernel (the mid2 forward in the
+Winograd form on its own symbol): traffic_bytes = FETCH_SIZE x 2 (the gfx950 correction for wide coalesced reads, MI355X guide) +
 WRITE_SIZE, in bytes per launch; clock_ghz = GRBM_GUI_ACTIVE / 8 XCDs / duration; mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES /
 (clock x duration x 1024 SIMDs)."""
 import csv
@@ -12,8 +12,9 @@ import os
 import sys
 from collections import defaultdict
 
-DOMINANT = "mid2 Conv3D data gradient (roofline launch)"
-KEYS = {"k_igemm_halo<1, false, 1, 2": DOMINANT, "k_wgrad_halo<false, 7>": "mid wgrad (halo)", "k_field_taps": "field conv: taps",
+DOMINANT = "mid2 Conv3D forward, Winograd form (roofline launch)"
+KEYS = {"k_wino<false, 0, 1>": DOMINANT, "k_igemm_halo<1, false, 1, 2": "mid2 Conv3D data gradient, direct form (roofline launch)",
+        "k_wino<false, 0, 0>": "Winograd contractions without on-load BN (mid blocks, data gradients)", "k_wino<true, 0, 0>": "Winograd contractions with on-load BN (rpn1 forward)", "k_wgrad_halo<false, 7>": "mid wgrad (halo)", "k_field_taps": "field conv: taps",
         "k_field_combine": "field conv: combine", "k_igemm_halo<0, false, 1, 2>": "mid1 Conv3D fwd (roofline launch)", "k_vfe_grid": "VFE grid writer",
         "k_vfe_stage<2": "VFE layers 1+2", "k_vfe_stage<3": "VFE layer 3", "k_wgrad_halo<false>": "mid wgrad (halo)",
         "k_wgrad_ring<false, 5>": "mid wgrad (ring)", "k_wgrad_ring_batch<true, 5>": "rpn1/rpn2 batched wgrad (ring)",
@@ -54,7 +55,7 @@ for d in args:
                         vfe[c] = sum(big) / len(big)
 if dominant_out:
     import json
-    out = {"kernel": "k_igemm_halo<1,false,1,2,64,false> (mid2 Conv3D data gradient, bench.py's roofline launch)",
+    out = {"kernel": "k_wino<false,0,1> (mid2 Conv3D forward in the Winograd form, bench.py's roofline launch)",
            "source": "rocprofv3 --pmc passes of `python bench.py --steps 3 --warmup 2 --no-cpu-baseline`, one counter set per pass "
                      "(tools/profile_round.sh), summarised by tools/pmc_summary.py"}
     if "FETCH_SIZE" in dom and "WRITE_SIZE" in dom:
@@ -78,8 +79,8 @@ if dominant_out:
         best = None
         for ln in open(tl):
             f = ln.split()
-            if "k_igemm_halo<1, false, 0, 2, 64" in ln and ln.rstrip().endswith("1250"):
-                best = max(best or 0.0, float(f[1]))
+            if best is None and "k_wino<false, 0, 0>" in ln and ln.rstrip().endswith("650"):   # mid2 forward: the step's first 650-block launch
+                best = float(f[1])
         if best:
             out["in_step_us"] = best
     json.dump(out, open(dominant_out, "w"), indent=1)
