@@ -32,6 +32,7 @@ namespace lisec {
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kWinoThreads = 512;
 constexpr int WT = 64;                      // Winograd tiles per workgroup (8 x 8)
@@ -119,7 +120,8 @@ k_wino(ConvGeom g, int mode, const float* __restrict__ in, const float* __restri
     // cache lines per wave instruction, every position fetched by up to four tiles: the loop was bound by the address unit,
     // ~1500 of 6200 cycles per chunk.)
     float* sR = smem + 2 * STAGE_FLOATS;
-    int rg_off[R_ITEMS];
+    unsigned rg_off[R_ITEMS];                        // BYTE offsets inside one plane (< 2^32: checked by the host), so that the
+                                                     // loads take the scalar-base + 32-bit lane offset form (no 64-bit lane addresses)
 #pragma unroll
     for (int r = 0; r < R_ITEMS; ++r) {
         int item = tid + 256 * r;
@@ -129,7 +131,7 @@ k_wino(ConvGeom g, int mode, const float* __restrict__ in, const float* __restri
         int y = 16 * by - 1 + py, x = 16 * bx - 1 + px;
         y = y < 0 ? 0 : (y > H - 1 ? H - 1 : y);                 // positions outside the map read a valid address: the
         x = x < 0 ? 0 : (x > W - 1 ? W - 1 : x);                 // transform gates them to zero (pmask)
-        rg_off[r] = (flags & 0x1000) ? 0 : (y * W + x) * g.in_stride + quad * 4;
+        rg_off[r] = (flags & 0x1000) ? 0u : (unsigned)((y * W + x) * g.in_stride + quad * 4) * 4u;
     }
     // LDS offset of item tid + 256 r: (position) * R_STRIDE + quad * 4 = rl0 + 64 R_STRIDE r; the last round is partial
     const int rl0 = (tid >> 2) * R_STRIDE + (tid & 3) * 4;
@@ -166,15 +168,22 @@ k_wino(ConvGeom g, int mode, const float* __restrict__ in, const float* __restri
         const int sd = src_coord(dplane, w_kd, g.ls_d, g.pd, g.Di, mode, dok);
         return in + (size_t)sd * plane_floats + w_cc * WK;
     };
-#define WINO_R_LD(R_, I_) R_ = *reinterpret_cast<const float4*>(wsrc + rg_off[I_])
+#define WINO_R_LD(R_, I_) { const u32x4 w_ = __builtin_amdgcn_raw_buffer_load_b128(wrs, rg_off[I_], 0, 0); \
+                           R_ = make_float4(__uint_as_float(w_.x), __uint_as_float(w_.y), __uint_as_float(w_.z), __uint_as_float(w_.w)); }
 #define WINO_R_ST(R_, I_) *reinterpret_cast<float4*>(sR + ((I_) < 5 ? rl0 + (I_) * 64 * R_STRIDE : rl5)) = R_
-#define WINO_U_LD4(Q_) { ub0 = *reinterpret_cast<const float4*>(us + ((Q_) + 0) * 1024); ub1 = *reinterpret_cast<const float4*>(us + ((Q_) + 1) * 1024); \
-                         ub2 = *reinterpret_cast<const float4*>(us + ((Q_) + 2) * 1024); ub3 = *reinterpret_cast<const float4*>(us + ((Q_) + 3) * 1024); }
+#define WINO_U_LD1(R_, Q_) { const u32x4 u_ = __builtin_amdgcn_raw_buffer_load_b128(urs, tid * 16, (Q_) * 4096, 0); \
+                             R_ = make_float4(__uint_as_float(u_.x), __uint_as_float(u_.y), __uint_as_float(u_.z), __uint_as_float(u_.w)); }
+#define WINO_U_LD4(Q_) { WINO_U_LD1(ub0, (Q_) + 0) WINO_U_LD1(ub1, (Q_) + 1) WINO_U_LD1(ub2, (Q_) + 2) WINO_U_LD1(ub3, (Q_) + 3) }
 #define WINO_U_ST2(A_, B_, Q_) { *reinterpret_cast<float4*>(up + (Q_) * 1024) = A_; *reinterpret_cast<float4*>(up + ((Q_) + 1) * 1024) = B_; }
-    auto load_x = [&](float2& sc, float2& sh, int xc) {      // on-load constants of channel chunk xc
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(XF ? in_bn : in), 0,
+                                                                         XF ? 8 * g.Cin : 0, 0x00020000);
+    auto load_x = [&](float2& sc, float2& sh, int xc) {      // on-load constants of channel chunk xc (scalar base + lane offset)
         if (XF) {
-            sc = *reinterpret_cast<const float2*>(in_bn + xc * WK + cp * 2);
-            sh = *reinterpret_cast<const float2*>(in_bn + g.Cin + xc * WK + cp * 2);
+            const u32x2 a_ = __builtin_amdgcn_raw_buffer_load_b64(xrs, cp * 8, xc * (WK * 4), 0);
+            const u32x2 b_ = __builtin_amdgcn_raw_buffer_load_b64(xrs, cp * 8, (g.Cin + xc * WK) * 4, 0);
+            sc = make_float2(__uint_as_float(a_.x), __uint_as_float(a_.y));
+            sh = make_float2(__uint_as_float(b_.x), __uint_as_float(b_.y));
         }
     };
 
@@ -196,11 +205,12 @@ k_wino(ConvGeom g, int mode, const float* __restrict__ in, const float* __restri
                 d[4 * i + j] = *reinterpret_cast<const float2*>(sR + rsrc + (i * 18 + j) * R_STRIDE + ch_half * WK);
     };
     // gate (+ BatchNormalization, ReLU) of patch row i, in place
-    auto gate_row = [&](int i, const float2& sc, const float2& sh) {
+    // (gate = false: a block whose whole window lies inside the map -- most of them -- has nothing to gate)
+    auto gate_row = [&](int i, const float2& sc, const float2& sh, bool gate) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int e = 4 * i + j;
-            const bool ok = (pmask >> e) & 1;
+            const bool ok = !gate || ((pmask >> e) & 1);
             float2 v = d[e];
             if (XF) {
                 v.x = fmaxf(fmaf(v.x, sc.x, sh.x), relu_lo);
@@ -210,6 +220,8 @@ k_wino(ConvGeom g, int mode, const float* __restrict__ in, const float* __restri
             d[e].y = ok ? v.y : 0.f;
         }
     };
+    // the block's 18 x 18 window lies inside the map (wave-uniform)
+    const bool interior = 16 * by >= 1 && 16 * by + 16 <= H - 1 && 16 * bx >= 1 && 16 * bx + 16 <= W - 1;
     auto bt_col = [&](int j) {                       // B^T d, column j
         t[0 + j].x = d[0 + j].x - d[8 + j].x;   t[0 + j].y = d[0 + j].y - d[8 + j].y;
         t[4 + j].x = d[4 + j].x + d[8 + j].x;   t[4 + j].y = d[4 + j].y + d[8 + j].y;
@@ -236,6 +248,7 @@ k_wino(ConvGeom g, int mode, const float* __restrict__ in, const float* __restri
         // window of group 0 -> LDS, image of chunk 0 -> stage 0 (the loop then prepares chunk c + 1 inside chunk c)
         if (half == 0) {
             const float* wsrc = window_src();
+            const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wsrc), 0, 0x7fffffff, 0x00020000);
             WINO_R_LD(rw0, 0); WINO_R_LD(rw1, 1); WINO_R_LD(rw2, 2);
             WINO_R_ST(rw0, 0); WINO_R_ST(rw1, 1); WINO_R_ST(rw2, 2);
             WINO_R_LD(rw0, 3); WINO_R_LD(rw1, 4); WINO_R_LD(rw2, 5);
@@ -245,13 +258,14 @@ k_wino(ConvGeom g, int mode, const float* __restrict__ in, const float* __restri
         }
         __syncthreads();
         if (half == 0) {
-            const float* us = U + ((size_t)(u_kd * ncc + u_cc) * nnb + nb) * u_chunk + tid * 4;
+            const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(U + ((size_t)(u_kd * ncc + u_cc) * nnb + nb) * u_chunk), 0, 16 * WN * WK * 4, 0x00020000);
             float* up = smem + V_FLOATS + tid * 4;
             WINO_U_LD4(0)
             read_rows(0, 0);
             read_rows(2, 0);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) gate_row(i, tsc, tsh);
+            for (int i = 0; i < 4; ++i) gate_row(i, tsc, tsh, true);
 #pragma unroll
             for (int j = 0; j < 4; ++j) bt_col(j);
 #pragma unroll
@@ -281,7 +295,7 @@ k_wino(ConvGeom g, int mode, const float* __restrict__ in, const float* __restri
     //            is single: an even chunk reads its second half (p 0-1), ALL waves meet at a barrier after group 3 (p 7), and
     //            only then is it overwritten; the odd chunk that follows reads the new window after the barrier that ends
     //            the even one
-    //   p 2-5    gate (+ BatchNormalization, ReLU) of patch row i;  p 3  the on-load constants of chunk c + 2
+    //   p 2-5    gate (+ BatchNormalization, ReLU) of patch row i;  p 6  the on-load constants of chunk c + 2
     //   p 6-9    B^T d (column j)
     //   p 10-13  (B^T d) B (row i) and its four 8-byte stores into the other stage
 #define WINO_MFMA4(P_)                                                                                   \
@@ -291,18 +305,19 @@ k_wino(ConvGeom g, int mode, const float* __restrict__ in, const float* __restri
     acc[P_] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b0.w, acc[P_], 0, 0, 0);
     auto chunk = [&](auto par_tag, auto stager_tag) {
         constexpr int PAR = decltype(par_tag)::value;
-        constexpr bool STAGER = decltype(stager_tag)::value != 0;
+        constexpr bool STAGER = (decltype(stager_tag)::value & 1) != 0, GATE = (decltype(stager_tag)::value & 2) != 0;
         const float* st = smem + PAR * STAGE_FLOATS;
         float* nx = smem + (PAR ^ 1) * STAGE_FLOATS;
         const float* ap = st + aoff;
         const float* bp = st + boff;
         float4 a0 = *reinterpret_cast<const float4*>(ap);
         float4 b0 = *reinterpret_cast<const float4*>(bp);
-        const float* us = U + ((size_t)(u_kd * ncc + u_cc) * nnb + nb) * u_chunk + tid * 4;
+        const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(U + ((size_t)(u_kd * ncc + u_cc) * nnb + nb) * u_chunk), 0, 16 * WN * WK * 4, 0x00020000);
         float* up = nx + V_FLOATS + tid * 4;
         const float* wsrc = STAGER ? window_src() : in;
-        const float2 sc = tsc, sh = tsh;             // chunk c + 1's
-        float2 scn = sc, shn = sh;
+        // (a buffer descriptor over the plane: scalar base + one 32-bit lane offset per load, no 64-bit lane addresses)
+        const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wsrc), 0, 0x7fffffff, 0x00020000);
         const int x_next = (u_left > 0) ? (u_cc + 1 == ncc ? 0 : u_cc + 1) : u_cc;      // channel chunk of chunk c + 2
         float* vp = nx + vdst;
 #pragma unroll
@@ -324,8 +339,8 @@ k_wino(ConvGeom g, int mode, const float* __restrict__ in, const float* __restri
                         if (p == 9) { WINO_R_LD(rw0, 3); WINO_R_LD(rw1, 4); WINO_R_LD(rw2, 5); }
                         if (p == 15) { WINO_R_ST(rw0, 3); WINO_R_ST(rw1, 4); WINO_R_ST(rw2, 5); }
                     }
-                    if (p >= 2 && p < 6) gate_row(p - 2, sc, sh);
-                    if (p == 3) load_x(scn, shn, x_next);
+                    if (p >= 2 && p < 6) gate_row(p - 2, tsc, tsh, GATE);       // (chunk c + 1's constants)
+                    if (p == 6) load_x(tsc, tsh, x_next);                       // chunk c + 2's, once the gate is through
                     if (p >= 6 && p < 10) bt_col(p - 6);
                     if (p >= 10 && p < 14) b_row(p - 10, vp, true);
                     if (p == 6) WINO_U_ST2(ub0, ub1, 0)
@@ -352,14 +367,18 @@ k_wino(ConvGeom g, int mode, const float* __restrict__ in, const float* __restri
         if (STAGER) {
             advance(u_kd, u_cc, u_left, 1);
             if (PAR == 0) advance(w_kd, w_cc, w_left, 2);
-            tsc = scn; tsh = shn;
         }
         __syncthreads();
     };
-    if (half == 0) {
+    if (half == 0 && interior) {
         for (int c = 0; c < nchunks; c += 2) {
             chunk(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
             chunk(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+        }
+    } else if (half == 0) {
+        for (int c = 0; c < nchunks; c += 2) {
+            chunk(std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{});
+            chunk(std::integral_constant<int, 1>{}, std::integral_constant<int, 3>{});
         }
     } else {
         for (int c = 0; c < nchunks; c += 2) {
@@ -371,6 +390,7 @@ k_wino(ConvGeom g, int mode, const float* __restrict__ in, const float* __restri
 #undef WINO_R_LD
 #undef WINO_R_ST
 #undef WINO_U_LD4
+#undef WINO_U_LD1
 #undef WINO_U_ST2
 
     WINO_STAMP(2, __builtin_amdgcn_s_memrealtime());
@@ -417,7 +437,9 @@ k_wino(ConvGeom g, int mode, const float* __restrict__ in, const float* __restri
     }
     __syncthreads();
     float sum = 0.f, sq = 0.f;
-    {
+    // (full: every one of the block's 16 x 16 outputs and 64 channels exists -- no per-store predicate)
+    auto store_lines = [&](auto full_tag) {
+        constexpr bool full = decltype(full_tag)::value;
         const float* take = smem + half * 8192 + ((wave & 3) * 32) * 64 + lane_e;
         const int a2 = half;
 #pragma unroll
@@ -434,7 +456,7 @@ k_wino(ConvGeom g, int mode, const float* __restrict__ in, const float* __restri
             for (int b2 = 0; b2 < 2; ++b2) {
                 const int dx = 2 * (r & 3) + b2;
                 const float part = take[(2 * r + b2) * 64], mine = b2 ? k1 : k0;
-                if (y < H && xt + dx < W && nok) {
+                if (full || (y < H && xt + dx < W && nok)) {
                     const unsigned off = xo + (unsigned)(dx * g.out_stride);
                     float v = (half == 0 ? mine + part : part + mine) + bv;       // (rows 0-1 of M first: one order)
                     if (accum) v += oline[off];
@@ -451,7 +473,9 @@ k_wino(ConvGeom g, int mode, const float* __restrict__ in, const float* __restri
                 }
             }
         }
-    }
+    };
+    if (16 * by + 16 <= H && 16 * bx + 16 <= W && nb * WN + WN <= g.Cout) store_lines(std::true_type{});
+    else store_lines(std::false_type{});
     WINO_STAMP(3, __builtin_amdgcn_s_memrealtime());
     if (g.sink.acc) {
         __syncthreads();                             // (the exchange is over: the scratch below reuses its space)
@@ -521,6 +545,7 @@ bool wino_ok(const lisec_conv_geom* c, const ConvGeom& g, bool has_in_bn, int fl
     LISEC_WINO_NEED(c->Hi == c->Ho && c->Wi == c->Wo && c->Ho >= 2 && c->Wo >= 2, "equal input and output maps of at least 2 x 2");
     LISEC_WINO_NEED(!c->ps, "no pixel-shuffle store");
     LISEC_WINO_NEED(c->Cin % 16 == 0 && c->in_stride % 4 == 0, "Cin % 16 == 0 and in_stride % 4 == 0");
+    LISEC_WINO_NEED((long long)c->Hi * c->Wi * c->in_stride < (1LL << 29), "one plane of the gathered tensor below 2 GB");
     LISEC_WINO_NEED(has_in_bn || !(flags & LISEC_CONV_IN_RELU), "LISEC_CONV_IN_RELU needs in_bnstate");
     LISEC_WINO_NEED(!(flags & LISEC_CONV_TAG_ROOFLINE) || !has_in_bn, "the roofline tag only without in_bnstate");
     if (ex) {
