@@ -358,7 +358,7 @@ int lisec_conv_forward(const lisec_conv_geom* g, const float* in, const float* p
  * (model_training.py:193, 237-238), the stride-1 Conv2Ds of the RPN (:210-214) and the data gradients of both.  Same
  * arithmetic contract as lisec_conv_forward_ex -- fp32 operands, fp32 accumulation, in_bnstate / LISEC_CONV_IN_RELU applied
  * on load with exact zero padding, bias, LISEC_CONV_ACCUMULATE / LISEC_CONV_OUT_RELU, extras.out_mask, extras.bwd_y +
- * a LISEC_SINK_BACKWARD sink, or a LISEC_SINK_FORWARD sink -- with 4 / 9 of the multiplications: a 2 x 2 block of outputs is
+ * a LISEC_SINK_BACKWARD sink, or a LISEC_SINK_FORWARD sink, extras.tail_w / tail_out (Cout = out_stride = 64) -- with 4 / 9 of the multiplications: a 2 x 2 block of outputs is
  * A^T [ sum_c (G g G^T) . (B^T d B) ] A.  Results differ from lisec_conv_forward_ex by fp32 rounding only (the transforms add
  * and halve exactly representable values; tests/test_gpu_winograd.py holds both against the fp64 oracle).
  *   lisec_conv_pack_weights_winograd: G g G^T of every (depth tap, k, n) kernel slice, in the LDS image order of the kernel.

@@ -437,6 +437,11 @@ k_wino(ConvGeom g, int mode, const float* __restrict__ in, const float* __restri
     }
     __syncthreads();
     float sum = 0.f, sq = 0.f;
+    // optional second contraction on the stored tile (lisec_conv_extras.tail_w, as in k_igemm_halo<..., TAIL>): the gated
+    // 16 x 16 x 64 block also goes to LDS ([256 positions][LDT], behind the exchange scratch) as the tail's A operand
+    const bool tail = g.tail_w != nullptr;
+    constexpr int LDT = 68;
+    float* tT = smem + 16384;
     // (full: every one of the block's 16 x 16 outputs and 64 channels exists -- no per-store predicate)
     auto store_lines = [&](auto full_tag) {
         constexpr bool full = decltype(full_tag)::value;
@@ -449,7 +454,7 @@ k_wino(ConvGeom g, int mode, const float* __restrict__ in, const float* __restri
             const size_t line = ((size_t)dplane * H + y) * W;
             float* oline = out + line * g.out_stride;
             const float* mline = g.out_mask ? g.out_mask + line * g.out_stride : nullptr;
-            const float* yline = g.bwd_y ? g.bwd_y + line * g.Cout : nullptr;
+            const float* yline = (g.bwd_y && !tail) ? g.bwd_y + line * g.Cout : nullptr;
             float k0, k1;
             share(r, a2, k0, k1);
 #pragma unroll
@@ -463,21 +468,94 @@ k_wino(ConvGeom g, int mode, const float* __restrict__ in, const float* __restri
                     if (mline && !(mline[off] > 0.f)) v = 0.f;
                     if (orelu) v = fmaxf(v, 0.f);
                     oline[off] = v;
-                    if (yline) {
+                    if (tail) {
+                        tT[((2 * (wm * 4 + (r >> 2)) + a2) * 16 + 8 * hi + dx) * LDT + wn * 32 + col] = v;
+                    } else if (yline) {
                         const float yv = yline[xy + (unsigned)(dx * g.Cout)];
                         const float dv = (g.bwd_relu && !(fmaf(yv, ys, yh) > 0.f)) ? 0.f : v;
                         sum += dv; sq = fmaf(dv, (yv - ym) * yi, sq);
                     } else {
                         sum += v; sq = fmaf(v, v, sq);
                     }
+                } else if (tail) {                   // (outside the map: a zero row of the tail's operand)
+                    tT[((2 * (wm * 4 + (r >> 2)) + a2) * 16 + 8 * hi + dx) * LDT + wn * 32 + col] = 0.f;
                 }
             }
         }
     };
     if (16 * by + 16 <= H && 16 * bx + 16 <= W && nb * WN + WN <= g.Cout) store_lines(std::true_type{});
     else store_lines(std::false_type{});
+    float sumB = 0.f, sqB = 0.f;                     // (tail: statistics of its second 32 columns)
+    if (tail) {
+        // Dense(64) backward riding on the block (model_training.py:195 backwards): dz = (gated block) @ Wd^T -> tail_out, with
+        // the backward statistics of the BatchNormalization under the Dense.  Wave w owns the block's lines 2 w, 2 w + 1 (32
+        // positions) x 64 columns; the B fragments come straight from the packed 64 x 64 kernel (16 KB, L2-resident).
+        __syncthreads();
+        f32x16 t0 = {0}, t1 = {0};
+        const float* aRow = tT + (wave * 32 + (lane_e & 31)) * LDT + 4 * hi;
+        const float* bC = g.tail_w + (hi * 64 + (lane_e & 31)) * 4;
+#pragma unroll
+        for (int kc = 0; kc < 8; ++kc) {
+            const float4 a = *reinterpret_cast<const float4*>(aRow + kc * 8);
+            const float4 b0 = *reinterpret_cast<const float4*>(bC + kc * 2 * 64 * 4);
+            const float4 b1 = *reinterpret_cast<const float4*>(bC + kc * 2 * 64 * 4 + 32 * 4);
+            t0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, t0, 0, 0, 0);
+            t1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1.x, t1, 0, 0, 0);
+            t0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b0.y, t0, 0, 0, 0);
+            t1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1.y, t1, 0, 0, 0);
+            t0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b0.z, t0, 0, 0, 0);
+            t1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b1.z, t1, 0, 0, 0);
+            t0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b0.w, t0, 0, 0, 0);
+            t1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b1.w, t1, 0, 0, 0);
+        }
+        const int nA = col, nB = 32 + col;           // the tail has 64 columns, row stride 64
+        float sA = 1.f, hA = 0.f, mA = 0.f, iA = 0.f, sB = 1.f, hB = 0.f, mB = 0.f, iB = 0.f;
+        if (g.bwd_y) {
+            sA = g.bwd_bn[nA]; hA = g.bwd_bn[64 + nA]; mA = g.bwd_bn[128 + nA]; iA = g.bwd_bn[192 + nA];
+            sB = g.bwd_bn[nB]; hB = g.bwd_bn[64 + nB]; mB = g.bwd_bn[128 + nB]; iB = g.bwd_bn[192 + nB];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;         // position 32 wave + row of the block: line, column
+            const int y = 16 * by + 2 * wave + (row >> 4), x = 16 * bx + (row & 15);
+            if (y < H && x < W) {
+                const size_t pos = ((size_t)dplane * H + y) * W + x;
+                const float va = t0[r], vb = t1[r];
+                g.tail_out[pos * 64 + nA] = va;
+                g.tail_out[pos * 64 + nB] = vb;
+                if (g.bwd_y) {
+                    const float ya = g.bwd_y[pos * 64 + nA], yb = g.bwd_y[pos * 64 + nB];
+                    const float da = (g.bwd_relu && !(fmaf(ya, sA, hA) > 0.f)) ? 0.f : va;
+                    const float db = (g.bwd_relu && !(fmaf(yb, sB, hB) > 0.f)) ? 0.f : vb;
+                    sum += da; sq = fmaf(da, (ya - mA) * iA, sq);
+                    sumB += db; sqB = fmaf(db, (yb - mB) * iB, sqB);
+                } else {
+                    sum += va; sq = fmaf(va, va, sq);
+                    sumB += vb; sqB = fmaf(vb, vb, sqB);
+                }
+            }
+        }
+    }
     WINO_STAMP(3, __builtin_amdgcn_s_memrealtime());
-    if (g.sink.acc) {
+    if (g.sink.acc && tail) {
+        __syncthreads();
+        float* red = smem;                           // [8 waves][4][32]
+        sum += __shfl_xor(sum, 32, 64); sq += __shfl_xor(sq, 32, 64);
+        sumB += __shfl_xor(sumB, 32, 64); sqB += __shfl_xor(sqB, 32, 64);
+        if (lane < 32) {
+            red[(wave * 4 + 0) * 32 + lane] = sum; red[(wave * 4 + 1) * 32 + lane] = sq;
+            red[(wave * 4 + 2) * 32 + lane] = sumB; red[(wave * 4 + 3) * 32 + lane] = sqB;
+        }
+        __syncthreads();
+        if (threadIdx.x < 128) {
+            const int q = threadIdx.x >> 5, c = threadIdx.x & 31;    // q: 0 sumA, 1 sqA, 2 sumB, 3 sqB
+            double v = 0.0;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) v += (double)red[(w * 4 + q) * 32 + c];
+            sink_add(g.sink, q & 1, (q >> 1) * 32 + c, v);
+        }
+        sink_finish(g.sink);
+    } else if (g.sink.acc) {
         __syncthreads();                             // (the exchange is over: the scratch below reuses its space)
         float* red = smem;                           // [8 waves][2][32]
         sum += __shfl_xor(sum, 32, 64); sq += __shfl_xor(sq, 32, 64);
@@ -549,7 +627,11 @@ bool wino_ok(const lisec_conv_geom* c, const ConvGeom& g, bool has_in_bn, int fl
     LISEC_WINO_NEED(has_in_bn || !(flags & LISEC_CONV_IN_RELU), "LISEC_CONV_IN_RELU needs in_bnstate");
     LISEC_WINO_NEED(!(flags & LISEC_CONV_TAG_ROOFLINE) || !has_in_bn, "the roofline tag only without in_bnstate");
     if (ex) {
-        LISEC_WINO_NEED(!ex->tail_w && !ex->in_y && !ex->queue, "no tail contraction, no backward on load, no row queue");
+        LISEC_WINO_NEED(!ex->in_y && !ex->queue, "no backward on load, no row queue");
+        LISEC_WINO_NEED(!ex->tail_w || (ex->tail_out && c->Cout == 64 && c->out_stride == 64 &&
+                                        !(flags & (LISEC_CONV_ACCUMULATE | LISEC_CONV_OUT_RELU)) && (!ex->bwd_y || ex->sink) &&
+                                        ((uintptr_t)ex->tail_w & 15) == 0),
+                        "tail: a packed 64 x 64 kernel and an output, Cout = out_stride = 64, no accumulate / ReLU, statistics through a sink");
         LISEC_WINO_NEED(!ex->bwd_y || (ex->bwd_bnstate && ex->sink && ex->sink->kind == LISEC_SINK_BACKWARD),
                         "backward statistics go through a backward sink");
         LISEC_WINO_NEED(!ex->sink || ex->sink->kind == LISEC_SINK_BACKWARD || !ex->bwd_y, "a forward sink excludes bwd_y");
@@ -607,6 +689,7 @@ extern "C" int lisec_conv_forward_winograd(const lisec_conv_geom* c, const float
     const int nnb = (int)(align_up(g.Cout, WN) / WN);
     if (extras) {
         g.out_mask = extras->out_mask;
+        if (extras->tail_w) { g.tail_w = extras->tail_w; g.tail_out = extras->tail_out; }
         if (extras->bwd_y) { g.bwd_y = extras->bwd_y; g.bwd_bn = extras->bwd_bnstate; g.bwd_relu = extras->bwd_relu ? 1 : 0; }
         if (const lisec_bn_sink* sk = extras->sink) {
             LISEC_CHECK_ARG(sk->acc && sk->n_rows > 0, "bn sink: accumulators and a row count");

@@ -651,10 +651,25 @@ class LisecNet:
             self._fold_ok[c.name] = ok
         return ok
 
-    def _tail_supported(self, c, dst_name):
+    def _tail_supported(self, c, dst_name, winograd=False):
         """Can the Dense data gradient of block dst_name[:-2] ride on the data gradient of conv `c`?  (asked of the library
-        once per layer: lisec_conv_plan_query refuses geometries the two-line w-halo kernel does not serve)"""
-        ok = self._tail_ok.get(c.name)
+        once per layer: lisec_conv_plan_query refuses geometries the two-line w-halo kernel does not serve;
+        lisec_conv_winograd_supported answers for the Winograd form)"""
+        ok = self._tail_ok.get((c.name, winograd))
+        if ok is None and winograd:
+            # (LISEC_TUNING winograd_tail: the tail on the Winograd epilogue is built and parity-tested
+            # (tests/test_gpu_winograd.py) and measured 0.5 % SLOWER in the step than the separate HBM-bound Dense launch,
+            # which hides beside the MFMA-bound weight gradients of the second stream: off)
+            n = dst_name[:-2]
+            Ln = {L["name"]: L for L in self.layers}.get(n)
+            ok = False
+            if Ln is not None and "dense" in Ln and self.dgeom[c.name].Cout == 64 and _lib.knob("winograd_tail", False):
+                cn, dn = Ln["conv"], Ln["dense"]
+                ok = ops.winograd_supported(self.dgeom[c.name], out_mask=self.act[dst_name],
+                                            bwd=(self.act[n + ".y"], self.bnstate[cn.bn], False),
+                                            sink=self._bwd_sink(cn.bn, 64, cn.M),
+                                            tail=(self.packed_t[dn.name][0], self.dact[n + ".z"]))
+            self._tail_ok[(c.name, winograd)] = ok
         if ok is None:
             n = dst_name[:-2]
             Ln = {L["name"]: L for L in self.layers}.get(n)
@@ -668,7 +683,7 @@ class LisecNet:
                     ok = True
                 except _lib.LisecError:
                     ok = False
-            self._tail_ok[c.name] = ok
+            self._tail_ok[(c.name, winograd)] = ok
         return ok
 
     def _backward(self, y_cls, y_reg, loss, grad_scale, rpn_grads_ready, side_filler=None):
@@ -805,7 +820,7 @@ class LisecNet:
                 bwd, sink = (a[dst_name], self.bnstate[bn_name], True), self._bwd_sink(bn_name, C, a[dst_name].numel() // C)
                 bwd_ready[dst_name] = sink
             use_w = c.name in self.packed_wu_t and fold is None
-            if mask is not None and self.fuse_dense_bwd and not use_w and self._tail_supported(c, dst_name):
+            if mask is not None and self.fuse_dense_bwd and self._tail_supported(c, dst_name, use_w):
                 # the Dense(64, relu) of the block BELOW (model_training.py:195) rides on this tile: its data gradient
                 # dz = (gated gradient) @ Wd^T and the statistics of the BatchNormalization under it come out of the same
                 # launch (lisec_conv_extras.tail_w); the separate Dense data-gradient launch is skipped further down
@@ -818,7 +833,7 @@ class LisecNet:
                 fused_dense[n] = sink
             if use_w:
                 ops.conv_forward_winograd(self.dgeom[c.name], dy, self.packed_wu_t[c.name], d[dst_name], flags=flags,
-                                          out_mask=mask, bwd=bwd, sink=sink)
+                                          out_mask=mask, bwd=bwd, sink=sink, tail=tail)
             else:
                 ops.conv_forward(self.dgeom[c.name], dy, self.packed_t[c.name][0], d[dst_name], flags=flags, out_mask=mask,
                                  bwd=bwd, sink=sink, ws_tag=ws_tag, tail=tail, fold=fold)

@@ -184,20 +184,23 @@ def pack_weights_winograd(src, KD, K, N, tap_stride, k_stride, n_stride, flip=Fa
     return out
 
 
-def _wino_extras(out_mask, bwd, sink):
+def _wino_extras(out_mask, bwd, sink, tail=None):
     return _lib.ConvExtras(_lib.ptr(out_mask), _lib.ptr(bwd[0]) if bwd is not None else None,
                            _lib.ptr(bwd[1]) if bwd is not None else None, 1 if (bwd is not None and bwd[2]) else 0,
-                           sink.ref if sink is not None else None, None, None, None, None, None, None, 0)
+                           sink.ref if sink is not None else None, None,
+                           _lib.ptr(tail[0]) if tail is not None else None, _lib.ptr(tail[1]) if tail is not None else None,
+                           None, None, None, 0)
 
 
-def winograd_supported(g, in_bn=False, flags=0, out_mask=None, bwd=None, sink=None):
-    ex = _wino_extras(out_mask, bwd, sink)
+def winograd_supported(g, in_bn=False, flags=0, out_mask=None, bwd=None, sink=None, tail=None):
+    ex = _wino_extras(out_mask, bwd, sink, tail)
     return bool(_lib.load().lisec_conv_winograd_supported(ctypes.byref(g), 1 if in_bn else 0, flags, ctypes.byref(ex)))
 
 
-def conv_forward_winograd(g, x, wu, out, bias=None, in_bn=None, flags=0, out_mask=None, bwd=None, sink=None):
-    """conv_forward(...) in the Winograd F(2x2, 3x3) form (lisec_conv_forward_winograd); wu from pack_weights_winograd."""
-    ex = _wino_extras(out_mask, bwd, sink)
+def conv_forward_winograd(g, x, wu, out, bias=None, in_bn=None, flags=0, out_mask=None, bwd=None, sink=None, tail=None):
+    """conv_forward(...) in the Winograd F(2x2, 3x3) form (lisec_conv_forward_winograd); wu from pack_weights_winograd.
+    tail: optional (packed 64 x 64 kernel, out2) as in conv_forward: out2 = out (as stored) @ kernel; bwd / sink describe out2."""
+    ex = _wino_extras(out_mask, bwd, sink, tail)
     _lib.check(_lib.load().lisec_conv_forward_winograd(ctypes.byref(g), _lib.ptr(x), _lib.ptr(wu), _lib.ptr(bias),
                                                        _lib.ptr(in_bn), flags, _lib.ptr(out), ctypes.byref(ex),
                                                        _lib.current_stream()))

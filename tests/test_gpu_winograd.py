@@ -186,3 +186,47 @@ def test_lyft_geometries(case):
     assert np.abs(dbeta.cpu().numpy() - db).max() <= tol_s and np.abs(dgamma.cpu().numpy() - dg).max() <= 3 * tol_s, name
     coef = sink.coef.cpu().numpy().astype(np.float64)
     assert np.abs(coef[:cout] - db / M).max() <= tol_s / M and np.abs(coef[cout:] - dg / M).max() <= 3 * tol_s / M, name
+
+
+@pytest.mark.parametrize("case", [("small", (2, 12, 20), (4, 12, 20), 3, 1, 0), ("mid2", (2, H, W), (4, H, W), 3, 1, 0),
+                                  ("mid3", (1, H, W), (2, H, W), 3, 2, 1)], ids=["small", "mid2", "mid3"])
+def test_data_gradient_with_dense_tail(case):
+    """The Dense(64, relu) data gradient of the block below riding on the block (lisec_conv_extras.tail_w, model_training.py:195
+    backwards), as tests/test_gpu_lyft_layers.py holds the direct kernels to it: out = gate(dy (*) W^T), out2 = out @ Wd^T, and
+    (sum dz, sum dz*yhat) of out2 for the BatchNormalization under the Dense -- against the two separate steps in fp64."""
+    from lisec_amd import ops
+    from oracle import conv_ref
+    name, ind, outd, KD, sd, pd = case
+    dev = torch.device("cuda")
+    rng = np.random.default_rng(zlib.crc32(("tail" + name).encode()))
+    k, s, p = (KD, 3, 3), (sd, 1, 1), (pd, 1, 1)
+    ntaps = KD * 9
+    dy = rng.normal(0, 1, (*ind, 64)).astype(np.float32)
+    Wt = (rng.normal(0, 1, (ntaps, 64, 64)) / np.sqrt(ntaps * 64)).astype(np.float32)
+    Wd = (rng.normal(0, 1, (1, 64, 64)) / 8).astype(np.float32)          # the tail kernel as the contraction sees it: (c, j)
+    M = outd[0] * outd[1] * outd[2]
+    g = ops.geom(1, ind, outd, k, s, p, 64, 64)
+    wu = ops.pack_weights_winograd(torch.from_numpy(Wt).to(dev), KD, 64, 64, 64 * 64, 64, 1, flip=True)
+    wdp = ops.pack_weights(torch.from_numpy(Wd).to(dev), 1, 64, 64, 0, 64, 1)
+    act = rng.normal(0, 1, (*outd, 64)).astype(np.float32)
+    y = rng.normal(0, 1, (*outd, 64)).astype(np.float32)
+    st_dev, _ = make_bn(rng, 64, dev)
+    st = st_dev.cpu().numpy().astype(np.float64)
+    dgamma, dbeta = torch.zeros(64, device=dev), torch.zeros(64, device=dev)
+    sink = ops.BnSink(64, M, dev, dgamma=dgamma, dbeta=dbeta)
+    out = torch.full((*outd, 64), float("nan"), device=dev)
+    out2 = torch.full((*outd, 64), float("nan"), device=dev)
+    kw = dict(out_mask=torch.from_numpy(act).to(dev), bwd=(torch.from_numpy(y).to(dev), st_dev, False), sink=sink,
+              tail=(wdp, out2))
+    assert ops.winograd_supported(g, **kw)
+    ref = np.where(act > 0, conv_ref.conv_forward(dy, Wt, outd, k, s, p, mode=1), 0.0)
+    ref2 = ref.reshape(M, 64) @ Wd[0].astype(np.float64)
+    for rep in range(2):                                  # twice: the sink must come back to zero
+        ops.conv_forward_winograd(g, torch.from_numpy(dy).to(dev), wu, out, **kw)
+        torch.cuda.synchronize()
+        assert rel_l2(out.cpu().numpy(), ref) <= TOL
+        assert rel_l2(out2.cpu().numpy(), ref2) <= TOL
+        yhat = (y.astype(np.float64).reshape(M, 64) - st[128:192]) * st[192:]
+        db, dg = ref2.sum(0), (ref2 * yhat).sum(0)
+        tol_s = 3e-6 * np.sqrt(M) * np.abs(ref2).max()
+        assert np.abs(dbeta.cpu().numpy() - db).max() <= tol_s and np.abs(dgamma.cpu().numpy() - dg).max() <= 4 * tol_s, name
