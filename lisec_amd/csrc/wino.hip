@@ -60,7 +60,7 @@ __device__ unsigned long long* g_wino_stamps = nullptr;
     } while (0)
 
 // EXP: timing-only variants (wrong results; tools/wino_stamps.py): 1 = no side work in the K loop, 2 = no global loads in it,
-// 3 = no LDS stores in it, 4 = no MFMAs in the helper waves, 5 = no MFMAs in the staging waves
+// 3 = no LDS stores in it, 4 = no MFMAs in the helper waves, 5 = no MFMAs in the staging waves, 6 = the chunk walks stand still
 // TAG only changes the symbol name: bench.py launches the second middle block's forward through k_wino<false, 0, 1> so that
 // its row in a rocprofv3 --stats summary is that layer alone (same code as TAG 0).
 template <bool XF, int EXP = 0, int TAG = 0>
@@ -364,7 +364,7 @@ k_wino(ConvGeom g, int mode, const float* __restrict__ in, const float* __restri
             if (PAR == 0 && pp == 3 && EXP != 1) __syncthreads();      // every wave has read the window's second half
             a0 = a0n; b0 = b0n;
         }
-        if (STAGER) {
+        if (STAGER && EXP != 6) {                    // (EXP 6: the walks stand still -- what the scalar work costs)
             advance(u_kd, u_cc, u_left, 1);
             if (PAR == 0) advance(w_kd, w_cc, w_left, 2);
         }
@@ -731,6 +731,7 @@ extern "C" int lisec_conv_forward_winograd(const lisec_conv_geom* c, const float
         else if (exp == 3) LISEC_WINO_GO(false, 3);
         else if (exp == 4) LISEC_WINO_GO(false, 4);
         else if (exp == 5) LISEC_WINO_GO(false, 5);
+        else if (exp == 6) LISEC_WINO_GO(false, 6);
         else if (flags & LISEC_CONV_TAG_ROOFLINE)
             LISEC_LAUNCH((k_wino<false, 0, 1>), grid, dim3(kWinoThreads), kWinoLds, st, g, c->mode, in, wino_w, bias, in_bnstate, flags, out, BH, BW, plane_list);
         else if (in_bnstate) LISEC_WINO_GO(true, 0);
