@@ -11,19 +11,23 @@
 // direct kernels by summation order and by the transforms' own roundings (measured in tests/test_gpu_winograd.py against
 // the fp64 oracle, same bound as the direct kernels).
 //
-// One 256-thread workgroup (one wave per SIMD, one workgroup per CU: 256 accumulator registers per lane) owns 8 x 8
-// Winograd tiles (16 x 16 outputs) of one output plane x 64 output channels; wave (wm, wn) owns 32 tiles x 32 channels x
-// ALL 16 points, so the output transform is lane-local (accumulator register r of every point is the same (tile, channel)).
-// K runs in chunks of 8 input channels of one depth tap; per chunk
-//   V[pt][tile][8]  -- each thread loads the 4 x 4 patch of one (tile, channel pair) straight from global memory (two
-//                      channels = 8 bytes per position; the BatchNormalization(+ReLU) of the producing layer is applied
-//                      here, padding stays exactly zero), transforms it (32 adds per channel) and stores 16 x 8 bytes
-//   U[pt][n][8]     -- linear 32 KB copy of the pre-transformed kernel (lisec_conv_pack_weights_winograd writes the LDS
-//                      image, swizzle included)
-//   64 MFMAs per wave: per point one ds_read_b128 of V and one of U (four K steps each).
-// Two LDS stages (128 KB): the image of chunk c + 1 is built while the MFMAs of chunk c read the other one; one barrier
-// per chunk.  Rows of V / U are 32 bytes; the 16-byte half a lane reads is swizzled by bit 3 of the row so that every
-// 16-lane group of a ds_read_b128 covers all 64 banks.
+// One 512-thread workgroup per CU owns 8 x 8 Winograd tiles (16 x 16 outputs) of one output plane x 64 output channels.
+// Wave (half, wm, wn) owns 32 tiles x 32 channels x 8 of the 16 points (half = rows i of M: 128 accumulator registers per
+// lane, two waves per SIMD); waves 0-3 also do ALL of the staging.  K runs in chunks of 8 input channels of one depth tap;
+// per chunk
+//   window          the raw 18 x 18 positions under the block, 16 channels of one depth plane at a time (two chunks), parked
+//                   in LDS: every position is fetched ONCE, as 64 contiguous bytes
+//   V[pt][tile][8]  each staging thread reads the 4 x 4 patch of one (tile, channel pair) from the window, gates it (the
+//                   BatchNormalization(+ReLU) of the producing layer is applied here, padding stays exactly zero), transforms
+//                   it (32 adds per channel) and stores 16 x 8 bytes
+//   U[pt][n][8]     linear 32 KB copy of the pre-transformed kernel (lisec_conv_pack_weights_winograd writes the LDS image,
+//                   swizzle included)
+//   32 MFMAs per wave: per point one ds_read_b128 of V and one of U (four K steps each).
+// Two LDS stages + the window (153 KB): the image of chunk c + 1 is built while the MFMAs of chunk c read the other stage.
+// Rows of V / U are 32 bytes; the 16-byte half a lane reads is swizzled by bit 3 of the row so that every 16-lane group of a
+// ds_read_b128 covers all 64 banks.  The output transform is linear in the rows of M: each half forms its share of both
+// output lines, keeps one and hands the other to its partner through LDS.  What was measured on the way (and why the form
+// stops at 1.4-1.6x of the direct kernels instead of 2.25x): DESIGN.md section 4.3, profiles/r04_winograd.txt.
 #include <type_traits>
 
 #include "conv.h"

@@ -230,3 +230,35 @@ def test_data_gradient_with_dense_tail(case):
         db, dg = ref2.sum(0), (ref2 * yhat).sum(0)
         tol_s = 3e-6 * np.sqrt(M) * np.abs(ref2).max()
         assert np.abs(dbeta.cpu().numpy() - db).max() <= tol_s and np.abs(dgamma.cpu().numpy() - dg).max() <= 4 * tol_s, name
+
+
+def test_lyft_network_direct_and_winograd_forms_agree(monkeypatch):
+    """The whole Lyft-grid network (createModel, model_training.py:222-257) twice on the same variables and sweep: with the
+    direct kernels everywhere (LISEC_TUNING winograd=0) and with the Winograd form where LisecNet runs it (winograd=7).  The
+    training-mode forward maps and one training step's loss agree to fp32 rounding through 11 layers; the gradients of both
+    against the fp64 oracle are the subject of tests/test_gpu_network.py, which runs the default (Winograd) form."""
+    from conftest import LYFT
+    from lisec_amd.network import LisecNet
+    from lisec_amd.params import ParamStore
+    from lisec_amd.voxelizer import Voxelizer
+    from oracle import model_ref as M
+    dev = torch.device("cuda")
+    rng = np.random.default_rng(3)
+    pts = np.stack([rng.uniform(-55, 55, 20000), rng.uniform(-55, 55, 20000), rng.uniform(-0.5, 2.5, 20000)], 1).astype(np.float32)
+    op = M.glorot_params(seed=31, randomize_bn=True)
+    y_cls = torch.from_numpy(rng.integers(0, 2, (100, 200, 2)).astype(np.float32)).to(dev)
+    y_reg = torch.from_numpy(rng.normal(0, 1, (100, 200, 14)).astype(np.float32)).to(dev)
+    res = {}
+    for bits in (0, 7):
+        monkeypatch.setenv("LISEC_TUNING", f"winograd={bits}")
+        net = LisecNet(200, 400, 8, 35, params=ParamStore(dev, init=op))
+        assert bool(net.packed_wu) == (bits != 0)
+        sample = Voxelizer(**LYFT)(pts)
+        cls, reg = net.forward(sample, training=True)
+        head = net.act["head"].cpu().numpy().copy()
+        loss = net.train_step(sample, y_cls, y_reg)
+        torch.cuda.synchronize()
+        res[bits] = (head, float(loss[0].item()), net.params.grad_view(net.grad, "mid2.conv.kernel").cpu().numpy().copy())
+    assert rel_l2(res[7][0], res[0][0]) <= 2e-5, "RPN maps of the two forms"
+    assert abs(res[7][1] - res[0][1]) <= 1e-5 * abs(res[0][1]), "loss of the two forms"
+    assert np.isfinite(res[7][2]).all() and np.abs(res[7][2]).max() > 0
