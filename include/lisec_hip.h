@@ -377,6 +377,17 @@ int lisec_conv_forward_winograd(const lisec_conv_geom* g, const float* in, const
                                 const float* in_bnstate, int flags, float* out, const lisec_conv_extras* extras,
                                 lisec_stream_t stream);
 
+/* Winograd F(2x2, 3x3) form of lisec_conv_wgrad (csrc/wino_wgrad.hip) for the 64 -> 64 Conv3D blocks with 3 x 3 (h, w) taps, stride 1
+ * and padding 1 along h and w (model_training.py:193, 237-238; what fit() derives for their kernels, :299): dU[kd] = sum over
+ * tiles of (B^T d B) (x) (A dY A^T) per transform point, then dW = G^T dU G -- 4 / 9 of the multiplications of the direct weight
+ * gradient, fp32 operands and accumulation, slabs summed in a fixed order (deterministic).  g: the geometry of the FORWARD layer
+ * (mode 0), in = the layer's input (packed rows of 64), dy (packed rows of 64), dW in the Keras layout (taps, 64, 64).  No
+ * on-load affine.  workspace: lisec_conv_wgrad_winograd_workspace_bytes(g), no initialisation needed. */
+int lisec_conv_wgrad_winograd_supported(const lisec_conv_geom* g);
+size_t lisec_conv_wgrad_winograd_workspace_bytes(const lisec_conv_geom* g);
+int lisec_conv_wgrad_winograd(const lisec_conv_geom* g, const float* in, const float* dy, void* workspace,
+                              size_t workspace_bytes, float* dW, lisec_stream_t stream);
+
 /* Weight gradient of the contraction described by `g` (the geometry of the FORWARD layer):
  *   dW[tap][c][n] = sum_m f(in[src(m,tap), c]) * dy[m, n]      dy: float32, g->out_stride floats per row
  * Written in the Keras kernel layout (taps, Cin, Cout); transpose_out != 0 writes (taps, Cout, Cin),

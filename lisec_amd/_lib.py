@@ -173,6 +173,12 @@ def _declare(lib):
     lib.lisec_conv_winograd_supported.argtypes = [POINTER(ConvGeom), c_int, c_int, POINTER(ConvExtras)]
     lib.lisec_conv_forward_winograd.restype = c_int
     lib.lisec_conv_forward_winograd.argtypes = [POINTER(ConvGeom), P, P, P, P, c_int, P, POINTER(ConvExtras), P]
+    lib.lisec_conv_wgrad_winograd_supported.restype = c_int
+    lib.lisec_conv_wgrad_winograd_supported.argtypes = [POINTER(ConvGeom)]
+    lib.lisec_conv_wgrad_winograd_workspace_bytes.restype = c_size_t
+    lib.lisec_conv_wgrad_winograd_workspace_bytes.argtypes = [POINTER(ConvGeom)]
+    lib.lisec_conv_wgrad_winograd.restype = c_int
+    lib.lisec_conv_wgrad_winograd.argtypes = [POINTER(ConvGeom), P, P, P, c_size_t, P, P]
     lib.lisec_conv_num_mblocks_bwd.restype = c_int
     lib.lisec_conv_num_mblocks_bwd.argtypes = [POINTER(ConvGeom)]
     lib.lisec_bn_backward_apply.restype = c_int

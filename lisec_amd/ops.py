@@ -306,6 +306,22 @@ def conv_wgrad(g, x, dy, dW, workspace, in_bn=None, flags=0, transpose_out=False
     return dW
 
 
+def wgrad_winograd_supported(g):
+    return bool(_lib.load().lisec_conv_wgrad_winograd_supported(ctypes.byref(g)))
+
+
+def wgrad_winograd_workspace_bytes(g):
+    return _lib.load().lisec_conv_wgrad_winograd_workspace_bytes(ctypes.byref(g))
+
+
+def conv_wgrad_winograd(g, x, dy, dW, workspace):
+    """conv_wgrad(g, x, dy, dW, ...) in the Winograd F(2x2, 3x3) form (lisec_conv_wgrad_winograd): 64 -> 64 Conv3D blocks."""
+    _lib.check(_lib.load().lisec_conv_wgrad_winograd(ctypes.byref(g), _lib.ptr(x), _lib.ptr(dy), _lib.ptr(workspace),
+                                                     workspace.numel() * workspace.element_size(), _lib.ptr(dW),
+                                                     _lib.current_stream()))
+    return dW
+
+
 _EW = {}
 
 

@@ -262,3 +262,36 @@ def test_lyft_network_direct_and_winograd_forms_agree(monkeypatch):
     assert rel_l2(res[7][0], res[0][0]) <= 2e-5, "RPN maps of the two forms"
     assert abs(res[7][1] - res[0][1]) <= 1e-5 * abs(res[0][1]), "loss of the two forms"
     assert np.isfinite(res[7][2]).all() and np.abs(res[7][2]).max() > 0
+
+
+TOL_W = 3e-6          # weight gradients sum 160 000 - 320 000 positions (the bound of tests/test_gpu_lyft_layers.py)
+
+
+@pytest.mark.parametrize("case", [("small valid depth", (4, 12, 20), (2, 12, 20), 3, 1, 0),
+                                  ("small odd map, depth stride 2 pad 1", (2, 11, 19), (1, 11, 19), 3, 2, 1),
+                                  ("small 2d", (1, 34, 50), (1, 34, 50), 1, 1, 0),
+                                  ("mid2", (4, H, W), (2, H, W), 3, 1, 0), ("mid3", (2, H, W), (1, H, W), 3, 2, 1)],
+                         ids=["small", "small-odd", "small-2d", "mid2", "mid3"])
+def test_weight_gradient_against_the_oracle(case):
+    """dW[tap][c][n] = sum over positions of x[src(pos, tap)][c] dy[pos][n] in the Winograd form (lisec_conv_wgrad_winograd)
+    against the fp64 restatement oracle/conv_ref.conv_wgrad -- the oracle and bound of the direct weight gradients."""
+    from lisec_amd import ops
+    from oracle import conv_ref
+    name, ind, outd, KD, sd, pd = case
+    dev = torch.device("cuda")
+    rng = np.random.default_rng(zlib.crc32(("wgrad" + name).encode()))
+    k, s, p = (KD, 3, 3), (sd, 1, 1), (pd, 1, 1)
+    x = rng.normal(0, 1, (*ind, 64)).astype(np.float32)
+    dy = rng.normal(0, 1, (*outd, 64)).astype(np.float32)
+    g = ops.geom(0, ind, outd, k, s, p, 64, 64)
+    assert ops.wgrad_winograd_supported(g)
+    ws = torch.empty(ops.wgrad_winograd_workspace_bytes(g), dtype=torch.uint8, device=dev)
+    dW = torch.full((KD * 9, 64, 64), float("nan"), device=dev)
+    ref = conv_ref.conv_wgrad(x, dy, outd, k, s, p, mode=0)
+    for rep in range(2):
+        ops.conv_wgrad_winograd(g, torch.from_numpy(x).to(dev), torch.from_numpy(dy).to(dev), dW, ws)
+        torch.cuda.synchronize()
+        got = dW.cpu().numpy()
+        assert np.isfinite(got).all()
+        e = rel_l2(got, ref)
+        assert e <= TOL_W, f"{name}: relative L2 {e:.2e}"
