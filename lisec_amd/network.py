@@ -159,8 +159,9 @@ class LisecNet:
         # Winograd F(2x2, 3x3) form (csrc/wino.hip) of the stride-1 3x3 contractions that fill the chip in it (>= 128 blocks of
         # 8 x 8 tiles x 64 channels: the Conv3D blocks behind the first and the stride-1 Conv2Ds of RPN block 1): 4 / 9 of the
         # multiplications.  LISEC_TUNING winograd: bit 0 = forward calls, bit 1 = data gradients of the Conv2Ds, bit 2 = data gradients of the Conv3D
-        # blocks (their Dense(64) gradient then runs as a launch of its own); 0 keeps the direct kernels
-        self.winograd = _lib.knob("winograd", 7)
+        # blocks (their Dense(64) gradient then runs as a launch of its own), bit 3 = weight gradients of the Conv3D blocks
+        # (csrc/wino_wgrad.hip); 0 keeps the direct kernels
+        self.winograd = _lib.knob("winograd", 15)
         self.packed_wu, self.packed_wu_t = {}, {}
         for L in self.layers:
             c = L["conv"]
@@ -581,6 +582,15 @@ class LisecNet:
                     self.wgrad_batches[convs[0]["name"]] = (batch, {L["name"] for L in convs})
         # zero-filled: the head of the workspace holds the arrival counters of the slab-combining kernels
         self.wgrad_ws = torch.zeros(ws_bytes, dtype=torch.uint8, device=dev)
+        # weight gradients of the Conv3D blocks behind the first in the Winograd form (winograd bit 3): one slab workspace for
+        # all of them (they run one after the other on the second stream)
+        self.wino_wgrad_ws = {}
+        if self.winograd & 8:
+            mids = [L["conv"] for L in self.layers if L["kind"] == "mid" and L["src"] != "grid"
+                    and ops.wgrad_winograd_supported(L["conv"].g)]
+            if mids:
+                shared = torch.empty(max(ops.wgrad_winograd_workspace_bytes(c.g) for c in mids), dtype=torch.uint8, device=dev)
+                self.wino_wgrad_ws = {c.name: shared for c in mids}
         self._packed_t_version = -1
         self._train_ready = True
 
@@ -997,8 +1007,13 @@ class LisecNet:
                     # on their own and run slower side by side than one after the other (mid2: 800 us together,
                     # 333 + 358 alone); behind the data gradient the weight gradient shares the chip with the
                     # short kernels of the rest of the chain instead
-                    wg = lambda L=L, c=c, n=n: ops.conv_wgrad(c.g, a[L["src"]], d[n + ".z"], p.grad_view(G, c.wname),
-                                                              self.wgrad_ws)
+                    if c.name in self.wino_wgrad_ws:
+                        # Winograd-domain weight gradient (csrc/wino_wgrad.hip): 4 / 9 of the ring kernel's MFMAs
+                        wg = lambda L=L, c=c, n=n: ops.conv_wgrad_winograd(c.g, a[L["src"]], d[n + ".z"],
+                                                                           p.grad_view(G, c.wname), self.wino_wgrad_ws[c.name])
+                    else:
+                        wg = lambda L=L, c=c, n=n: ops.conv_wgrad(c.g, a[L["src"]], d[n + ".z"], p.grad_view(G, c.wname),
+                                                                  self.wgrad_ws)
                     if self.mid_wgrad_first:
                         on_side(wg)
                         if late_dense:

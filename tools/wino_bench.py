@@ -79,5 +79,26 @@ def main():
               f"   x{t_d / t_w:.2f}   |direct - winograd| / |direct| = {err:.1e}", flush=True)
 
 
+def wgrad_main():
+    reps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+    dev = torch.device("cuda")
+    rng = np.random.default_rng(1)
+    for name, ind, outd, KD, sd, pd in [("mid2 weight gradient", (4, H, W), (2, H, W), 3, 1, 0),
+                                        ("mid3 weight gradient", (2, H, W), (1, H, W), 3, 2, 1)]:
+        g = ops.geom(0, ind, outd, (KD, 3, 3), (sd, 1, 1), (pd, 1, 1), 64, 64)
+        x = torch.from_numpy(rng.normal(0, 1, (*ind, 64)).astype(np.float32)).to(dev)
+        dy = torch.from_numpy(rng.normal(0, 1, (*outd, 64)).astype(np.float32)).to(dev)
+        dW, dW2 = torch.empty(KD * 9, 64, 64, device=dev), torch.empty(KD * 9, 64, 64, device=dev)
+        ws = torch.zeros(ops.wgrad_workspace_bytes(g), dtype=torch.uint8, device=dev)
+        ws2 = torch.empty(ops.wgrad_winograd_workspace_bytes(g), dtype=torch.uint8, device=dev)
+        t_d = timeit(lambda: ops.conv_wgrad(g, x, dy, dW, ws), reps)
+        t_w = timeit(lambda: ops.conv_wgrad_winograd(g, x, dy, dW2, ws2), reps)
+        err = float((dW - dW2).norm() / dW.norm())
+        gf = 2.0 * outd[1] * outd[2] * live_taps(0, ind, outd, KD, sd, pd) * 64 * 64 / 1e9
+        print(f"{name:28s} ring   {t_d:7.1f} us ({gf / t_d * 1e3:6.1f} TF/s)   winograd {t_w:7.1f} us ({gf / t_w * 1e3:6.1f} TF/s algorithmic)"
+              f"   x{t_d / t_w:.2f}   |ring - winograd| / |ring| = {err:.1e}", flush=True)
+
+
 if __name__ == "__main__":
     main()
+    wgrad_main()
