@@ -14,7 +14,8 @@ from collections import defaultdict
 
 DOMINANT = "mid2 Conv3D forward, Winograd form (roofline launch)"
 KEYS = {"k_wino<false, 0, 1>": DOMINANT, "k_igemm_halo<1, false, 1, 2": "mid2 Conv3D data gradient, direct form (roofline launch)",
-        "k_wino<false, 0, 0>": "Winograd contractions without on-load BN (mid blocks, data gradients)", "k_wino<true, 0, 0>": "Winograd contractions with on-load BN (rpn1 forward)", "k_wgrad_halo<false, 7>": "mid wgrad (halo)", "k_field_taps": "field conv: taps",
+        "k_wino<false, 0, 0>": "Winograd contractions without on-load BN (mid blocks, data gradients)", "k_wino<true, 0, 0>": "Winograd contractions with on-load BN (rpn1 forward)",
+        "k_wino_wgrad(": "Winograd weight gradient (mid2, mid3)", "k_wino_wgrad_sum": "Winograd weight gradient: slab sum", "k_wgrad_halo<false, 7>": "mid wgrad (halo)", "k_field_taps": "field conv: taps",
         "k_field_combine": "field conv: combine", "k_igemm_halo<0, false, 1, 2>": "mid1 Conv3D fwd (roofline launch)", "k_vfe_grid": "VFE grid writer",
         "k_vfe_stage<2": "VFE layers 1+2", "k_vfe_stage<3": "VFE layer 3", "k_wgrad_halo<false>": "mid wgrad (halo)",
         "k_wgrad_ring<false, 5>": "mid wgrad (ring)", "k_wgrad_ring_batch<true, 5>": "rpn1/rpn2 batched wgrad (ring)",
