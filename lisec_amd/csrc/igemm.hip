@@ -1213,7 +1213,7 @@ k_igemm_wide(ConvGeom g, const float* __restrict__ in, const float* __restrict__
 //   XF:  BatchNormalization of the producer applied on load (forward: Dense reads BN(conv)), bias + optional ReLU on store
 //   BWD: (sum dz, sum dz * yhat) of the stored gradient for the BatchNormalization it is about to cross -> g.sink
 template <bool XF, bool BWD>
-__global__ void __launch_bounds__(kThreads)
+__global__ void __launch_bounds__(kThreads, 3)     // three resident workgroups per CU (resident_slots): <= 168 registers
 k_dense64(ConvGeom g, const float* __restrict__ in, const float* __restrict__ wp, const float* __restrict__ bias,
           const float* __restrict__ in_bn, int flags, float* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1274,6 +1274,19 @@ k_dense64(ConvGeom g, const float* __restrict__ in, const float* __restrict__ wp
         __syncthreads();
         const int next = tile + gridDim.x;
         if (next < ntiles) issue(next);
+        const int mw = tile * BM + wave * 32;
+        // BWD: the tile's rows of y are requested HERE, before the MFMAs.  Read one by one inside the store loop they were
+        // serialised behind the stores (the compiler cannot rule out that `out` aliases g.bwd_y): 16 dependent round trips
+        // per tile, 15 us per tile and CU -- the kernel moved 246 MB in 148 us (1.7 TB/s)
+        float yA[BWD ? 16 : 1], yB[BWD ? 16 : 1];
+        if (BWD) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mw + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const float* yr = g.bwd_y + (size_t)(m < g.M ? m : 0) * 64;
+                yA[r] = yr[col]; yB[r] = yr[32 + col];
+            }
+        }
         f32x16 acc0 = {0}, acc1 = {0};
 #pragma unroll
         for (int kc = 0; kc < BK / 8; ++kc) {
@@ -1289,7 +1302,6 @@ k_dense64(ConvGeom g, const float* __restrict__ in, const float* __restrict__ wp
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b0.w, acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b1.w, acc1, 0, 0, 0);
         }
-        const int mw = tile * BM + wave * 32;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = mw + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -1300,8 +1312,7 @@ k_dense64(ConvGeom g, const float* __restrict__ in, const float* __restrict__ wp
                 o[col] = va;
                 o[32 + col] = vb;
                 if (BWD) {
-                    const float* yr = g.bwd_y + (size_t)m * 64;
-                    const float ya = yr[col], yb = yr[32 + col];
+                    const float ya = yA[r], yb = yB[r];
                     const float da = (g.bwd_relu && !(fmaf(ya, ysA, yhA) > 0.f)) ? 0.f : va;
                     const float db = (g.bwd_relu && !(fmaf(yb, ysB, yhB) > 0.f)) ? 0.f : vb;
                     sumA += da; sqA = fmaf(da, (ya - ymA) * yiA, sqA);
