@@ -140,6 +140,20 @@ __device__ __forceinline__ void store_tile(const ConvGeom& g, const f32x16& acc0
     const float biasB = (bias && nB < g.Cout) ? bias[ncB] : 0.f;
     const bool orelu = (flags & LISEC_CONV_OUT_RELU) != 0, accum = (flags & LISEC_CONV_ACCUMULATE) != 0;
     float sumA = 0.f, sqA = 0.f, sumB = 0.f, sqB = 0.f;
+    // Backward statistics on a plain row order: the rows of y this wave needs are requested BEFORE the first store.  Read
+    // inside the store loop each of them waited behind the stores in front of it (`out` may alias y for all the compiler
+    // knows, and the memory pipeline returns in order): 16 dependent round trips per tile
+    const bool y_ahead = bwd_y && !g.pc_span && !g.ps;
+    float yA[16], yB[16];
+    if (y_ahead) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = mw + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const float* yr = bwd_y + (size_t)(m < mlimit ? m : 0) * g.Cout;
+            yA[r] = nA < g.Cout ? yr[nA] : 0.f;
+            yB[r] = nB < g.Cout ? yr[nB] : 0.f;
+        }
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -176,7 +190,7 @@ __device__ __forceinline__ void store_tile(const ConvGeom& g, const f32x16& acc0
             if (bwd_y) {
                 // (sum dz, sum dz * yhat) of the gradient just stored, for the BatchNormalization it is about to cross
                 const float* yr = bwd_y + orow * g.Cout;
-                const float ya = nA < g.Cout ? yr[nA] : 0.f, yb = nB < g.Cout ? yr[nB] : 0.f;
+                const float ya = y_ahead ? yA[r] : (nA < g.Cout ? yr[nA] : 0.f), yb = y_ahead ? yB[r] : (nB < g.Cout ? yr[nB] : 0.f);
                 const float da = (g.bwd_relu && !(fmaf(ya, ysA, yhA) > 0.f)) || nA >= g.Cout ? 0.f : va;
                 const float db = (g.bwd_relu && !(fmaf(yb, ysB, yhB) > 0.f)) || nB >= g.Cout ? 0.f : vb;
                 sumA += da; sqA = fmaf(da, (ya - ymA) * yiA, sqA);
