@@ -309,7 +309,19 @@ typedef struct lisec_conv_extras {
     const float* in_fold_bnstate;
     const float* in_fold_coef;
     int in_fold_relu;
+    /* optional weight gradient of the SAME Dense (model_training.py:195 backwards, what fit() derives for its kernel, :299),
+     * for the call that is a Dense(64)'s data gradient with backward statistics (1x1x1, 64 -> 64, packed rows, bwd_y + a
+     * LISEC_SINK_BACKWARD sink, no in_bnstate): the call already reads both operands of
+     *     dW[i][j] = sum_m f(bwd_y[m, i]) * in[m, j],   f = bwd_bnstate's affine (+ ReLU when bwd_relu)
+     * -- the Dense's input is the BatchNormalization output whose statistics the call reduces -- so the resident workgroups
+     * accumulate it beside the data gradient instead of a second pass over 2 x (positions x 64) floats.
+     * dense_dw: lisec_dense_dw_slabs() x 4096 floats, 16-byte aligned, no initialisation needed; lisec_dense_dw_reduce then
+     * sums the slabs in index order (deterministic) into dW (64, 64) = (in channel, out channel), the Keras layout.
+     * Needs at least lisec_dense_dw_slabs() tiles of 128 rows; LISEC_EINVAL for any other call. */
+    float* dense_dw;
 } lisec_conv_extras;
+int lisec_dense_dw_slabs(void);
+int lisec_dense_dw_reduce(const float* slabs, float* dW, lisec_stream_t stream);
 int lisec_conv_num_mblocks_bwd(const lisec_conv_geom* g);
 
 /* The launch plan lisec_conv_forward_ex WILL run for these arguments (pointers only matter as NULL / non-NULL, so the

@@ -42,7 +42,7 @@ class ConvExtras(ctypes.Structure):           # lisec_conv_extras
                 ("bwd_relu", ctypes.c_int), ("sink", POINTER(BnSinkDesc)), ("queue", ctypes.c_void_p),
                 ("tail_w", ctypes.c_void_p), ("tail_out", ctypes.c_void_p),
                 ("in_y", ctypes.c_void_p), ("in_fold_bnstate", ctypes.c_void_p), ("in_fold_coef", ctypes.c_void_p),
-                ("in_fold_relu", ctypes.c_int)]
+                ("in_fold_relu", ctypes.c_int), ("dense_dw", ctypes.c_void_p)]
 
 
 class ConvPlan(Structure):                     # lisec_conv_plan
@@ -179,6 +179,10 @@ def _declare(lib):
     lib.lisec_conv_wgrad_winograd_workspace_bytes.argtypes = [POINTER(ConvGeom)]
     lib.lisec_conv_wgrad_winograd.restype = c_int
     lib.lisec_conv_wgrad_winograd.argtypes = [POINTER(ConvGeom), P, P, P, c_size_t, P, P]
+    lib.lisec_dense_dw_slabs.restype = c_int
+    lib.lisec_dense_dw_slabs.argtypes = []
+    lib.lisec_dense_dw_reduce.restype = c_int
+    lib.lisec_dense_dw_reduce.argtypes = [P, P, P]
     lib.lisec_conv_num_mblocks_bwd.restype = c_int
     lib.lisec_conv_num_mblocks_bwd.argtypes = [POINTER(ConvGeom)]
     lib.lisec_bn_backward_apply.restype = c_int

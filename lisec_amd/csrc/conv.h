@@ -58,6 +58,9 @@ struct ConvGeom {
     const float* fold_bn;    // its bnstate float[4*Cin]
     const float* fold_coef;  // float[2*Cin]: mean(dz), mean(dz * yhat) (a backward sink's coef)
     int fold_relu;
+    // optional weight gradient of the Dense(64) whose data gradient this call is (lisec_conv_extras.dense_dw): per-workgroup
+    // 64 x 64 slabs of  sum_m bn(bwd_y)[m, i] * in[m, j]  (k_dense64<false, true, true>)
+    float* dw_slabs;
 };
 
 int conv_geom_check(const lisec_conv_geom* c, ConvGeom* g);

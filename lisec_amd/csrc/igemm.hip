@@ -1243,8 +1243,13 @@ k_igemm_wide(ConvGeom g, const float* __restrict__ in, const float* __restrict__
 // per workgroup instead of one per tile).
 //   XF:  BatchNormalization of the producer applied on load (forward: Dense reads BN(conv)), bias + optional ReLU on store
 //   BWD: (sum dz, sum dz * yhat) of the stored gradient for the BatchNormalization it is about to cross -> g.sink
-template <bool XF, bool BWD>
-__global__ void __launch_bounds__(kThreads, 3)     // three resident workgroups per CU (resident_slots): <= 168 registers
+//   DW:  (with BWD) the weight gradient of the same Dense beside its data gradient: the tile's rows of the gradient are in
+//        LDS (the A operand) and its rows of y in registers (the statistics), which are the two operands of
+//        dW[i][j] = sum_m bn(y)[m, i] * g[m, j] -- 64 more MFMAs per wave and tile under a kernel that waits for HBM, instead of
+//        a second pass over both maps (k_wgrad: 35 / 46 / 67 us alone for the three middle blocks).  The accumulators stay in
+//        registers for the whole launch; one 64 x 64 slab per workgroup, summed by k_dense_dw_reduce.
+template <bool XF, bool BWD, bool DW = false>
+__global__ void __launch_bounds__(kThreads, DW ? 2 : 3)     // three resident workgroups per CU (resident_slots): <= 168 registers;
 k_dense64(ConvGeom g, const float* __restrict__ in, const float* __restrict__ wp, const float* __restrict__ bias,
           const float* __restrict__ in_bn, int flags, float* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1273,20 +1278,28 @@ k_dense64(ConvGeom g, const float* __restrict__ in, const float* __restrict__ wp
         ysB = g.bwd_bn[32 + col]; yhB = g.bwd_bn[96 + col]; ymB = g.bwd_bn[160 + col]; yiB = g.bwd_bn[224 + col];
     }
     float sumA = 0.f, sqA = 0.f, sumB = 0.f, sqB = 0.f;
+    f32x16 dw00 = {0}, dw01 = {0}, dw10 = {0}, dw11 = {0};      // DW: blocks (i half, j half) of this wave's share of dW
 
-    float4 ra[8];
+    // Every global access goes through a buffer descriptor over the layer's rows: one 32-bit lane offset per tile instead of a
+    // 64-bit address, a clamp and a branch per row -- rows beyond the layer read zeros and their stores are dropped
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const int nbytes = g.M * 256;
+    const __amdgpu_buffer_rsrc_t irs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in), 0, nbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(out, 0, nbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(BWD ? g.bwd_y : in), 0, nbytes, 0x00020000);
+    const int a_voff = (tid >> 4) * 256 + piece * 16;                         // row tid >> 4 of a 16-row group, 16 bytes of it
+    const int c_voff = (wave * 32 + 4 * (lane >> 5)) * 256 + col * 4;         // C layout: the wave's rows, this lane's column
+
+    u32x4 ra[8];
     auto issue = [&](int tile) {
+        const int vo = tile * (BM * 256) + a_voff;
 #pragma unroll
-        for (int p = 0; p < 8; ++p) {
-            const int m = tile * BM + p * 16 + (tid >> 4);
-            const int mm = m < g.M ? m : 0;                       // rows beyond the layer read row 0 and are never stored
-            ra[p] = *reinterpret_cast<const float4*>(in + (size_t)mm * 64 + piece * 4);
-        }
+        for (int p = 0; p < 8; ++p) ra[p] = __builtin_amdgcn_raw_buffer_load_b128(irs, vo + p * 4096, 0, 0);
     };
     auto stage = [&]() {
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
-            float4 v = ra[p];
+            float4 v = make_float4(__uint_as_float(ra[p].x), __uint_as_float(ra[p].y), __uint_as_float(ra[p].z), __uint_as_float(ra[p].w));
             if (XF) {
                 v.x = fmaxf(fmaf(v.x, tsc.x, tsh.x), relu_lo); v.y = fmaxf(fmaf(v.y, tsc.y, tsh.y), relu_lo);
                 v.z = fmaxf(fmaf(v.z, tsc.z, tsh.z), relu_lo); v.w = fmaxf(fmaf(v.w, tsc.w, tsh.w), relu_lo);
@@ -1306,6 +1319,7 @@ k_dense64(ConvGeom g, const float* __restrict__ in, const float* __restrict__ wp
         const int next = tile + gridDim.x;
         if (next < ntiles) issue(next);
         const int mw = tile * BM + wave * 32;
+        const int cvo = tile * (BM * 256) + c_voff;               // accumulator row r is cvo + ((r & 3) + 8 * (r >> 2)) * 256
         // BWD: the tile's rows of y are requested HERE, before the MFMAs.  Read one by one inside the store loop they were
         // serialised behind the stores (the compiler cannot rule out that `out` aliases g.bwd_y): 16 dependent round trips
         // per tile, 15 us per tile and CU -- the kernel moved 246 MB in 148 us (1.7 TB/s)
@@ -1313,9 +1327,9 @@ k_dense64(ConvGeom g, const float* __restrict__ in, const float* __restrict__ wp
         if (BWD) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = mw + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const float* yr = g.bwd_y + (size_t)(m < g.M ? m : 0) * 64;
-                yA[r] = yr[col]; yB[r] = yr[32 + col];
+                const int ro = ((r & 3) + 8 * (r >> 2)) * 256;
+                yA[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(yrs, cvo + ro, 0, 0));
+                yB[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(yrs, cvo + ro + 128, 0, 0));
             }
         }
         f32x16 acc0 = {0}, acc1 = {0};
@@ -1333,24 +1347,62 @@ k_dense64(ConvGeom g, const float* __restrict__ in, const float* __restrict__ wp
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b0.w, acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b1.w, acc1, 0, 0, 0);
         }
+        if (DW) {
+            // C-layout registers of y ARE an A operand: lanes 0-31 hold row m_r (k = 0), lanes 32-63 row m_r + 4 (k = 1), lane & 31
+            // the channel i; the B operand is the same two rows of the gradient tile in LDS, lane & 31 the column j.  Rows beyond
+            // the layer: the gradient rows are zeros (descriptor), so whatever bn(0) is, the product is zero
+            const float* gRow = sA + (wave * 32 + 4 * (lane >> 5)) * LDA + col;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ml = (r & 3) + 8 * (r >> 2);
+                float xa = fmaf(yA[r], ysA, yhA), xb = fmaf(yB[r], ysB, yhB);
+                if (g.bwd_relu) { xa = fmaxf(xa, 0.f); xb = fmaxf(xb, 0.f); }
+                const float g0 = gRow[ml * LDA], g1 = gRow[ml * LDA + 32];
+                dw00 = __builtin_amdgcn_mfma_f32_32x32x2f32(xa, g0, dw00, 0, 0, 0);
+                dw01 = __builtin_amdgcn_mfma_f32_32x32x2f32(xa, g1, dw01, 0, 0, 0);
+                dw10 = __builtin_amdgcn_mfma_f32_32x32x2f32(xb, g0, dw10, 0, 0, 0);
+                dw11 = __builtin_amdgcn_mfma_f32_32x32x2f32(xb, g1, dw11, 0, 0, 0);
+            }
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int m = mw + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            if (m < g.M) {
-                float va = acc0[r] + biasA, vb = acc1[r] + biasB;
-                if (orelu) { va = fmaxf(va, 0.f); vb = fmaxf(vb, 0.f); }
-                float* o = out + (size_t)m * 64;
-                o[col] = va;
-                o[32 + col] = vb;
-                if (BWD) {
-                    const float ya = yA[r], yb = yB[r];
-                    const float da = (g.bwd_relu && !(fmaf(ya, ysA, yhA) > 0.f)) ? 0.f : va;
-                    const float db = (g.bwd_relu && !(fmaf(yb, ysB, yhB) > 0.f)) ? 0.f : vb;
-                    sumA += da; sqA = fmaf(da, (ya - ymA) * yiA, sqA);
-                    sumB += db; sqB = fmaf(db, (yb - ymB) * yiB, sqB);
+            const int ml = (r & 3) + 8 * (r >> 2);
+            float va = acc0[r] + biasA, vb = acc1[r] + biasB;
+            if (orelu) { va = fmaxf(va, 0.f); vb = fmaxf(vb, 0.f); }
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(va), ors, cvo + ml * 256, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(vb), ors, cvo + ml * 256 + 128, 0, 0);
+            if (BWD) {
+                const bool ok = mw + ml + 4 * (lane >> 5) < g.M;
+                const float ya = yA[r], yb = yB[r];
+                const float da = (!ok || (g.bwd_relu && !(fmaf(ya, ysA, yhA) > 0.f))) ? 0.f : va;
+                const float db = (!ok || (g.bwd_relu && !(fmaf(yb, ysB, yhB) > 0.f))) ? 0.f : vb;
+                sumA += da; sqA = fmaf(da, (ya - ymA) * yiA, sqA);
+                sumB += db; sqB = fmaf(db, (yb - ymB) * yiB, sqB);
+            }
+        }
+    }
+    if (DW) {
+        // the four waves' shares, added in wave order (deterministic), then the workgroup's slab
+        float* dsum = smem;                                       // [64][64]
+#pragma unroll 1
+        for (int w = 0; w < 4; ++w) {
+            __syncthreads();
+            if (wave == w) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    float* d0 = dsum + i * 64 + col;
+                    float* d1 = dsum + (32 + i) * 64 + col;
+                    if (w == 0) { d0[0] = dw00[r]; d0[32] = dw01[r]; d1[0] = dw10[r]; d1[32] = dw11[r]; }
+                    else        { d0[0] += dw00[r]; d0[32] += dw01[r]; d1[0] += dw10[r]; d1[32] += dw11[r]; }
                 }
             }
         }
+        __syncthreads();
+        float* slab = g.dw_slabs + (size_t)blockIdx.x * 4096;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            *reinterpret_cast<float4*>(slab + (i * 256 + tid) * 4) = *reinterpret_cast<const float4*>(dsum + (i * 256 + tid) * 4);
     }
     if (BWD) {
         __syncthreads();
@@ -1370,6 +1422,33 @@ k_dense64(ConvGeom g, const float* __restrict__ in, const float* __restrict__ wp
             sink_add(g.sink, q & 1, (q >> 1) * 32 + c, v);
         }
         sink_finish(g.sink);
+    }
+}
+
+// dW[e] = sum over the workgroups' slabs.  256 workgroups of 16 elements; thread (group = tid >> 4, e = tid & 15) adds slabs
+// group * n/16 ... in index order with eight loads in flight, the 16 group sums are then added in group order: a fixed tree,
+// so the result does not depend on timing (one thread per element walking all 512 slabs took 70-96 us: 128 dependent round trips)
+__global__ void __launch_bounds__(256) k_dense_dw_reduce(const float* __restrict__ slabs, int n, float* __restrict__ dW) {
+    __shared__ float part[16][16];
+    const int e = blockIdx.x * 16 + (threadIdx.x & 15), grp = threadIdx.x >> 4;
+    const int per = (n + 15) / 16, z0 = grp * per, z1 = z0 + per < n ? z0 + per : n;
+    float s = 0.f;
+    int z = z0;
+    for (; z + 8 <= z1; z += 8) {
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = slabs[(size_t)(z + k) * 4096 + e];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += v[k];
+    }
+    for (; z < z1; ++z) s += slabs[(size_t)z * 4096 + e];
+    part[grp][threadIdx.x & 15] = s;
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += part[k][threadIdx.x];
+        dW[e] = t;
     }
 }
 
@@ -1457,6 +1536,7 @@ int conv_geom_check(const lisec_conv_geom* c, ConvGeom* g) {
     g->plane_tiles = 0; g->plane_pair = 0; g->queue = nullptr;
     g->tail_w = nullptr; g->tail_out = nullptr;
     g->in_y = nullptr; g->fold_bn = nullptr; g->fold_coef = nullptr; g->fold_relu = 0;
+    g->dw_slabs = nullptr;
     g->pointwise = c->KD * c->KH * c->KW == 1 && ld == 0 && lh == 0 && lw == 0 && c->pd == 0 && c->ph == 0 && c->pw == 0 &&
                    c->Di == c->Do && c->Hi == c->Ho && c->Wi == c->Wo;
     return 0;
@@ -1525,6 +1605,9 @@ int resident_slots() {
     }
     return slots;
 }
+
+// k_dense64 with the Dense weight gradient beside the data gradient holds 64 more accumulators: two workgroups per CU
+int dense_dw_slots() { return 2 * (resident_slots() / 3); }
 
 // Switches `g` to the parity-class row order (conv.h) when the geometry is a 2D transposed gather with stride 2 along
 // h and w over an even map.
@@ -1666,6 +1749,15 @@ int plan_conv(const lisec_conv_geom* c, bool has_in_bn, int flags, const lisec_c
                         "backward statistics need y, its bnstate, a partials buffer, dense rows and Cout % 4 == 0");
         g.bwd_y = extras->bwd_y; g.bwd_bn = extras->bwd_bnstate; g.bwd_relu = extras->bwd_relu ? 1 : 0;
     }
+    if (extras && extras->dense_dw) {
+        LISEC_CHECK_ARG(bwd_stats && sk && !has_in_bn && !out_mask && !extras->in_y && !extras->tail_w && !table_stats &&
+                        !(flags & (LISEC_CONV_ACCUMULATE | LISEC_CONV_TAG_ROOFLINE | LISEC_CONV_IN_RELU)) && g.pointwise &&
+                        g.Cin == 64 && g.Cout == 64 && g.in_stride == 64 && g.out_stride == 64 && tn.dense64 &&
+                        cdiv(g.M, BM) >= dense_dw_slots() && g.M < (1 << 23) && ((uintptr_t)extras->dense_dw & 15) == 0,
+                        "dense_dw: the data gradient of a Dense(64) (1x1x1, 64 -> 64, packed rows) with bwd_y and a backward sink, "
+                        "at least lisec_dense_dw_slabs() tiles of 128 rows, 16-byte aligned slabs");
+        g.dw_slabs = extras->dense_dw;
+    }
     if (extras && extras->in_y) {
         LISEC_CHECK_ARG(extras->in_fold_bnstate && extras->in_fold_coef && c->mode == 1 && !has_in_bn && !(flags & LISEC_CONV_IN_RELU) &&
                         !row_coords && c->Cin % 4 == 0 && ((uintptr_t)extras->in_y & 15) == 0 &&
@@ -1763,15 +1855,18 @@ int plan_conv(const lisec_conv_geom* c, bool has_in_bn, int flags, const lisec_c
     }
     // Dense(64) and its data gradient: the resident-workgroup kernel
     if (tn.dense64 && !g.in_y && g.pointwise && g.Cin == 64 && g.Cout == 64 && g.in_stride == 64 && g.out_stride == 64 && !g.row_coords &&
+        g.M < (1 << 23) &&      // rows x 256 bytes fit a buffer descriptor
         !g.out_mask && !(flags & (LISEC_CONV_ACCUMULATE | LISEC_CONV_TAG_ROOFLINE)) && !table_stats &&
-        (!sk || (sk->kind == LISEC_SINK_BACKWARD && bwd_stats)) && !(bwd_stats && !sk) && ntiles >= resident_slots()) {
+        (!sk || (sk->kind == LISEC_SINK_BACKWARD && bwd_stats)) && !(bwd_stats && !sk) &&
+        ntiles >= (g.dw_slabs ? dense_dw_slots() : resident_slots())) {
         p->dense64 = true;
         p->kernel = KERN_DENSE64;
         p->tile0_tail = ntiles; p->nsplit = 1; p->halo = false; g.plane_pair = 0;
-        p->launch_tiles = resident_slots();
-        if (sk) g.sink.total = (unsigned)resident_slots();
+        p->launch_tiles = g.dw_slabs ? dense_dw_slots() : resident_slots();
+        if (sk) g.sink.total = (unsigned)p->launch_tiles;
         return LISEC_OK;
     }
+    LISEC_CHECK_ARG(!g.dw_slabs, "dense_dw: not served by this call");
     // the halo kernel slices K by whole A tiles: (kd, kh, channel slab) entries
     const int nstage = g.KD * g.KH * cdiv(g.Cin, BK);
     p->halo = halo_geom && p->nsplit <= nstage;
@@ -1833,7 +1928,7 @@ extern "C" int lisec_conv_plan_query(const lisec_conv_geom* c, int has_in_bnstat
     out->double_buffered = p.db && p.nsplit > 1 ? 1 : 0;
     const int ycols = p.half_n ? cdiv(p.g.Cout, 32) : p.nnb;
     int wgs = 0, launches = 0;
-    if (p.kernel == KERN_DENSE64 || p.kernel == KERN_QUEUE) { wgs = resident_slots(); launches = 1; }
+    if (p.kernel == KERN_DENSE64 || p.kernel == KERN_QUEUE) { wgs = p.kernel == KERN_DENSE64 ? p.launch_tiles : resident_slots(); launches = 1; }
     else if (p.wide) { wgs = p.ntiles * (p.g.CoutP / 128) * p.nsplit; launches = 1; }
     else {
         if (p.tile0_tail > 0) { wgs += (p.g.plane_pair ? p.launch_tiles : p.tile0_tail) * ycols; ++launches; }
@@ -1861,6 +1956,15 @@ extern "C" int lisec_conv_forward_masked(const lisec_conv_geom* c, const float* 
     lisec_conv_extras ex = {out_mask, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
     return lisec_conv_forward_ex(c, in, packed_w, bias, in_bnstate, flags, out, &ex, stats_partials, workspace,
                                  workspace_bytes, row_coords, row_count, row_capacity, stream_);
+}
+
+extern "C" int lisec_dense_dw_slabs(void) { return dense_dw_slots(); }
+
+extern "C" int lisec_dense_dw_reduce(const float* slabs, float* dW, lisec_stream_t stream_) {
+    LISEC_CHECK_ARG(slabs && dW, "NULL tensor pointer");
+    LISEC_LAUNCH(k_dense_dw_reduce, dim3(256), dim3(256), 0, static_cast<hipStream_t>(stream_), slabs, dense_dw_slots(), dW);
+    LISEC_LAUNCH_CHECK();
+    return LISEC_OK;
 }
 
 extern "C" int lisec_conv_forward_ex(const lisec_conv_geom* c, const float* in, const float* packed_w,
@@ -1906,11 +2010,13 @@ extern "C" int lisec_conv_forward_ex(const lisec_conv_geom* c, const float* in, 
         return LISEC_OK;
     }
     if (p.dense64) {
-        const int wgs = resident_slots();
+        const int wgs = p.launch_tiles;
         const bool xf_bn = in_bnstate != nullptr, bwd_stats = g.bwd_y != nullptr;
 #define LISEC_D64(X_, B_) LISEC_LAUNCH((k_dense64<X_, B_>), dim3(wgs), dim3(kThreads), lds, st, g, in, packed_w, bias, \
         in_bnstate, flags, out)
-        if (bwd_stats) { if (xf_bn) LISEC_D64(true, true); else LISEC_D64(false, true); }
+        if (g.dw_slabs)
+            LISEC_LAUNCH((k_dense64<false, true, true>), dim3(wgs), dim3(kThreads), lds, st, g, in, packed_w, bias, in_bnstate, flags, out);
+        else if (bwd_stats) { if (xf_bn) LISEC_D64(true, true); else LISEC_D64(false, true); }
         else           { if (xf_bn) LISEC_D64(true, false); else LISEC_D64(false, false); }
 #undef LISEC_D64
         LISEC_LAUNCH_CHECK();

@@ -631,7 +631,7 @@ bool wino_ok(const lisec_conv_geom* c, const ConvGeom& g, bool has_in_bn, int fl
     LISEC_WINO_NEED(has_in_bn || !(flags & LISEC_CONV_IN_RELU), "LISEC_CONV_IN_RELU needs in_bnstate");
     LISEC_WINO_NEED(!(flags & LISEC_CONV_TAG_ROOFLINE) || !has_in_bn, "the roofline tag only without in_bnstate");
     if (ex) {
-        LISEC_WINO_NEED(!ex->in_y && !ex->queue, "no backward on load, no row queue");
+        LISEC_WINO_NEED(!ex->in_y && !ex->queue && !ex->dense_dw, "no backward on load, no row queue, no Dense weight gradient");
         LISEC_WINO_NEED(!ex->tail_w || (ex->tail_out && c->Cout == 64 && c->out_stride == 64 &&
                                         !(flags & (LISEC_CONV_ACCUMULATE | LISEC_CONV_OUT_RELU)) && (!ex->bwd_y || ex->sink) &&
                                         ((uintptr_t)ex->tail_w & 15) == 0),

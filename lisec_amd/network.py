@@ -208,6 +208,8 @@ class LisecNet:
         self._early_from = None
         self.dense_wgrad_late = _lib.knob("dense_wgrad_late", True)   # Dense weight gradient behind the block's ring weight gradient
         self.mid_wgrad_first = _lib.knob("mid_wgrad_first", True)   # ring weight gradient enqueued before the block's data gradient
+        self.dense_dw = _lib.knob("dense_dw", True)      # Dense(64) weight gradients ride on the Dense data gradients
+        self.dense_dw_slabs = {}                         # middle block -> slabs of lisec_conv_extras.dense_dw
         self.fuse_dense_bwd = _lib.knob("fuse_dense_bwd", True)   # Dense(64) data gradients ride on the tile of the block above
         self.chain_first = _lib.knob("chain_first", True)      # head phase: the chain's contraction is enqueued before the leaves
         self._fwd_events = {}
@@ -591,6 +593,14 @@ class LisecNet:
             if mids:
                 shared = torch.empty(max(ops.wgrad_winograd_workspace_bytes(c.g) for c in mids), dtype=torch.uint8, device=dev)
                 self.wino_wgrad_ws = {c.name: shared for c in mids}
+        # Dense(64) weight gradients carried by the Dense data gradients (dense_dw): one slab buffer per middle block -- the sum
+        # runs on the second stream, possibly after the next block's data gradient has started writing its own
+        self.dense_dw_slabs = {}
+        if self.dense_dw:
+            nslabs = ops.dense_dw_slabs()
+            for L in self.layers:
+                if L["kind"] == "mid" and (L["conv"].M + 127) // 128 >= nslabs:
+                    self.dense_dw_slabs[L["name"]] = torch.empty(nslabs * 4096, dtype=torch.float32, device=dev)
         self._packed_t_version = -1
         self._train_ready = True
 
@@ -970,7 +980,11 @@ class LisecNet:
                 # workgroups per CU and waited 474 us in the queue IN FRONT of the block's ring weight gradient: behind it
                 # (dense_wgrad_late) the ring kernel starts as soon as its gradient exists
                 late_dense = self.dense_wgrad_late and self.mid_wgrad_first and L["src"] != "grid"
-                if not late_dense:
+                # the Dense data gradient below reads both operands of the Dense weight gradient: it carries it (dense_dw)
+                carried = n not in fused_dense and n in self.dense_dw_slabs
+                if carried:
+                    late_dense = False
+                elif not late_dense:
                     on_side(dense_wg)
                 # Dense data gradient; its store also reduces the statistics of the BatchNormalization under it
                 if n in fused_dense:
@@ -978,7 +992,10 @@ class LisecNet:
                 else:
                     msink = self._bwd_sink(c.bn, 64, c.M)
                     ops.conv_forward(self.dgeom[dn.name], d[n + ".u"], self.packed_t[dn.name][0], d[n + ".z"],
-                                     bwd=(a[n + ".y"], self.bnstate[c.bn], False), sink=msink)
+                                     bwd=(a[n + ".y"], self.bnstate[c.bn], False), sink=msink,
+                                     dense_dw=self.dense_dw_slabs[n] if carried else None)
+                    if carried:
+                        on_side(lambda n=n, dn=dn: ops.dense_dw_reduce(self.dense_dw_slabs[n], p.grad_view(G, dn.wname)))
                 if L["src"] != "grid":
                     ops.bn_backward_apply_coef(d[n + ".z"], 64, a[n + ".y"], self.bnstate[c.bn], c.M, 64, False, msink.coef,
                                                d[n + ".z"])

@@ -141,7 +141,7 @@ def _fold_fields(fold):
 
 
 def conv_forward(g, x, wp, out, bias=None, in_bn=None, flags=0, stats=None, splitk=True, rows=None, out_mask=None,
-                 bwd=None, sink=None, ws_tag="main", queue=None, tail=None, fold=None):
+                 bwd=None, sink=None, ws_tag="main", queue=None, tail=None, fold=None, dense_dw=None):
     """rows: optional (row_coords int32 (cap,3), row_count int32 device scalar, capacity) row list.
     out_mask: optional tensor laid out like `out`; values are stored as 0 where out_mask <= 0.
     bwd: optional (y, bnstate, relu): `out` is a gradient about to cross that BatchNormalization(+ReLU) backwards and
@@ -152,20 +152,33 @@ def conv_forward(g, x, wp, out, bias=None, in_bn=None, flags=0, stats=None, spli
     tail: optional (packed 64 x 64 kernel, out2): out2 = out (as stored) @ kernel rides on the tile; bwd / sink then describe
     out2 (lisec_conv_extras.tail_w).
     fold: optional (y, bnstate, coef, relu): x is a gradient about to cross that BatchNormalization(+ReLU) backwards and the
-    apply pass runs on load (lisec_conv_extras.in_y)."""
+    apply pass runs on load (lisec_conv_extras.in_y).
+    dense_dw: optional float32 tensor of dense_dw_slabs() * 4096 elements: the call is a Dense(64)'s data gradient (bwd + sink)
+    and also leaves the per-workgroup slabs of the Dense's weight gradient there (lisec_conv_extras.dense_dw; dense_dw_reduce)."""
     rc, rn, cap = rows if rows is not None else (None, None, 0)
     ws = conv_workspace(g, out.device, cap, ws_tag) if splitk else None
     ex = _lib.ConvExtras(_lib.ptr(out_mask), _lib.ptr(bwd[0]) if bwd is not None else None,
                          _lib.ptr(bwd[1]) if bwd is not None else None, 1 if (bwd is not None and bwd[2]) else 0,
                          sink.ref if sink is not None else None, _lib.ptr(queue),
                          _lib.ptr(tail[0]) if tail is not None else None, _lib.ptr(tail[1]) if tail is not None else None,
-                         *_fold_fields(fold))
+                         *_fold_fields(fold), _lib.ptr(dense_dw))
     _lib.check(_lib.load().lisec_conv_forward_ex(ctypes.byref(g), _lib.ptr(x), _lib.ptr(wp), _lib.ptr(bias),
                                                  _lib.ptr(in_bn), flags, _lib.ptr(out), ctypes.byref(ex),
                                                  _lib.ptr(stats), _lib.ptr(ws),
                                                  ws.numel() if ws is not None else 0,
                                                  _lib.ptr(rc), _lib.ptr(rn), cap, _lib.current_stream()))
     return out
+
+
+def dense_dw_slabs():
+    """Slabs (of 64 x 64 floats) a conv_forward(..., dense_dw=) call writes (lisec_dense_dw_slabs)."""
+    return _lib.load().lisec_dense_dw_slabs()
+
+
+def dense_dw_reduce(slabs, dW):
+    """dW (64, 64) = the slabs of a conv_forward(..., dense_dw=slabs) call summed in index order (lisec_dense_dw_reduce)."""
+    _lib.check(_lib.load().lisec_dense_dw_reduce(_lib.ptr(slabs), _lib.ptr(dW), _lib.current_stream()))
+    return dW
 
 
 def winograd_packed_floats(KD, K, N):
@@ -208,7 +221,7 @@ def conv_forward_winograd(g, x, wu, out, bias=None, in_bn=None, flags=0, out_mas
 
 
 def conv_plan(g, in_bn=False, flags=0, stats=False, splitk=True, rows_capacity=0, out_mask=None, bwd=None, sink=None,
-              queue=None, tail=None, fold=None):
+              queue=None, tail=None, fold=None, dense_dw=None):
     """The launch plan conv_forward(...) with the same arguments runs (lisec_conv_plan_query), as a dict."""
     lib = _lib.load()
     ws_bytes = 0
@@ -219,7 +232,7 @@ def conv_plan(g, in_bn=False, flags=0, stats=False, splitk=True, rows_capacity=0
                          _lib.ptr(bwd[1]) if bwd is not None else None, 1 if (bwd is not None and bwd[2]) else 0,
                          sink.ref if sink is not None else None, _lib.ptr(queue),
                          _lib.ptr(tail[0]) if tail is not None else None, _lib.ptr(tail[1]) if tail is not None else None,
-                         *_fold_fields(fold))
+                         *_fold_fields(fold), _lib.ptr(dense_dw))
     plan = _lib.ConvPlan()
     _lib.check(lib.lisec_conv_plan_query(ctypes.byref(g), 1 if in_bn else 0, flags, ctypes.byref(ex), 1 if stats else 0,
                                          ws_bytes, 1 if rows_capacity > 0 else 0, rows_capacity, ctypes.byref(plan)))

@@ -373,6 +373,66 @@ def test_dense64_resident_kernel_forward_and_data_gradient():
     assert np.abs(dgamma.cpu().numpy() - (r * yhat).sum(0)).max() <= 4 * tol_s
 
 
+@pytest.mark.parametrize("dims,relu", [((1, H, W), False), ((2, H, W), False), ((1, H - 1, W + 1), True)])
+def test_dense64_data_gradient_carries_the_weight_gradient(dims, relu):
+    """Dense(64) backwards in ONE pass over the two maps (model_training.py:195; what fit() derives for the Dense kernel, :299):
+    the data-gradient call reads the gradient rows (its A operand) and the rows of y (its backward statistics), which are the
+    two operands of dW = bn(y)^T du -- lisec_conv_extras.dense_dw.  Against the fp64 oracle, against lisec_conv_wgrad, bit for
+    bit against itself; the ragged case ends in a partial tile."""
+    from lisec_amd import ops, _lib
+    from oracle import conv_ref
+    dev = torch.device("cuda")
+    rng = np.random.default_rng(dims[0] * 7 + dims[1])
+    M = dims[0] * dims[1] * dims[2]
+    y = rng.normal(0, 1, (*dims, 64)).astype(np.float32)
+    du = rng.normal(0, 1, (*dims, 64)).astype(np.float32)
+    Wt = (rng.normal(0, 1, (1, 64, 64)) / 8).astype(np.float32)
+    bn_dev, bn_ref = make_bn(rng, 64, dev)
+    g = ops.geom(0, dims, dims, (1, 1, 1), (1, 1, 1), (0, 0, 0), 64, 64)
+    wpt = ops.pack_weights(torch.from_numpy(Wt).to(dev), 1, 64, 64, 0, 1, 64)
+    yd, dud = torch.from_numpy(y).to(dev), torch.from_numpy(du).to(dev)
+    n = ops.dense_dw_slabs()
+    assert n == 512
+    results = []
+    for rep in range(2):
+        dgamma, dbeta = torch.zeros(64, device=dev), torch.zeros(64, device=dev)
+        sink = ops.BnSink(64, M, dev, dgamma=dgamma, dbeta=dbeta)
+        slabs = torch.full((n * 4096,), float("nan"), device=dev)
+        dz = torch.empty(*dims, 64, device=dev)
+        dW = torch.full((64, 64), float("nan"), device=dev)
+        check_plan(ops.conv_plan(g, bwd=(yd, bn_dev, relu), sink=sink, dense_dw=slabs), dict(kernel="dense64", workgroups=n))
+        ops.conv_forward(g, dud, wpt, dz, bwd=(yd, bn_dev, relu), sink=sink, dense_dw=slabs)
+        ops.dense_dw_reduce(slabs, dW)
+        torch.cuda.synchronize()
+        results.append((dz.cpu().numpy(), dW.cpu().numpy(), dgamma.cpu().numpy(), dbeta.cpu().numpy()))
+    for a, b in zip(results[0], results[1]):
+        assert np.array_equal(a, b)
+    dz_h, dW_h, dgamma_h, dbeta_h = results[0]
+    ref_dz = conv_ref.conv_forward(du, np.transpose(Wt, (0, 2, 1)), dims, (1, 1, 1), (1, 1, 1), (0, 0, 0))
+    assert rel_l2(dz_h, ref_dz) <= TOL
+    ref_dW = conv_ref.conv_wgrad(y, du, dims, (1, 1, 1), (1, 1, 1), (0, 0, 0), mode=0, in_bn=bn_ref, relu=relu)
+    e = rel_l2(dW_h[None], ref_dW, note="Dense weight gradient beside the data gradient")
+    assert e <= TOL_W, f"relative L2 {e:.2e}"
+    ws = torch.zeros(ops.wgrad_workspace_bytes(g), dtype=torch.uint8, device=dev)
+    dW2 = torch.empty(1, 64, 64, device=dev)
+    ops.conv_wgrad(g, yd, dud, dW2, ws, in_bn=bn_dev, flags=ops.IN_RELU if relu else 0)
+    assert rel_l2(dW_h[None], dW2.cpu().numpy()) <= TOL_W
+    st = bn_dev.cpu().numpy().astype(np.float64)
+    yhat = (y.astype(np.float64).reshape(M, 64) - st[128:192]) * st[192:]
+    r = ref_dz.reshape(M, 64)
+    if relu:
+        r = r * ((y.astype(np.float64).reshape(M, 64) * st[:64] + st[64:128]) > 0)
+    tol_s = 3e-6 * np.sqrt(M) * np.abs(r).max()
+    assert np.abs(dbeta_h - r.sum(0)).max() <= tol_s
+    assert np.abs(dgamma_h - (r * yhat).sum(0)).max() <= 4 * tol_s
+    # refused where the call is not that data gradient: too few tiles, no backward statistics
+    small = ops.geom(0, (1, 100, 200), (1, 100, 200), (1, 1, 1), (1, 1, 1), (0, 0, 0), 64, 64)
+    with pytest.raises(_lib.LisecError):
+        ops.conv_forward(small, dud, wpt, dz, bwd=(yd, bn_dev, relu), sink=sink, dense_dw=slabs)
+    with pytest.raises(_lib.LisecError):
+        ops.conv_forward(g, dud, wpt, dz, dense_dw=slabs)
+
+
 @pytest.mark.parametrize("cap,expect_kernel", [(20000, "igemm"), (120000, "queue")])
 def test_first_conv3d_row_list_gradients(cap, expect_kernel):
     """Exact sparse backward of the first Conv3D (model_training.py:236): its data gradient evaluated only at the occupied
