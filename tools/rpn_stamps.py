@@ -111,4 +111,7 @@ if __name__ == "__main__":
     case("rpn3.conv1 256->256 (1250)", 0, (1, 25, 50), (1, 25, 50), (1, 3, 3), (1, 1, 1), (0, 1, 1), 256, 256)
     case("rpn3.conv1 dgrad (1250)", 1, (1, 25, 50), (1, 25, 50), (1, 3, 3), (1, 1, 1), (0, 1, 1), 256, 256, in_bn=False, sink=False)
     case("rpn2.conv1 dgrad (5000)", 1, (1, 50, 100), (1, 50, 100), (1, 3, 3), (1, 1, 1), (0, 1, 1), 128, 128, in_bn=False, sink=False)
+    case("rpn1.conv0 s2 dgrad (80000)", 1, (1, 100, 200), (1, 200, 400), (1, 3, 3), (1, 2, 2), (0, 1, 1), 128, 64, in_bn=False, sink=False)
+    case("rpn2.conv0 s2 dgrad (20000)", 1, (1, 50, 100), (1, 100, 200), (1, 3, 3), (1, 2, 2), (0, 1, 1), 128, 128, in_bn=False, sink=False)
+    case("rpn3.conv0 s2 dgrad (5000)", 1, (1, 25, 50), (1, 50, 100), (1, 3, 3), (1, 2, 2), (0, 1, 1), 256, 128, in_bn=False, sink=False)
     case("up1 deconv k3s1 128->256", 1, (1, 100, 200), (1, 100, 200), (1, 3, 3), (1, 1, 1), (0, 1, 1), 128, 256, sink=False)

@@ -1,5 +1,5 @@
 #!/bin/bash
-# kernel trace of a few steps -> step timeline + anatomy (no PMC passes):  tools/_trace_only.sh tag
+# kernel trace of a few steps -> step timeline + anatomy (no PMC passes):  tools/step_trace.sh tag
 tag=${1:-x}
 R=$(pwd)
 cd /tmp && export TMPDIR=/tmp

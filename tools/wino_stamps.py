@@ -46,7 +46,9 @@ def case(name, mode, ind, outd, KD, sd, pd, cin, cout, flags=0):
 
 if __name__ == "__main__":
     H, W = 200, 400
-    for fl in (0, 0x10000, 0x40000, 0x50000, 0x60000):
+    for fl in ((0,) if len(sys.argv) > 1 else (0, 0x10000, 0x40000, 0x50000, 0x60000)):
         case("mid2 fwd", 0, (4, H, W), (2, H, W), 3, 1, 0, 64, 64, fl)
+    case("mid3 fwd", 0, (2, H, W), (1, H, W), 3, 2, 1, 64, 64)
+    case("mid3 dgrad", 1, (1, H, W), (2, H, W), 3, 2, 1, 64, 64)
     case("mid2 dgrad", 1, (2, H, W), (4, H, W), 3, 1, 0, 64, 64)
     case("rpn1.conv1 fwd", 0, (1, 100, 200), (1, 100, 200), 1, 1, 0, 128, 128)
