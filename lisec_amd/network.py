@@ -208,6 +208,7 @@ class LisecNet:
         self._early_from = None
         self.dense_wgrad_late = _lib.knob("dense_wgrad_late", True)   # Dense weight gradient behind the block's ring weight gradient
         self.mid_wgrad_first = _lib.knob("mid_wgrad_first", True)   # ring weight gradient enqueued before the block's data gradient
+        self.pack_mid_first = _lib.knob("pack_mid_first", True)   # the forward waits for the middle blocks' repack only
         self.dense_dw = _lib.knob("dense_dw", True)      # Dense(64) weight gradients ride on the Dense data gradients
         self.dense_dw_slabs = {}                         # middle block -> slabs of lisec_conv_extras.dense_dw
         self.fuse_dense_bwd = _lib.knob("fuse_dense_bwd", True)   # Dense(64) data gradients ride on the tile of the block above
@@ -248,26 +249,36 @@ class LisecNet:
                                               (p.view("reg.bias"), self.head_b[2:])], self.device)
         self._head_merge.run()
         if getattr(self, "_pack_table", None) is None:
-            entries, late = [], []
+            entries, rest, late = [], [], []
             for L in self.layers:
                 for key in ("conv", "dense"):
                     if key in L:
                         c = L[key]
-                        (entries if c.wname else late).append(
+                        (late if not c.wname else entries if L["kind"] == "mid" else rest).append(
                             ((p.view(c.wname) if c.wname else L["Wc"]), self.packed[c.name]) + tuple(c.pack))
             self._pack_table = ops.PackTable(entries, self.device)
+            self._pack_table_rest = ops.PackTable(rest, self.device)
             self._pack_table_wc = ops.PackTable(late, self.device) if late else None
-        # the kernels that are variables first: the first contraction of the forward pass waits for these only
-        # (after_main records that point when the repack runs early on the second stream); the composite kernels of the
-        # collapsed heads -- three compose launches in front of their pack -- are not read before the first branch
+
+        def wino_packs(mid):
+            for L in self.layers:
+                c = L["conv"]
+                if c.name in self.packed_wu and (L["kind"] == "mid") == mid:
+                    g = c.g
+                    ops.pack_weights_winograd(p.view(c.wname), g.KD, g.Cin, g.Cout, g.Cin * g.Cout, g.Cout, 1,
+                                              out=self.packed_wu[c.name])
+        # the kernels of the middle blocks first: the first contraction of the forward pass waits for these only (after_main
+        # records that point when the repack runs early on the second stream: 6 small kernels, done before the VFE is -- with
+        # every variable kernel in front of that point the main stream stood 22 us per step).  The RPN's kernels, the composite
+        # kernels of the collapsed heads -- three compose launches in front of their pack -- and the transposed set follow;
+        # the first Conv2D of the RPN, ~0.5 ms into the step, waits for all of them (_pack_late)
         self._pack_table.run()
-        for L in self.layers:
-            c = L["conv"]
-            if c.name in self.packed_wu:
-                g = c.g
-                ops.pack_weights_winograd(p.view(c.wname), g.KD, g.Cin, g.Cout, g.Cin * g.Cout, g.Cout, 1,
-                                          out=self.packed_wu[c.name])
-        if after_main is not None:
+        wino_packs(True)
+        if after_main is not None and self.pack_mid_first:
+            after_main()
+        self._pack_table_rest.run()
+        wino_packs(False)
+        if after_main is not None and not self.pack_mid_first:
             after_main()
         if self.compose_head:
             self._compose_all()
@@ -377,6 +388,7 @@ class LisecNet:
             _lib.pin_stream(prev_pin)
 
     def _forward(self, sample, training):
+        self._mark("step:begin")
         pending = getattr(self, "_pack_pending", False)
         if pending and (self._packed_version != (self.params_version, self.params.version)):
             self._wait(self._pack_late, torch.cuda.current_stream())     # variables changed since the early repack
@@ -395,6 +407,7 @@ class LisecNet:
             self.vfe.forward(sample, training, dense=False)
         else:
             self.vfe.forward(sample, training, out=self.dense_grid(rewrite=False))
+        self._mark("step:vfe done")
         if pending:
             # the repack of this step's weights was enqueued on the second stream right after the last optimizer step
             # and ran under this sweep's voxeliser and VFE; the first contraction is the first reader
@@ -416,6 +429,10 @@ class LisecNet:
                     self._run_conv(L["conv"], a[L["src"]], a[n + ".y"], training)
                 self._run_conv(L["dense"], a[n + ".y"], a[n + ".u"], training)
             elif L["kind"] == "conv":
+                if getattr(self, "_late_pending", False):
+                    # first reader of a kernel repacked behind the middle blocks' (see _pack_all)
+                    self._wait(self._pack_late, torch.cuda.current_stream())
+                    self._late_pending = False
                 if L["src"] == "fold":
                     ops.fold_depth(a[self.fold_src], a["fold"], self.dprime, self.H * self.W, 64)
                 self._run_conv(L["conv"], a[L["src"]], a[L["dst"]], training)
