@@ -209,7 +209,8 @@ class LisecNet:
         self.dense_wgrad_late = _lib.knob("dense_wgrad_late", True)   # Dense weight gradient behind the block's ring weight gradient
         self.mid_wgrad_first = _lib.knob("mid_wgrad_first", True)   # ring weight gradient enqueued before the block's data gradient
         self.pack_mid_first = _lib.knob("pack_mid_first", True)   # the forward waits for the middle blocks' repack only
-        self.dense_dw = _lib.knob("dense_dw", True)      # Dense(64) weight gradients ride on the Dense data gradients
+        self.dense_dw = _lib.knob("dense_dw", True)
+        self.dense_dw_late = _lib.knob("dense_dw_late", True)   # their slab sums behind the last weight gradient of the second stream      # Dense(64) weight gradients ride on the Dense data gradients
         self.dense_dw_slabs = {}                         # middle block -> slabs of lisec_conv_extras.dense_dw
         self.fuse_dense_bwd = _lib.knob("fuse_dense_bwd", True)   # Dense(64) data gradients ride on the tile of the block above
         self.chain_first = _lib.knob("chain_first", True)      # head phase: the chain's contraction is enqueued before the leaves
@@ -839,6 +840,7 @@ class LisecNet:
 
         early_dst = {}                         # gradient buffer -> event behind a contribution made on the second stream
         fused_dense = {}                       # middle block -> backward sink of a Dense data gradient that rode on a tile
+        late_reduces = []                      # slab sums of the carried Dense weight gradients (dense_dw_late)
 
         def dgrad_into(c, dy, dst_name, ws_tag="main", fold=None):
             ev = early_dst.pop(dst_name, None) if ws_tag == "main" else None
@@ -1012,7 +1014,14 @@ class LisecNet:
                                      bwd=(a[n + ".y"], self.bnstate[c.bn], False), sink=msink,
                                      dense_dw=self.dense_dw_slabs[n] if carried else None)
                     if carried:
-                        on_side(lambda n=n, dn=dn: ops.dense_dw_reduce(self.dense_dw_slabs[n], p.grad_view(G, dn.wname)))
+                        reduce = lambda n=n, dn=dn: ops.dense_dw_reduce(self.dense_dw_slabs[n], p.grad_view(G, dn.wname))
+                        # the 8 MB slab sum finds no registers beside the Winograd workgroups (46 - 60 us in the step for 6 us of
+                        # work) and the second stream is in order: enqueued right here it held the block's weight gradient back;
+                        # nothing reads the result before the optimizer, so the three sums go behind the last weight gradient
+                        if self.dense_dw_late:
+                            late_reduces.append(reduce)
+                        else:
+                            on_side(reduce)
                 if L["src"] != "grid":
                     ops.bn_backward_apply_coef(d[n + ".z"], 64, a[n + ".y"], self.bnstate[c.bn], c.M, 64, False, msink.coef,
                                                d[n + ".z"])
@@ -1059,6 +1068,8 @@ class LisecNet:
                         on_side(wg)
         # ---- VFE -----------------------------------------------------------------------------------
         self._mark("bwd:before vfe")
+        for fn in late_reduces:
+            pending.append((fn, False))
         flush_side()
         self.vfe.backward(None, G, dout_rows=self.dout_rows, g_all=self.g_all)
         if self._join_event is None:
